@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: M points/s for forward + pullback, 10 M 3-D points -> 256^3 fp32 grid
+(BASELINE.json metric; config C3 = `configs[2]`), one pose per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one raster! + one raster_pullback! of this rank's pose over the full point
+cloud, inputs already resident in HBM.  At N > 1 the global problem is a batch of N poses
+sharded one per rank (weak scaling) and each step ends with the all-reduce(sum) of the
+fused [ds_dpoints | ds_dpoint_weight] buffer -- the only exchange the batched pullback has
+(/root/reference/src/raster_pullback.jl:141,146).
+
+Besides the contract's JSON line fields this prints `roofline` (dominant kernel, HIP-event
+timed on the stream the kernels run on) and, on rank 0 at N = 1, `cpu_baseline` (the CPU
+oracle's threaded port of the reference algorithm on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (P, n_in, grid, dtype)
+    "C2": (1_000_000, 3, (128, 128, 128), "f32"),
+    "C3": (10_000_000, 3, (256, 256, 256), "f32"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0  # measured float4 copy ceiling (same guide)
+
+
+def synth_inputs(cfg, rank, device, order):
+    """points 0.4*N(0,I) seed 0 (test/data.jl:22,27); rotation uniform on
+    SO(3), translation 0.1*N(0,I), seed 1 (+rank); ds_dout N(0,1) seed 2 (+rank)."""
+    import torch
+
+    from tests import data as D
+
+    P, n_in, grid, dt = CONFIGS[cfg]
+    npdt = np.float32 if dt == "f32" else np.float64
+    rng = np.random.default_rng(0)
+    pts = (0.4 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
+    if order == "morton":
+        pts = pts[morton_order(pts)]
+    prng = np.random.default_rng(1 + rank)
+    R = D.random_rotations(prng, 1, n_in)[:, : len(grid), :].astype(npdt)
+    t = (0.1 * prng.normal(size=(1, len(grid)))).astype(npdt)
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2 + rank)
+    g = torch.randn((1,) + tuple(reversed(grid)), device=device, dtype=tdt, generator=gen)
+    g = g.permute(*reversed(range(g.ndim)))  # [i1, i2, i3, b] view, reference memory order
+    to = lambda a: torch.as_tensor(a, device=device)
+    return dict(points=to(pts), R=to(R), t=to(t), ds_dout=g, np_points=pts, np_R=R, np_t=t)
+
+
+def morton_order(pts, bits=10):
+    """Pose-independent spatial pre-sort of the model-frame points (Morton / Z-order)."""
+    q = np.clip(((pts * 0.5 + 0.5) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    code = np.zeros(len(pts), dtype=np.int64)
+    for b in range(bits):
+        for d in range(pts.shape[1]):
+            code |= ((q[:, d] >> b) & 1) << (pts.shape[1] * b + d)
+    return np.argsort(code, kind="stable")
+
+
+def algorithmic_bytes(cfg, with_point_weight=False):
+    """A_fwd = s[P(N_in+w) + B G]; A_bwd = s[P(N_in+w) + B G + P N_in + P]."""
+    P, n_in, grid, dt = CONFIGS[cfg]
+    s = 4 if dt == "f32" else 8
+    G = int(np.prod(grid))
+    w = 1 if with_point_weight else 0
+    a_fwd = s * (P * (n_in + w) + G)
+    a_bwd = s * (P * (n_in + w) + G + P * n_in + P)
+    return a_fwd, a_bwd
+
+
+def cpu_baseline(cfg, inp, budget_s=20.0):
+    """Threaded CPU port of the reference algorithm (oracle/, kind "port") on a bounded
+    sample: the first `n` points of the same cloud into the same grid, n chosen so the
+    fwd+bwd pair takes roughly `budget_s` seconds."""
+    from oracle import oracle
+
+    P, n_in, grid, dt = CONFIGS[cfg]
+    npdt = np.float32 if dt == "f32" else np.float64
+    threads = oracle.max_threads()
+    g = np.asfortranarray(inp["ds_dout"].cpu().numpy())
+
+    def run(n):
+        t0 = time.perf_counter()
+        oracle.raster(grid, inp["np_points"][:n], inp["np_R"], inp["np_t"], dtype=npdt, threaded=True)
+        t1 = time.perf_counter()
+        oracle.raster_pullback(g, inp["np_points"][:n], inp["np_R"], inp["np_t"], dtype=npdt,
+                               threaded=True)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    n = min(P, 200_000)
+    f, b = run(n)  # calibration (includes the fixed grid fill / grid sum cost)
+    rate = n / max(f + b, 1e-9)
+    n2 = int(min(P, max(n, rate * budget_s)))
+    f, b = run(n2)
+    return {
+        "value": round(n2 / (f + b) / 1e6, 4), "unit": "M points/s", "cores": threads,
+        "kind": "port",
+        "sample": f"first {n2} of {P} points, same grid/pose; fwd {f:.2f}s on {threads} threads "
+                  f"(atomic scatter), bwd {b:.2f}s on 1 thread (the reference's batched pullback "
+                  f"is serial within a pose, src/raster_pullback.jl:39,115-139)",
+        "fwd_M_points_s": round(n2 / f / 1e6, 4), "bwd_M_points_s": round(n2 / b / 1e6, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled"])
+    ap.add_argument("--order", default="random", choices=["random", "morton"],
+                    help="point order in memory: as generated, or pre-sorted (pose-independent)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+
+    import dpr_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    P, n_in, grid, dt = CONFIGS[args.config]
+    inp = synth_inputs(args.config, rank, device, args.order)
+    tdt = inp["points"].dtype
+    out = dpr_amd.empty_grid(grid, 1, tdt, device)
+    fused = torch.empty(P * (n_in + 1), dtype=tdt, device=device)
+    d_pts = fused[: P * n_in].view(P, n_in)
+    d_pw = fused[P * n_in:]
+    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P, 1, n_in, tdt, args.algo),
+                   dpr_amd.workspace_bytes("pullback", grid, P, 1, n_in, tdt, args.algo))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
+
+    def fwd():
+        dpr_amd.raster_(out, inp["points"], inp["R"], inp["t"], algo=args.algo, workspace=ws)
+
+    def bwd():
+        dpr_amd.raster_pullback_(inp["ds_dout"], inp["points"], inp["R"], inp["t"],
+                                 ds_dpoints=d_pts, ds_dpoint_weight=d_pw, algo=args.algo,
+                                 workspace=ws)
+
+    def step():
+        fwd()
+        bwd()
+        if world > 1:
+            dist.all_reduce(fused, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * P / (elapsed / args.steps) / 1e6  # M points/s, whole job
+
+    # ---- per-pass device time with HIP events on the launch stream (torch's current stream)
+    def event_time(fn, reps):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
+
+    reps = max(5, min(args.steps, 20))
+    ms_fwd = event_time(fwd, reps)
+    ms_bwd = event_time(bwd, reps)
+    a_fwd, a_bwd = algorithmic_bytes(args.config)
+    stages = dpr_amd.stage_times(fwd, bwd, reps) if hasattr(dpr_amd, "stage_times") else None
+
+    roof = {
+        "bound": "hbm", "kernel": "raster! (all launches of one forward call)",
+        "achieved": round(a_fwd / (ms_fwd * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+        "algorithmic_bytes": a_fwd, "ms": round(ms_fwd, 4),
+        "frac_of_measured_copy_peak": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_COPY_GBS, 4),
+        "pullback": {"algorithmic_bytes": a_bwd, "ms": round(ms_bwd, 4),
+                     "achieved": round(a_bwd / (ms_bwd * 1e-3) / 1e9, 2),
+                     "frac": round(a_bwd / (ms_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    if stages:
+        roof["stages"] = stages
+
+    line = {
+        "metric": "M points/s fwd+bwd, 10M pts→256³ grid; HBM GB/s vs roofline",
+        "value": round(value, 3), "unit": "M points/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+        "config": {"workload": f"{args.config}: {P} 3-D points (0.4*N(0,I), {args.order} order) -> "
+                               f"{'x'.join(map(str, grid))} {dt} grid, one pose per GPU, "
+                               f"raster! + raster_pullback!",
+                   "algo": args.algo, "poses_global": world, "point_order": args.order,
+                   "exchange": "all-reduce(sum) of [ds_dpoints|ds_dpoint_weight]" if world > 1 else "none"},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.config, inp, args.cpu_budget)
+    if rank == 0:
+        print(json.dumps(line, ensure_ascii=False))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,16 @@
+"""MI355X-native `raster` / `raster_pullback!` hot path of DiffPointRasterisation.jl.
+
+Exports mirror the reference module (`export raster, raster!, raster_pullback!`,
+/root/reference/src/DiffPointRasterisation.jl:17); `!` becomes a trailing underscore.
+"""
+from . import _lib
+from ._lib import DprError, build, lib
+from .interface import (DimensionMismatch, PullbackResult, empty_grid, raster, raster_,
+                        raster_pullback_, to_grid_layout, workspace_bytes)
+from .sharded import raster_pullback_sharded_, raster_sharded, shard_range
+
+__all__ = [
+    "raster", "raster_", "raster_pullback_", "PullbackResult", "DimensionMismatch", "DprError",
+    "empty_grid", "to_grid_layout", "workspace_bytes", "build", "lib",
+    "raster_sharded", "raster_pullback_sharded_", "shard_range",
+]

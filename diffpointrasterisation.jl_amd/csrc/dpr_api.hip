@@ -1,0 +1,293 @@
+// C-ABI entry points of libdpr (declared in include/dpr.h) and host-side dispatch.
+// Host checks mirror the reference's @argcheck's (src/raster.jl:14-23,
+// ext/DiffPointRasterisationCUDAExt.jl:246-262) but report through status codes.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/dpr.h"
+#include "dpr_kernels_atomic.h"
+#include "dpr_tiled.h"
+
+namespace dpr {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define DPR_HIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+static bool dims_supported(int n_in, int n_out) {
+    return (n_in == 2 && n_out == 2) || (n_in == 3 && n_out == 3) || (n_in == 3 && n_out == 2);
+}
+
+static int check_common(int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B,
+                        int64_t* G_out) {
+    if (!dims_supported(n_in, n_out))
+        return fail(DPR_ERR_UNSUPPORTED_DIMS,
+                    "unsupported (n_in, n_out) = (%d, %d); supported: (2,2), (3,3), (3,2)", n_in,
+                    n_out);
+    if (!grid) return fail(DPR_ERR_INVALID_ARG, "grid is NULL");
+    if (P < 0 || B < 0) return fail(DPR_ERR_INVALID_ARG, "negative P (%lld) or B (%lld)",
+                                    (long long)P, (long long)B);
+    int64_t G = 1;
+    for (int d = 0; d < n_out; ++d) {
+        if (grid[d] < 1 || grid[d] > 32768)
+            return fail(DPR_ERR_INVALID_ARG, "grid[%d] = %lld out of range [1, 32768]", d,
+                        (long long)grid[d]);
+        G *= grid[d];
+    }
+    if (G > (int64_t)0x7fffffff)
+        return fail(DPR_ERR_INVALID_ARG, "voxels per pose (%lld) exceed 2^31-1", (long long)G);
+    *G_out = G;
+    return DPR_OK;
+}
+
+template <int NO> static GridDesc<NO> make_grid(const int64_t* grid, int64_t G) {
+    GridDesc<NO> gd;
+    for (int d = 0; d < NO; ++d) gd.n[d] = (int)grid[d];
+    gd.G = G;
+    return gd;
+}
+
+static int resolve_algo(int algo, int op, int n_out, int64_t P, int64_t B, int64_t G) {
+    if (algo != DPR_ALGO_AUTO) return algo;
+    return tiled_preferred(op, n_out, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
+}
+
+// ---------------------------------------------------------------- forward
+template <typename T, int NI, int NO>
+static int raster_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                         T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                         const T* ow, const T* pw) {
+    const GridDesc<NO> gd = make_grid<NO>(grid, G);
+    {
+        const int64_t want = (G + kBlock - 1) / kBlock;
+        dim3 g((unsigned)(want < 4096 ? want : 4096), (unsigned)(B < 65535 ? B : 65535));
+        // B > 65535 poses: loop on the host in slabs of 65535
+        for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+            const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
+            g.y = (unsigned)nb;
+            hipLaunchKernelGGL(k_fill_background<T>, g, dim3(kBlock), 0, st, out + b0 * G, G,
+                               bg ? bg + b0 : nullptr);
+        }
+    }
+    if (P > 0) {
+        dim3 g((unsigned)((P + kBlock - 1) / kBlock), (unsigned)(B < 65535 ? B : 65535));
+        hipLaunchKernelGGL((k_fwd_atomic<T, NI, NO>), g, dim3(kBlock), 0, st, gd, P, B, out,
+                           points, rot, trans, ow, pw);
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+template <typename T>
+static int raster_impl(void* stream, int algo, int n_in, int n_out, const int64_t* grid, int64_t P,
+                       int64_t B, T* out, const T* points, const T* rot, const T* trans,
+                       const T* bg, const T* ow, const T* pw, void* ws, size_t ws_bytes) {
+    int64_t G = 0;
+    if (int rc = check_common(n_in, n_out, grid, P, B, &G)) return rc;
+    if (B == 0) return DPR_OK;
+    if (!out) return fail(DPR_ERR_INVALID_ARG, "out is NULL");
+    if (!rot || !trans) return fail(DPR_ERR_INVALID_ARG, "rotation/translation is NULL");
+    if (P > 0 && !points) return fail(DPR_ERR_INVALID_ARG, "points is NULL with P > 0");
+    if ((P + kBlock - 1) / kBlock > 0x7fffffffLL)
+        return fail(DPR_ERR_INVALID_ARG, "P too large");
+    hipStream_t st = (hipStream_t)stream;
+    algo = resolve_algo(algo, DPR_OP_RASTER, n_out, P, B, G);
+#define DPR_CASE(NI, NO)                                                                       \
+    if (n_in == NI && n_out == NO) {                                                           \
+        if (algo == DPR_ALGO_ATOMIC)                                                           \
+            return raster_atomic<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow, \
+                                            pw);                                               \
+        if (algo == DPR_ALGO_TILED)                                                            \
+            return raster_tiled<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow,  \
+                                           pw, ws, ws_bytes);                                  \
+    }
+    DPR_CASE(2, 2)
+    DPR_CASE(3, 3)
+    DPR_CASE(3, 2)
+#undef DPR_CASE
+    return fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
+}
+
+// ---------------------------------------------------------------- pullback
+template <typename T, int NI, int NO>
+static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                           const T* g, const T* points, const T* rot, const T* trans, const T* ow,
+                           const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                           T* d_pw) {
+    const GridDesc<NO> gd = make_grid<NO>(grid, G);
+    DPR_HIP(hipMemsetAsync(d_rot, 0, sizeof(T) * (size_t)(B * NO * NI), st));
+    DPR_HIP(hipMemsetAsync(d_trans, 0, sizeof(T) * (size_t)(B * NO), st));
+    DPR_HIP(hipMemsetAsync(d_ow, 0, sizeof(T) * (size_t)B, st));
+    DPR_HIP(hipMemsetAsync(d_bg, 0, sizeof(T) * (size_t)B, st));
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+        const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
+        int64_t want = (G + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+        if (want * nb > 8192) want = (8192 + nb - 1) / nb;
+        if (want < 1) want = 1;
+        dim3 gg((unsigned)want, (unsigned)nb);
+        hipLaunchKernelGGL(k_grid_sum<T>, gg, dim3(kBlock), 0, st, g + b0 * G, G, d_bg + b0);
+    }
+    if (P > 0) {
+        const int64_t pblocks = (P + kBlock - 1) / kBlock;
+        // enough blocks to fill 256 CUs x 8: split poses into slices when P is small
+        int64_t slices = 1;
+        if (pblocks < 2048 && B > 1) {
+            slices = (2048 + pblocks - 1) / pblocks;
+            if (slices > B) slices = B;
+            if (slices > 65535) slices = 65535;
+        }
+        const int poses_per_slice = (int)((B + slices - 1) / slices);
+        slices = (B + poses_per_slice - 1) / poses_per_slice;
+        const int accumulate = slices > 1;
+        if (accumulate) {
+            DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * NI), st));
+            DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
+        }
+        dim3 gg((unsigned)pblocks, (unsigned)slices);
+        hipLaunchKernelGGL((k_bwd_gather<T, NI, NO>), gg, dim3(kBlock), 0, st, gd, P, B, g, points,
+                           rot, trans, ow, pw, d_pts, d_rot, d_trans, d_ow, d_pw, poses_per_slice,
+                           accumulate);
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+template <typename T>
+static int pullback_impl(void* stream, int algo, int n_in, int n_out, const int64_t* grid,
+                         int64_t P, int64_t B, const T* g, const T* points, const T* rot,
+                         const T* trans, const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans,
+                         T* d_bg, T* d_ow, T* d_pw, void* ws, size_t ws_bytes) {
+    int64_t G = 0;
+    if (int rc = check_common(n_in, n_out, grid, P, B, &G)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (P > 0 && (!d_pts || !d_pw))
+        return fail(DPR_ERR_INVALID_ARG, "ds_dpoints/ds_dpoint_weight is NULL with P > 0");
+    if (P > 0 && !points) return fail(DPR_ERR_INVALID_ARG, "points is NULL with P > 0");
+    if (B == 0) {
+        // no poses: point gradients are empty sums
+        if (P > 0) {
+            DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * n_in), st));
+            DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
+        }
+        return DPR_OK;
+    }
+    if (!g) return fail(DPR_ERR_INVALID_ARG, "ds_dout is NULL");
+    if (!rot || !trans) return fail(DPR_ERR_INVALID_ARG, "rotation/translation is NULL");
+    if (!d_rot || !d_trans || !d_bg || !d_ow)
+        return fail(DPR_ERR_INVALID_ARG, "a per-pose output pointer is NULL");
+    algo = resolve_algo(algo, DPR_OP_PULLBACK, n_out, P, B, G);
+#define DPR_CASE(NI, NO)                                                                         \
+    if (n_in == NI && n_out == NO) {                                                             \
+        if (algo == DPR_ALGO_ATOMIC)                                                             \
+            return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw,   \
+                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw);          \
+        if (algo == DPR_ALGO_TILED)                                                              \
+            return pullback_tiled<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw,    \
+                                             d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
+                                             ws_bytes);                                          \
+    }
+    DPR_CASE(2, 2)
+    DPR_CASE(3, 3)
+    DPR_CASE(3, 2)
+#undef DPR_CASE
+    return fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
+}
+
+template <typename T>
+static size_t workspace_impl(int op, int algo, int n_in, int n_out, const int64_t* grid, int64_t P,
+                             int64_t B) {
+    int64_t G = 0;
+    if (check_common(n_in, n_out, grid, P, B, &G)) return (size_t)-1;
+    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK) {
+        fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
+        return (size_t)-1;
+    }
+    algo = resolve_algo(algo, op, n_out, P, B, G);
+    if (algo == DPR_ALGO_ATOMIC) return 0;
+    if (algo == DPR_ALGO_TILED) return tiled_workspace_bytes(sizeof(T), op, n_in, n_out, grid, P, B);
+    fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
+    return (size_t)-1;
+}
+
+}  // namespace dpr
+
+extern "C" {
+
+int dpr_version(void) { return DPR_VERSION; }
+
+const char* dpr_last_error(void) { return dpr::g_last_error.c_str(); }
+
+size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t* grid,
+                               int64_t P, int64_t B) {
+    return dpr::workspace_impl<float>(op, algo, n_in, n_out, grid, P, B);
+}
+size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t* grid,
+                               int64_t P, int64_t B) {
+    return dpr::workspace_impl<double>(op, algo, n_in, n_out, grid, P, B);
+}
+
+#define DPR_DEFINE(SUF, T)                                                                        \
+    int dpr_raster_ex_##SUF(void* stream, int algo, int n_in, int n_out, const int64_t* grid,     \
+                            int64_t P, int64_t B, T* out, const T* points, const T* rotation,     \
+                            const T* translation, const T* background, const T* out_weight,       \
+                            const T* point_weight, void* workspace, size_t workspace_bytes) {     \
+        return dpr::raster_impl<T>(stream, algo, n_in, n_out, grid, P, B, out, points, rotation,  \
+                                   translation, background, out_weight, point_weight, workspace,  \
+                                   workspace_bytes);                                              \
+    }                                                                                             \
+    int dpr_raster_##SUF(void* stream, int n_in, int n_out, const int64_t* grid, int64_t P,       \
+                         int64_t B, T* out, const T* points, const T* rotation,                   \
+                         const T* translation, const T* background, const T* out_weight,          \
+                         const T* point_weight, void* workspace, size_t workspace_bytes) {        \
+        return dpr::raster_impl<T>(stream, DPR_ALGO_AUTO, n_in, n_out, grid, P, B, out, points,   \
+                                   rotation, translation, background, out_weight, point_weight,   \
+                                   workspace, workspace_bytes);                                   \
+    }                                                                                             \
+    int dpr_raster_pullback_ex_##SUF(                                                             \
+        void* stream, int algo, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B,   \
+        const T* ds_dout, const T* points, const T* rotation, const T* translation,               \
+        const T* out_weight, const T* point_weight, T* ds_dpoints, T* ds_drotation,               \
+        T* ds_dtranslation, T* ds_dbackground, T* ds_dout_weight, T* ds_dpoint_weight,            \
+        void* workspace, size_t workspace_bytes) {                                                \
+        return dpr::pullback_impl<T>(stream, algo, n_in, n_out, grid, P, B, ds_dout, points,      \
+                                     rotation, translation, out_weight, point_weight, ds_dpoints, \
+                                     ds_drotation, ds_dtranslation, ds_dbackground,               \
+                                     ds_dout_weight, ds_dpoint_weight, workspace,                 \
+                                     workspace_bytes);                                            \
+    }                                                                                             \
+    int dpr_raster_pullback_##SUF(                                                                \
+        void* stream, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B,             \
+        const T* ds_dout, const T* points, const T* rotation, const T* translation,               \
+        const T* out_weight, const T* point_weight, T* ds_dpoints, T* ds_drotation,               \
+        T* ds_dtranslation, T* ds_dbackground, T* ds_dout_weight, T* ds_dpoint_weight,            \
+        void* workspace, size_t workspace_bytes) {                                                \
+        return dpr::pullback_impl<T>(stream, DPR_ALGO_AUTO, n_in, n_out, grid, P, B, ds_dout,     \
+                                     points, rotation, translation, out_weight, point_weight,     \
+                                     ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,   \
+                                     ds_dout_weight, ds_dpoint_weight, workspace,                 \
+                                     workspace_bytes);                                            \
+    }
+
+DPR_DEFINE(f32, float)
+DPR_DEFINE(f64, double)
+#undef DPR_DEFINE
+
+}  // extern "C"

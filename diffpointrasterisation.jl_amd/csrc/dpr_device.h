@@ -1,0 +1,156 @@
+// Device-side arithmetic shared by every kernel of libdpr (gfx950 only).
+//
+// The operation ORDER below is the reference's (see the cited lines): the whole
+// library is compiled with -ffp-contract=off so that the fp32 cell choice
+// `ceil(coord - 1/2)` and every per-neighbour weight are bit-identical to the
+// fp32 CPU oracle; only the order in which contributions are summed differs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dpr {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+template <typename T> __device__ __forceinline__ T ceil_t(T x);
+template <> __device__ __forceinline__ float ceil_t<float>(float x) { return ceilf(x); }
+template <> __device__ __forceinline__ double ceil_t<double>(double x) { return ceil(x); }
+
+// Per-pose parameters; read from global memory with wave-uniform addresses
+// (the compiler turns them into scalar loads).
+template <typename T, int NI, int NO> struct Pose {
+    T R[NO * NI];  // column-major N_out x N_in (SMatrix memory order)
+    T t[NO];
+    T ow;
+};
+
+template <typename T, int NI, int NO>
+__device__ __forceinline__ Pose<T, NI, NO> load_pose(const T* __restrict__ rot,
+                                                    const T* __restrict__ trans,
+                                                    const T* __restrict__ ow, int64_t b) {
+    Pose<T, NI, NO> ps;
+#pragma unroll
+    for (int k = 0; k < NO * NI; ++k) ps.R[k] = rot[b * (NO * NI) + k];
+#pragma unroll
+    for (int d = 0; d < NO; ++d) ps.t[d] = trans[b * NO + d];
+    ps.ow = ow ? ow[b] : T(1);
+    return ps;
+}
+
+template <int NO> struct GridDesc {
+    int n[NO];        // voxels per axis
+    int64_t G;        // voxels per pose
+};
+
+// /root/reference/src/raster.jl:85-101 reference_coordinate_and_deltas, with
+// origin = -1 - t (src/raster.jl:53) and scale = n/2 (src/raster.jl:25).
+// ref0 = 0-based index of the LOWER neighbour (may be -1); dlo = deltas[:,1].
+// Returns false when some axis has no in-range neighbour (range test in floating
+// point before the float->int conversion; also rejects NaN/Inf).
+template <typename T, int NI, int NO>
+__device__ __forceinline__ bool ref_and_deltas(const T (&p)[NI], const Pose<T, NI, NO>& ps,
+                                               const GridDesc<NO>& gd, int (&ref0)[NO],
+                                               T (&dlo)[NO]) {
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        T proj = ps.R[d] * p[0];
+#pragma unroll
+        for (int j = 1; j < NI; ++j) proj = proj + ps.R[d + j * NO] * p[j];
+        const T origin = T(-1) - ps.t[d];
+        const T scale = T(gd.n[d]) / T(2);
+        const T coord = (proj - origin) * scale;
+        const T c = coord - T(0.5);
+        ok = ok && (c > T(-1)) && (c <= T(gd.n[d]));
+        const T r = ceil_t<T>(c);
+        ref0[d] = ok ? (int)r - 1 : 0;
+        dlo[d] = coord - (r - T(0.5));
+    }
+    return ok;
+}
+
+// src/raster.jl:103-108 voxel_weight: prod_d deltas[d, mod1(shift_d, 2)] * w;
+// neighbour s has shift_d = bit d of s (src/util.jl:7-8,26-27).
+template <typename T, int NO>
+__device__ __forceinline__ T voxel_weight(const T (&dlo)[NO], int s, T w) {
+    T v = (s & 1) ? dlo[0] : (T(1) - dlo[0]);
+#pragma unroll
+    for (int d = 1; d < NO; ++d) v = v * (((s >> d) & 1) ? dlo[d] : (T(1) - dlo[d]));
+    return v * w;
+}
+
+// src/raster_pullback.jl:150-160 interpolation_weight
+template <typename T, int NO>
+__device__ __forceinline__ T interp_weight(int n, const T (&dlo)[NO], int s) {
+    T v = ((s >> n) & 1) ? T(1) : T(-1);
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+        if (m == n) continue;
+        v *= ((s >> m) & 1) ? dlo[m] : (T(1) - dlo[m]);
+    }
+    return v;
+}
+
+// column-major offset of neighbour s inside one pose, or -1 if out of range
+// (individual drop, src/raster.jl:62 / src/raster_pullback.jl:51)
+template <int NO>
+__device__ __forceinline__ int nbr_offset(const int (&ref0)[NO], int s, const GridDesc<NO>& gd) {
+    int off = 0, stride = 1;
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        const int i = ref0[d] + ((s >> d) & 1);
+        ok = ok && (i >= 0) && (i < gd.n[d]);
+        off += i * stride;
+        stride *= gd.n[d];
+    }
+    return ok ? off : -1;
+}
+
+template <typename T, int NI>
+__device__ __forceinline__ void load_point(const T* __restrict__ points, int64_t p, T (&v)[NI]) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) v[j] = points[p * NI + j];
+}
+
+// Per-point backward quantities for one pose (src/raster_pullback.jl:46-67):
+// scaled = ds_dcoord .* scale (with out_weight*point_weight inside),
+// W = sum_s g_s * prod_d omega_d  (so d out_weight += W*pw, d point_weight += W*ow).
+// `fetch(off)` returns ds_dout at column-major offset `off` of this pose.
+template <typename T, int NI, int NO, typename Fetch>
+__device__ __forceinline__ void point_backward(const int (&ref0)[NO], const T (&dlo)[NO],
+                                               const GridDesc<NO>& gd, T ow, T pw, Fetch fetch,
+                                               T (&scaled)[NO], T& dow_part, T& dpw_part) {
+    T dcoord[NO];
+#pragma unroll
+    for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
+    dow_part = T(0);
+    dpw_part = T(0);
+#pragma unroll
+    for (int s = 0; s < (1 << NO); ++s) {
+        const int off = nbr_offset<NO>(ref0, s, gd);
+        if (off < 0) continue;
+        const T gi = fetch(off);
+        const T dweight = voxel_weight<T, NO>(dlo, s, gi);
+        dow_part += dweight * pw;
+        dpw_part += dweight * ow;
+        const T factor = gi * ow * pw;
+#pragma unroll
+        for (int n = 0; n < NO; ++n) dcoord[n] += factor * interp_weight<T, NO>(n, dlo, s);
+    }
+#pragma unroll
+    for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));
+}
+
+// wave-level sum (all 64 lanes must call)
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ void atomic_add(T* addr, T v) {
+    unsafeAtomicAdd(addr, v);  // native global_atomic_add_f32 / _f64 on gfx950
+}
+
+}  // namespace dpr

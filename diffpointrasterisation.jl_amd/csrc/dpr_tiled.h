@@ -1,0 +1,25 @@
+// DPR_ALGO_TILED (declarations; implementation in dpr_tiled_impl.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dpr {
+
+int fail(int code, const char* fmt, ...);
+
+bool tiled_preferred(int op, int n_out, int64_t P, int64_t B, int64_t G);
+size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
+                             int64_t P, int64_t B);
+
+template <typename T, int NI, int NO>
+int raster_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B, T* out,
+                 const T* points, const T* rot, const T* trans, const T* bg, const T* ow,
+                 const T* pw, void* ws, size_t ws_bytes);
+
+template <typename T, int NI, int NO>
+int pullback_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                   const T* g, const T* points, const T* rot, const T* trans, const T* ow,
+                   const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw,
+                   void* ws, size_t ws_bytes);
+
+}  // namespace dpr

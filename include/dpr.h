@@ -1,0 +1,140 @@
+/*
+ * libdpr -- MI355X (gfx950) implementation of DiffPointRasterisation.jl's
+ * `raster!` / `raster_pullback!` hot path behind a C ABI.
+ *
+ * This header is the drop-in boundary: the entry points are what a Julia
+ * `DiffPointRasterisationAMDGPUExt` would `ccall` from array-type-specialised
+ * methods of the reference's two canonical signatures (INTEGRATION.md shows the
+ * binding):
+ *
+ *   dpr_raster_<T>           replaces  raster!  7-arg canonical method
+ *                            /root/reference/src/raster.jl:5-34  (+ kernel :36-66)
+ *   dpr_raster_pullback_<T>  replaces  raster_pullback!  13-arg batched method
+ *                            /root/reference/src/raster_pullback.jl:85-148 and its
+ *                            CUDA specialisation
+ *                            /root/reference/ext/DiffPointRasterisationCUDAExt.jl:231-321
+ *   (flat, un-slabbed output buffers as chosen by the allocator hooks at
+ *    ext/DiffPointRasterisationCUDAExt.jl:323-333)
+ *
+ * Memory layouts are the reference's own (Julia column-major / AoS), so device
+ * buffers can be passed without copies:
+ *
+ *   points        P x n_in AoS                      Vector{SVector{N_in,T}}
+ *   rotation      B x (n_out x n_in, column-major)  Vector{SMatrix{N_out,N_in,T}}
+ *   translation   B x n_out                         Vector{SVector{N_out,T}}
+ *   background    B   or NULL => 0   (FillArrays.Zeros default, src/interface.jl:368-380)
+ *   out_weight    B   or NULL => 1   (FillArrays.Ones  default, src/interface.jl:382-390)
+ *   point_weight  P   or NULL => 1   (src/interface.jl:392-394)
+ *   out, ds_dout  (n_1, .., n_N, B) column-major: axis 1 fastest, pose slowest
+ *   ds_dpoints    n_in x P column-major (= AoS like points)
+ *   ds_drotation  n_out x n_in x B column-major
+ *   ds_dtranslation n_out x B ; ds_dbackground, ds_dout_weight: B ; ds_dpoint_weight: P
+ *
+ * All data pointers are DEVICE pointers owned by the caller (including the
+ * workspace).  Calls only enqueue work on `stream` (a hipStream_t; NULL = the
+ * default stream); they never synchronise the device and keep no device memory
+ * or global state between calls.  Supported (n_in, n_out): (2,2), (3,3), (3,2)
+ * -- the shapes the reference tests (src/raster.jl:112, test/data.jl:13-19).
+ *
+ * Error behaviour: the reference throws DimensionMismatch / ArgumentError before
+ * any launch (src/raster.jl:14-23, ext/...CUDAExt.jl:246-262).  Here every entry
+ * point returns a status (0 = ok) and records a message retrievable with
+ * dpr_last_error() (thread-local); nothing is launched on error.
+ */
+#ifndef DPR_H
+#define DPR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPR_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define DPR_OK 0
+#define DPR_ERR_UNSUPPORTED_DIMS (-1) /* (n_in, n_out) not one of (2,2),(3,3),(3,2) */
+#define DPR_ERR_INVALID_ARG (-2)      /* NULL required pointer, negative size, bad grid */
+#define DPR_ERR_WORKSPACE (-3)        /* workspace NULL/too small for the chosen algorithm */
+#define DPR_ERR_HIP (-4)              /* a HIP runtime call failed */
+#define DPR_ERR_UNSUPPORTED_ALGO (-5) /* algorithm not available for this shape */
+
+/* operations, for dpr_workspace_bytes_* */
+#define DPR_OP_RASTER 0
+#define DPR_OP_PULLBACK 1
+
+/* algorithms (the *_ex entry points; the plain ones use DPR_ALGO_AUTO) */
+#define DPR_ALGO_AUTO 0
+#define DPR_ALGO_ATOMIC 1 /* thread per point, direct global float atomics / gathers */
+#define DPR_ALGO_TILED 2  /* per-pose binning of points into voxel tiles, LDS-resident
+                             tile accumulation, plain-store flush (no global atomics) */
+
+int dpr_version(void);
+
+/* Thread-local message of the last failing call on this host thread ("" if none). */
+const char *dpr_last_error(void);
+
+/* Bytes of caller-provided device workspace needed by `op` with `algo`
+ * (may be 0).  Returns (size_t)-1 on invalid arguments. */
+size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t *grid,
+                               int64_t P, int64_t B);
+size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t *grid,
+                               int64_t P, int64_t B);
+
+/* Forward: out[.., b] = background[b] + sum_p splat(R[b] p + t[b]) * out_weight[b] * point_weight[p]
+ * `out` is fully overwritten (src/raster.jl:27). */
+int dpr_raster_f32(void *stream, int n_in, int n_out, const int64_t *grid, int64_t P, int64_t B,
+                   float *out, const float *points, const float *rotation,
+                   const float *translation, const float *background, const float *out_weight,
+                   const float *point_weight, void *workspace, size_t workspace_bytes);
+int dpr_raster_f64(void *stream, int n_in, int n_out, const int64_t *grid, int64_t P, int64_t B,
+                   double *out, const double *points, const double *rotation,
+                   const double *translation, const double *background, const double *out_weight,
+                   const double *point_weight, void *workspace, size_t workspace_bytes);
+int dpr_raster_ex_f32(void *stream, int algo, int n_in, int n_out, const int64_t *grid, int64_t P,
+                      int64_t B, float *out, const float *points, const float *rotation,
+                      const float *translation, const float *background, const float *out_weight,
+                      const float *point_weight, void *workspace, size_t workspace_bytes);
+int dpr_raster_ex_f64(void *stream, int algo, int n_in, int n_out, const int64_t *grid, int64_t P,
+                      int64_t B, double *out, const double *points, const double *rotation,
+                      const double *translation, const double *background,
+                      const double *out_weight, const double *point_weight, void *workspace,
+                      size_t workspace_bytes);
+
+/* Pullback.  All six outputs are OVERWRITTEN (ext/...CUDAExt.jl:272-276).
+ * `background` is not an input of the arithmetic (src/raster_pullback.jl:7,78). */
+int dpr_raster_pullback_f32(void *stream, int n_in, int n_out, const int64_t *grid, int64_t P,
+                            int64_t B, const float *ds_dout, const float *points,
+                            const float *rotation, const float *translation,
+                            const float *out_weight, const float *point_weight, float *ds_dpoints,
+                            float *ds_drotation, float *ds_dtranslation, float *ds_dbackground,
+                            float *ds_dout_weight, float *ds_dpoint_weight, void *workspace,
+                            size_t workspace_bytes);
+int dpr_raster_pullback_f64(void *stream, int n_in, int n_out, const int64_t *grid, int64_t P,
+                            int64_t B, const double *ds_dout, const double *points,
+                            const double *rotation, const double *translation,
+                            const double *out_weight, const double *point_weight,
+                            double *ds_dpoints, double *ds_drotation, double *ds_dtranslation,
+                            double *ds_dbackground, double *ds_dout_weight,
+                            double *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
+int dpr_raster_pullback_ex_f32(void *stream, int algo, int n_in, int n_out, const int64_t *grid,
+                               int64_t P, int64_t B, const float *ds_dout, const float *points,
+                               const float *rotation, const float *translation,
+                               const float *out_weight, const float *point_weight,
+                               float *ds_dpoints, float *ds_drotation, float *ds_dtranslation,
+                               float *ds_dbackground, float *ds_dout_weight,
+                               float *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
+int dpr_raster_pullback_ex_f64(void *stream, int algo, int n_in, int n_out, const int64_t *grid,
+                               int64_t P, int64_t B, const double *ds_dout, const double *points,
+                               const double *rotation, const double *translation,
+                               const double *out_weight, const double *point_weight,
+                               double *ds_dpoints, double *ds_drotation, double *ds_dtranslation,
+                               double *ds_dbackground, double *ds_dout_weight,
+                               double *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPR_H */

@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: libdpr.so loads without a GPU, exports every
+symbol include/dpr.h declares, and rejects bad arguments before touching the device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dpr_amd
+from tests.conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dpr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = dpr_amd.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(L, name), f"libdpr.so does not export {name}"
+    assert sorted(dpr_amd._lib.EXPORTS) == declared
+
+
+def test_version_matches_header():
+    text = open(os.path.join(ROOT, "include", "dpr.h")).read()
+    ver = int(re.search(r"#define DPR_VERSION (\d+)", text).group(1))
+    assert dpr_amd.lib().dpr_version() == ver
+
+
+def test_status_codes_match_header():
+    text = open(os.path.join(ROOT, "include", "dpr.h")).read()
+    for name, attr in [("DPR_ERR_UNSUPPORTED_DIMS", "ERR_UNSUPPORTED_DIMS"),
+                       ("DPR_ERR_INVALID_ARG", "ERR_INVALID_ARG"),
+                       ("DPR_ERR_WORKSPACE", "ERR_WORKSPACE"), ("DPR_ERR_HIP", "ERR_HIP"),
+                       ("DPR_ERR_UNSUPPORTED_ALGO", "ERR_UNSUPPORTED_ALGO"),
+                       ("DPR_ALGO_ATOMIC", "ALGO_ATOMIC"), ("DPR_ALGO_TILED", "ALGO_TILED"),
+                       ("DPR_OP_PULLBACK", "OP_PULLBACK")]:
+        val = int(re.search(rf"#define {name} \(?(-?\d+)\)?", text).group(1))
+        assert getattr(dpr_amd._lib, attr) == val
+
+
+@pytest.mark.parametrize("suf", ["f32", "f64"])
+def test_argument_errors_are_reported_without_a_device(suf):
+    """Errors come back as status + dpr_last_error(), nothing is launched
+    (reference: @argcheck before launch, src/raster.jl:14-23)."""
+    L = dpr_amd.lib()
+    grid = np.array([8, 8, 8], dtype=np.int64)
+    gp = grid.ctypes.data_as(ctypes.c_void_p)
+    fn = getattr(L, f"dpr_raster_{suf}")
+    # unsupported dims (2 -> 3)
+    rc = fn(None, 2, 3, gp, 10, 1, None, None, None, None, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
+    assert "unsupported" in dpr_amd._lib.last_error()
+    # NULL out
+    rc = fn(None, 3, 3, gp, 10, 1, None, None, None, None, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG
+    assert "NULL" in dpr_amd._lib.last_error()
+    # negative P
+    rc = fn(None, 3, 3, gp, -1, 1, None, None, None, None, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG
+    # bad grid
+    bad = np.array([8, 0, 8], dtype=np.int64)
+    rc = fn(None, 3, 3, bad.ctypes.data_as(ctypes.c_void_p), 1, 1, None, None, None, None, None,
+            None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG
+    pb = getattr(L, f"dpr_raster_pullback_{suf}")
+    rc = pb(None, 3, 1, gp, 10, 1, *([None] * 12), None, 0)
+    assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
+    ws = getattr(L, f"dpr_workspace_bytes_{suf}")
+    assert ws(0, 0, 3, 3, gp, 1000, 2) != ctypes.c_size_t(-1).value
+    assert ws(0, 0, 4, 3, gp, 1000, 2) == ctypes.c_size_t(-1).value
+    assert ws(7, 0, 3, 3, gp, 1000, 2) == ctypes.c_size_t(-1).value
+
+
+def test_host_api_refuses_cpu_tensors():
+    """No CPU fallback: the product path must fail loudly off-device."""
+    import torch
+
+    pts = torch.zeros(4, 2, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dpr_amd.raster((5, 5), pts, torch.eye(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dpr_amd.raster_pullback_(torch.zeros(5, 5, dtype=torch.float64), pts,
+                                 torch.eye(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64))
+
+
+def test_shard_range_is_a_partition():
+    for B in [0, 1, 5, 8, 9, 64, 513]:
+        for world in [1, 2, 3, 8]:
+            ranges = [dpr_amd.shard_range(B, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == B
+            for (a, b), (c, d) in zip(ranges, ranges[1:]):
+                assert b == c
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1

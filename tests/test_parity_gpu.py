@@ -1,0 +1,375 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the host mirror) against the CPU
+oracle, the reference's golden vectors, and size-independent properties at BASELINE sizes.
+
+Tolerances:
+  fp64  norm-wise rtol 1e-10  (the reference's own `≈` would allow sqrt(eps) = 1.5e-8)
+  fp32  vs the fp32 oracle (identical per-contribution arithmetic, different summation
+        order): norm-wise 1e-5 for `out`, 1e-4 for ds_dpoints / ds_dpoint_weight,
+        1e-3 for the per-pose sums (rotation / translation / out_weight / background)
+"""
+import numpy as np
+import pytest
+import torch
+
+import dpr_amd
+from tests import data as D
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = ["atomic", "tiled"]
+DTYPES = [(np.float64, torch.float64), (np.float32, torch.float32)]
+SHAPES = [(2, 2), (3, 3), (3, 2)]  # (n_in, n_out)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    # fail loudly if the extension is missing: there is no fallback
+    dpr_amd.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev, tdt=None):
+    if a is None:
+        return None
+    t = torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    return t if tdt is None else t.to(tdt)
+
+
+def grid_to_dev(a, dev):
+    """numpy [i1..iN, b] (any order) -> device tensor with the reference memory order."""
+    return dpr_amd.to_grid_layout(torch.as_tensor(np.ascontiguousarray(a), device=dev))
+
+
+def tol(npdt, kind):
+    if npdt == np.float64:
+        return 1e-10
+    return {"out": 1e-5, "points": 1e-4, "pose": 1e-3}[kind]
+
+
+def assert_close(actual, expected, rtol, what=""):
+    a = actual.detach().cpu().numpy() if isinstance(actual, torch.Tensor) else np.asarray(actual)
+    e = np.asarray(expected)
+    assert a.shape == e.shape, f"{what}: shape {a.shape} != {e.shape}"
+    na, ne = np.linalg.norm(a.ravel()), np.linalg.norm(e.ravel())
+    err = np.linalg.norm((a.astype(np.float64) - e.astype(np.float64)).ravel())
+    assert err <= rtol * max(na, ne) + 1e-300, f"{what}: |a-e|={err:.3e} > {rtol:g}*{max(na, ne):.3e}"
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+def test_forward_known_answers(dev, golden, algo, npdt, tdt):
+    """src/raster.jl:143-309 and README.md:41-68 through the HIP path (single-pose API)."""
+    for case in golden["forward"]:
+        pts = T(np.array(case["points"], dtype=npdt), dev)
+        R = T(np.array(case["rotation"], dtype=npdt), dev)
+        t = T(np.array(case["translation"], dtype=npdt), dev)
+        args = [pts, R, t]
+        if case["out_weight"] is not None:
+            args += [case["background"], case["out_weight"]]
+            if case["point_weight"] is not None:
+                args += [T(np.array(case["point_weight"], dtype=npdt), dev)]
+        out = dpr_amd.raster(tuple(case["grid_size"]), *args, algo=algo)
+        assert out.shape == (5, 5) and out.dtype == tdt
+        np.testing.assert_allclose(out.cpu().numpy(), np.array(case["expected"]), rtol=0,
+                                   atol=1e-12 if npdt == np.float64 else 1e-5,
+                                   err_msg=case["name"])
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_readme_gradient_example(dev, golden, algo):
+    """README.md:84-183 (values printed to 6 digits)."""
+    g = golden["readme_gradient"]
+    pts = T(np.array(g["points"]), dev)
+    R = T(np.array(g["rotation"]), dev)
+    t = T(np.array(g["translation"]), dev)
+    target = T(np.array(g["target_image"]), dev)
+    out = dpr_amd.raster((5, 5), pts, R, t, algo=algo)
+    ds_dout = 2.0 * (target - out)
+    np.testing.assert_allclose(ds_dout.cpu().numpy(), np.array(g["ds_dout"]), rtol=2e-5, atol=2e-6)
+    pb = dpr_amd.raster_pullback_(ds_dout, pts, R, t, algo=algo)
+    full = -np.array(g["ds_dpoints_zygote_full_precision_negated"])
+    np.testing.assert_allclose(pb.points.cpu().numpy(), full, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(pb.rotation.cpu().numpy(), np.array(g["ds_drotation"]), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(pb.translation.cpu().numpy(), np.array(g["ds_dtranslation"]), rtol=0, atol=2e-5)
+    assert pb.background.ndim == 0 and pb.out_weight.ndim == 0  # single pose -> scalars
+    np.testing.assert_allclose(float(pb.background), float(ds_dout.sum()), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ oracle parity
+def _run_both(oracle, dev, d, npdt, algo, with_optional=True):
+    opt = (d.backgrounds, d.weights, d.point_weights) if with_optional else (None, None, None)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, *opt, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, opt[1],
+                                    opt[2], dtype=npdt)
+    out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev),
+                         T(opt[0], dev), T(opt[1], dev), T(opt[2], dev), algo=algo)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), T(d.points, dev),
+                                  T(d.rotations, dev), T(d.translations, dev), T(opt[0], dev),
+                                  T(opt[1], dev), T(opt[2], dev), algo=algo)
+    return ref_out, ref_pb, out, pb
+
+
+def _compare(ref_out, ref_pb, out, pb, npdt):
+    assert_close(out, ref_out, tol(npdt, "out"), "out")
+    assert_close(pb.points, ref_pb.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.point_weight, ref_pb.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    assert_close(pb.rotation, ref_pb.rotation, tol(npdt, "pose"), "ds_drotation")
+    assert_close(pb.translation, ref_pb.translation, tol(npdt, "pose"), "ds_dtranslation")
+    assert_close(pb.background, ref_pb.background, tol(npdt, "pose"), "ds_dbackground")
+    assert_close(pb.out_weight, ref_pb.out_weight, tol(npdt, "pose"), "ds_dout_weight")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out", SHAPES)
+@pytest.mark.parametrize("n_points", [10, 1000, 100_000])
+def test_device_equals_oracle(oracle, dev, algo, npdt, tdt, n_in, n_out, n_points):
+    """Counterpart of test/cuda.jl:2-74 (`cuda_cpu_agree`): 8^N grids, uneven batch,
+    the distributions of test/data.jl, all optional arguments given."""
+    d = D.make(n_points=n_points, n_in=n_in, n_out=n_out, batch=D.uneven_batch(4), seed=11,
+               dtype=npdt)
+    _compare(*_run_both(oracle, dev, d, npdt, algo), npdt)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 37), (3, 2, 100), (2, 2, 33), (3, 3, 64)])
+def test_device_equals_oracle_odd_grids_defaults(oracle, dev, algo, npdt, tdt, n_in, n_out, grid_n):
+    """Non-power-of-two grids (tile remainders) and defaulted optional arguments."""
+    d = D.make(n_points=20_000, n_in=n_in, n_out=n_out, batch=2, grid_n=grid_n, seed=12, dtype=npdt)
+    _compare(*_run_both(oracle, dev, d, npdt, algo, with_optional=False), npdt)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_anisotropic_grid(oracle, dev, algo):
+    rng = np.random.default_rng(5)
+    grid = (20, 7, 45)
+    pts = 0.5 * rng.normal(size=(5000, 3))
+    R = D.random_rotations(rng, 3)
+    t = 0.1 * rng.normal(size=(3, 3))
+    g = np.asfortranarray(rng.normal(size=grid + (3,)))
+    ref = oracle.raster(grid, pts, R, t)
+    out = dpr_amd.raster(grid, T(pts, dev), T(R, dev), T(t, dev), algo=algo)
+    assert_close(out, ref, 1e-10, "out")
+    rp = oracle.raster_pullback(g, pts, R, t)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), T(pts, dev), T(R, dev), T(t, dev), algo=algo)
+    for a, e, n in zip(pb, rp, pb._fields):
+        assert_close(a, e, 1e-10, n)
+
+
+# ------------------------------------------------------------------ structural properties
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n_in,n_out", [(3, 3), (3, 2)])
+def test_batched_equals_loop_of_singles(dev, algo, n_in, n_out):
+    """src/raster.jl:383-431, src/raster_pullback.jl:271-345 on the device."""
+    d = D.make(n_points=20_000, n_in=n_in, n_out=n_out, batch=D.uneven_batch(4), seed=13)
+    pts, Rs, ts = T(d.points, dev), T(d.rotations, dev), T(d.translations, dev)
+    bgs, ws, pw = T(d.backgrounds, dev), T(d.weights, dev), T(d.point_weights, dev)
+    out_b = dpr_amd.raster(d.grid, pts, Rs, ts, bgs, ws, pw, algo=algo)
+    g = grid_to_dev(d.ds_dout, dev)
+    pb_b = dpr_amd.raster_pullback_(g, pts, Rs, ts, bgs, ws, pw, algo=algo)
+    sum_pts = torch.zeros_like(pb_b.points)
+    sum_pw = torch.zeros_like(pb_b.point_weight)
+    for b in range(d.batch):
+        out_i = dpr_amd.raster(d.grid, pts, Rs[b], ts[b], float(bgs[b]), float(ws[b]), pw, algo=algo)
+        assert out_i.shape == tuple(d.grid)
+        assert_close(out_b[..., b], out_i.cpu().numpy(), 1e-12, "out")
+        pi = dpr_amd.raster_pullback_(g[..., b], pts, Rs[b], ts[b], float(bgs[b]), float(ws[b]),
+                                      pw, algo=algo)
+        assert_close(pb_b.rotation[b], pi.rotation.cpu().numpy(), 1e-10, "rotation")
+        assert_close(pb_b.translation[b], pi.translation.cpu().numpy(), 1e-10, "translation")
+        assert_close(pb_b.background[b], pi.background.cpu().numpy(), 1e-10, "background")
+        assert_close(pb_b.out_weight[b], pi.out_weight.cpu().numpy(), 1e-10, "out_weight")
+        sum_pts += pi.points
+        sum_pw += pi.point_weight
+    assert_close(pb_b.points, sum_pts.cpu().numpy(), 1e-10, "points")
+    assert_close(pb_b.point_weight, sum_pw.cpu().numpy(), 1e-10, "point_weight")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_defaults_equal_explicit_and_preallocated_outputs(dev, algo):
+    """src/interface.jl:414-595 + kwargs outputs returned by identity and overwritten."""
+    d = D.make(n_points=3000, n_in=3, n_out=3, batch=3, seed=14)
+    pts, Rs, ts = T(d.points, dev), T(d.rotations, dev), T(d.translations, dev)
+    a = dpr_amd.raster(d.grid, pts, Rs, ts, algo=algo)
+    b = dpr_amd.raster(d.grid, pts, Rs, ts, torch.zeros(3, device=dev, dtype=torch.float64),
+                       torch.ones(3, device=dev, dtype=torch.float64),
+                       torch.ones(3000, device=dev, dtype=torch.float64), algo=algo)
+    assert_close(a, b.cpu().numpy(), 1e-13)
+    out = dpr_amd.empty_grid(d.grid, 3, torch.float64, dev)
+    out.fill_(123.0)  # must be fully overwritten
+    ret = dpr_amd.raster_(out, pts, Rs, ts, algo=algo)
+    assert ret is out
+    assert_close(out, a.cpu().numpy(), 1e-13)
+    g = grid_to_dev(d.ds_dout, dev)
+    pa = dpr_amd.raster_pullback_(g, pts, Rs, ts, algo=algo)
+    garbage = lambda *s: torch.full(s, 7.0, device=dev, dtype=torch.float64)
+    bufs = dict(ds_dpoints=garbage(3000, 3), ds_drotation=garbage(3, 3, 3).transpose(1, 2),
+                ds_dtranslation=garbage(3, 3), ds_dbackground=garbage(3),
+                ds_dout_weight=garbage(3), ds_dpoint_weight=garbage(3000))
+    pb = dpr_amd.raster_pullback_(g, pts, Rs, ts, algo=algo, **bufs)
+    assert pb.points is bufs["ds_dpoints"] and pb.point_weight is bufs["ds_dpoint_weight"]
+    assert pb.translation.data_ptr() == bufs["ds_dtranslation"].data_ptr()
+    assert pb.rotation.data_ptr() == bufs["ds_drotation"].data_ptr()
+    for x, y, n in zip(pa, pb, pa._fields):
+        assert_close(x, y.cpu().numpy(), 1e-10, n)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n_in,n_out", SHAPES)
+def test_pullback_matches_central_differences_on_device(dev, algo, n_in, n_out):
+    """Device counterpart of test_rrule (test/chainrules.jl:2-90; the CUDA version is
+    commented out as failing in the reference, test/cuda.jl:76-93)."""
+    d = D.make(n_points=10, n_in=n_in, n_out=n_out, batch=3, seed=15)
+    g = grid_to_dev(d.ds_dout, dev)
+    base = dict(points=T(d.points, dev), rot=T(d.rotations, dev), tr=T(d.translations, dev),
+                bg=T(d.backgrounds, dev), ow=T(d.weights, dev), pw=T(d.point_weights, dev))
+
+    def f(**over):
+        a = dict(base); a.update(over)
+        out = dpr_amd.raster(d.grid, a["points"], a["rot"], a["tr"], a["bg"], a["ow"], a["pw"], algo=algo)
+        return float((g * out).sum())
+
+    pb = dpr_amd.raster_pullback_(g, base["points"], base["rot"], base["tr"], base["bg"],
+                                  base["ow"], base["pw"], algo=algo)
+    h = 1e-6
+    for name, grad in [("points", pb.points), ("rot", pb.rotation), ("tr", pb.translation),
+                       ("bg", pb.background), ("ow", pb.out_weight), ("pw", pb.point_weight)]:
+        arr = base[name].cpu().numpy()
+        fd = np.zeros_like(arr)
+        for idx in np.ndindex(arr.shape):
+            ap = arr.copy(); ap[idx] += h
+            am = arr.copy(); am[idx] -= h
+            fd[idx] = (f(**{name: T(ap, dev)}) - f(**{name: T(am, dev)})) / (2 * h)
+        np.testing.assert_allclose(grad.cpu().numpy(), fd, rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+def test_edge_points(oracle, dev, algo, npdt, tdt):
+    """Border neighbours dropped individually (src/raster.jl:62); far / non-finite points
+    contribute nothing and get zero gradients."""
+    pts = np.array([[0.999, 0.0], [-0.999, -0.999], [0.0, 0.999], [5.0, 0.0], [np.nan, 0.0],
+                    [1e30, 0.0], [-1.2, 0.3], [0.3, np.inf]], dtype=npdt)
+    rng = np.random.default_rng(1)
+    R = D.random_rotations(rng, 2, 2).astype(npdt)
+    R[0] = np.eye(2)
+    t = np.zeros((2, 2), dtype=npdt)
+    g = np.asfortranarray(rng.normal(size=(6, 6, 2)).astype(npdt))
+    ref = oracle.raster((6, 6), pts, R, t, dtype=npdt)
+    out = dpr_amd.raster((6, 6), T(pts, dev), T(R, dev), T(t, dev), algo=algo)
+    assert torch.isfinite(out).all()
+    assert_close(out, ref, tol(npdt, "out"))
+    rp = oracle.raster_pullback(g, pts, R, t, dtype=npdt)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), T(pts, dev), T(R, dev), T(t, dev), algo=algo)
+    for a, e, n in zip(pb, rp, pb._fields):
+        assert torch.isfinite(a).all(), n
+        assert_close(a, e, tol(npdt, "pose"), n)
+    assert (pb.points[3:6] == 0).all() and (pb.point_weight[3:6] == 0).all()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_empty_and_tiny_inputs(dev, algo):
+    R = torch.eye(3, device=dev, dtype=torch.float64)[None].repeat(2, 1, 1)
+    t = torch.zeros(2, 3, device=dev, dtype=torch.float64)
+    empty = torch.zeros(0, 3, device=dev, dtype=torch.float64)
+    bg = torch.tensor([2.0, -1.0], device=dev, dtype=torch.float64)
+    out = dpr_amd.raster((4, 4, 4), empty, R, t, bg, algo=algo)
+    assert (out[..., 0] == 2.0).all() and (out[..., 1] == -1.0).all()
+    g = dpr_amd.empty_grid((4, 4, 4), 2, torch.float64, dev)
+    g.fill_(1.0)
+    pb = dpr_amd.raster_pullback_(g, empty, R, t, algo=algo)
+    assert pb.points.shape == (0, 3) and pb.point_weight.shape == (0,)
+    assert (pb.background == 64.0).all() and (pb.rotation == 0).all() and (pb.out_weight == 0).all()
+    one = torch.zeros(1, 3, device=dev, dtype=torch.float64)
+    out = dpr_amd.raster((4, 4, 4), one, R[0], t[0], algo=algo)
+    assert abs(float(out.sum()) - 1.0) < 1e-12
+
+
+def test_dimension_errors(dev):
+    """src/raster.jl:14-23, src/interface.jl:137-162: raised before any launch."""
+    f64 = dict(device=dev, dtype=torch.float64)
+    pts = torch.zeros(5, 3, **f64)
+    R = torch.eye(3, **f64)[None].repeat(2, 1, 1)
+    t = torch.zeros(2, 3, **f64)
+    with pytest.raises(dpr_amd.DimensionMismatch, match="Column dimension"):
+        dpr_amd.raster((4, 4, 4), torch.zeros(5, 2, **f64), R, t)
+    with pytest.raises(dpr_amd.DimensionMismatch, match="Row dimension"):
+        dpr_amd.raster((4, 4, 4), pts, R, torch.zeros(2, 2, **f64))
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster((4, 4, 4), pts, R, torch.zeros(3, 3, **f64))
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster((4, 4, 4), pts, R, t, torch.zeros(3, **f64))
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster((4, 4, 4), pts, R, t, None, None, torch.ones(4, **f64))
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster_(dpr_amd.empty_grid((4, 4), 2, torch.float64, dev), pts, R, t)
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster_pullback_(dpr_amd.empty_grid((4, 4, 4), 3, torch.float64, dev), pts, R, t)
+    with pytest.raises(dpr_amd.DprError):  # 2 -> 3 is rejected by the library itself
+        dpr_amd.raster((4, 4, 4), torch.zeros(5, 2, **f64), torch.zeros(1, 3, 2, **f64),
+                       torch.zeros(1, 3, **f64))
+
+
+def test_mixed_dtypes_promote(dev):
+    """promote_type over arguments (src/interface.jl:63-64); Bool rotation like I(2)."""
+    pts = torch.rand(100, 2, device=dev, dtype=torch.float32) - 0.5
+    out = dpr_amd.raster((8, 8), pts, torch.eye(2, device=dev, dtype=torch.bool),
+                         torch.zeros(2, device=dev, dtype=torch.float32))
+    assert out.dtype == torch.float32 and abs(float(out.sum()) - 100.0) < 1e-3
+    out = dpr_amd.raster((8, 8), pts, torch.eye(2, device=dev, dtype=torch.float64),
+                         torch.zeros(2, device=dev, dtype=torch.float32))
+    assert out.dtype == torch.float64
+
+
+# ------------------------------------------------------------------ BASELINE-size properties
+def _ball_points(n, dev, dtype, radius=0.85, seed=0):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    v = torch.randn(n, 3, device=dev, dtype=dtype, generator=g)
+    v = v / v.norm(dim=1, keepdim=True)
+    r = radius * torch.rand(n, 1, device=dev, dtype=dtype, generator=g) ** (1.0 / 3.0)
+    return v * r
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("config", ["C2", "C3"])
+def test_full_size_properties(dev, algo, config):
+    """BASELINE.json configs 2/3 (1M -> 128^3, 10M -> 256^3, fp32, one pose): properties
+    that do not need the oracle.  Points inside a ball of radius 0.85 stay interior under
+    any rotation + |t|<=0.1, so (i) total mass = out_weight * sum(point_weight) + bg*G,
+    (ii) linearity in out_weight, (iii) with constant ds_dout = c the position gradient
+    vanishes and d point_weight = c*out_weight, (iv) ds_dbackground = sum(ds_dout)."""
+    P, n = (1_000_000, 128) if config == "C2" else (10_000_000, 256)
+    f32 = dict(device=dev, dtype=torch.float32)
+    pts = _ball_points(P, dev, torch.float32)
+    rng = np.random.default_rng(1)
+    R = T(D.random_rotations(rng, 1).astype(np.float32), dev)
+    t = T((0.05 * rng.normal(size=(1, 3))).clip(-0.1, 0.1).astype(np.float32), dev)
+    ow = torch.tensor([1.5], **f32)
+    bg = torch.tensor([0.25], **f32)
+    out = dpr_amd.raster((n, n, n), pts, R, t, bg, ow, algo=algo)
+    G = n ** 3
+    total = float(out.double().sum())
+    assert abs(total - (1.5 * P + 0.25 * G)) <= 2e-4 * (1.5 * P + 0.25 * G)
+    out2 = dpr_amd.raster((n, n, n), pts, R, t, bg, 2 * ow, algo=algo)
+    lin = (out2 - bg) - 2 * (out - bg)
+    assert float(lin.abs().max()) <= 1e-3 * float((out - bg).abs().max())
+    # pullback with constant sensitivity
+    g = dpr_amd.empty_grid((n, n, n), 1, torch.float32, dev)
+    g.fill_(0.5)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow, algo=algo)
+    assert float(pb.points.abs().max()) <= 1e-3 * n  # exact 0 up to fp32 rounding * scale
+    assert_close(pb.point_weight, np.full(P, 0.75, dtype=np.float32), 1e-5)
+    assert abs(float(pb.background[0]) - 0.5 * G) <= 1e-3 * 0.5 * G
+    assert abs(float(pb.out_weight[0]) - 0.5 * P) <= 1e-3 * 0.5 * P
+    # random sensitivity: background gradient is the plain sum
+    g2 = torch.randn(1, n, n, n, **f32).permute(3, 2, 1, 0)
+    pb2 = dpr_amd.raster_pullback_(g2, pts, R, t, bg, ow, algo=algo)
+    assert abs(float(pb2.background[0]) - float(g2.double().sum())) <= 1e-3 * np.sqrt(G)
+    # <g2, out - bg> = ow * d/d(ow) => adjoint identity between forward and pullback
+    lhs = float((g2.double() * (out.double() - 0.25)).sum())
+    rhs = 1.5 * float(pb2.out_weight[0])
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), np.sqrt(P))
