@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0  # measured float4 copy ceiling (same guide)
 
 
-def synth_inputs(cfg, rank, device, order):
+def synth_inputs(cfg, rank, device, order, dist_kind="gauss"):
     """points 0.4*N(0,I) seed 0 (test/data.jl:22,27); rotation uniform on
     SO(3), translation 0.1*N(0,I), seed 1 (+rank); ds_dout N(0,1) seed 2 (+rank)."""
     import torch
@@ -47,6 +47,8 @@ def synth_inputs(cfg, rank, device, order):
     npdt = np.float32 if dt == "f32" else np.float64
     rng = np.random.default_rng(0)
     pts = (0.4 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
+    if dist_kind == "uniform":  # diagnostic only (balanced tiles); not the headline workload
+        pts = (1.1 * rng.random(size=(P, n_in), dtype=np.float32) - 0.55).astype(npdt)
     if order == "morton":
         pts = pts[morton_order(pts)]
     prng = np.random.default_rng(1 + rank)
@@ -126,6 +128,7 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled"])
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="point order in memory: as generated, or pre-sorted (pose-independent)")
+    ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -150,7 +153,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P, n_in, grid, dt = CONFIGS[args.config]
-    inp = synth_inputs(args.config, rank, device, args.order)
+    inp = synth_inputs(args.config, rank, device, args.order, args.dist)
     tdt = inp["points"].dtype
     out = dpr_amd.empty_grid(grid, 1, tdt, device)
     fused = torch.empty(P * (n_in + 1), dtype=tdt, device=device)
@@ -209,7 +212,12 @@ def main():
     ms_fwd = event_time(fwd, reps)
     ms_bwd = event_time(bwd, reps)
     a_fwd, a_bwd = algorithmic_bytes(args.config)
-    stages = dpr_amd.stage_times(fwd, bwd, reps) if hasattr(dpr_amd, "stage_times") else None
+    algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P, 1, n_in)
+    algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P, 1, n_in)
+    st_f = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
+    st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps)
+    stages = {"raster": {"algo": algo_f, **{k: round(v, 4) for k, v in st_f.items()}},
+              "pullback": {"algo": algo_b, **{k: round(v, 4) for k, v in st_b.items()}}}
 
     roof = {
         "bound": "hbm", "kernel": "raster! (all launches of one forward call)",
@@ -229,7 +237,7 @@ def main():
         "value": round(value, 3), "unit": "M points/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
-        "config": {"workload": f"{args.config}: {P} 3-D points (0.4*N(0,I), {args.order} order) -> "
+        "config": {"workload": f"{args.config}: {P} 3-D points ({'0.4*N(0,I)' if args.dist == 'gauss' else 'uniform(-.55,.55)'}, {args.order} order) -> "
                                f"{'x'.join(map(str, grid))} {dt} grid, one pose per GPU, "
                                f"raster! + raster_pullback!",
                    "algo": args.algo, "poses_global": world, "point_order": args.order,

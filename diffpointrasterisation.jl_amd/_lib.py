@@ -26,7 +26,8 @@ ALGO_TILED = 2
 ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED}
 
 EXPORTS = [
-    "dpr_version", "dpr_last_error",
+    "dpr_version", "dpr_last_error", "dpr_stage_timing_begin", "dpr_stage_timing_end",
+    "dpr_resolve_algo",
     "dpr_workspace_bytes_f32", "dpr_workspace_bytes_f64",
     "dpr_raster_f32", "dpr_raster_f64", "dpr_raster_ex_f32", "dpr_raster_ex_f64",
     "dpr_raster_pullback_f32", "dpr_raster_pullback_f64",
@@ -71,6 +72,12 @@ def lib() -> ctypes.CDLL:
     L.dpr_version.argtypes = []
     L.dpr_last_error.restype = ctypes.c_char_p
     L.dpr_last_error.argtypes = []
+    L.dpr_stage_timing_begin.restype = i
+    L.dpr_stage_timing_begin.argtypes = [vp, i]
+    L.dpr_stage_timing_end.restype = i
+    L.dpr_stage_timing_end.argtypes = []
+    L.dpr_resolve_algo.restype = i
+    L.dpr_resolve_algo.argtypes = [i, i, i, vp, i64, i64]
     for suf in ("f32", "f64"):
         f = getattr(L, f"dpr_workspace_bytes_{suf}")
         f.restype = sz

@@ -65,9 +65,20 @@ template <int NO> static GridDesc<NO> make_grid(const int64_t* grid, int64_t G) 
     return gd;
 }
 
-static int resolve_algo(int algo, int op, int n_out, int64_t P, int64_t B, int64_t G) {
+static int resolve_algo(int algo, int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
+                        int64_t G) {
     if (algo != DPR_ALGO_AUTO) return algo;
-    return tiled_preferred(op, n_out, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
+    return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
+}
+
+// Optional per-stage timing: the caller arms an array of hipEvent_t; every stage boundary
+// records the next one on the launch stream (bench.py reads kernel durations this way).
+static thread_local hipEvent_t* g_stage_events = nullptr;
+static thread_local int g_stage_cap = 0, g_stage_n = 0;
+
+void stage_mark(hipStream_t st) {
+    if (g_stage_events && g_stage_n < g_stage_cap)
+        (void)hipEventRecord(g_stage_events[g_stage_n++], st);
 }
 
 // ---------------------------------------------------------------- forward
@@ -87,11 +98,13 @@ static int raster_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t
                                bg ? bg + b0 : nullptr);
         }
     }
+    stage_mark(st);
     if (P > 0) {
         dim3 g((unsigned)((P + kBlock - 1) / kBlock), (unsigned)(B < 65535 ? B : 65535));
         hipLaunchKernelGGL((k_fwd_atomic<T, NI, NO>), g, dim3(kBlock), 0, st, gd, P, B, out,
                            points, rot, trans, ow, pw);
     }
+    stage_mark(st);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -109,7 +122,8 @@ static int raster_impl(void* stream, int algo, int n_in, int n_out, const int64_
     if ((P + kBlock - 1) / kBlock > 0x7fffffffLL)
         return fail(DPR_ERR_INVALID_ARG, "P too large");
     hipStream_t st = (hipStream_t)stream;
-    algo = resolve_algo(algo, DPR_OP_RASTER, n_out, P, B, G);
+    algo = resolve_algo(algo, DPR_OP_RASTER, n_out, grid, P, B, G);
+    stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                       \
     if (n_in == NI && n_out == NO) {                                                           \
         if (algo == DPR_ALGO_ATOMIC)                                                           \
@@ -145,6 +159,7 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
         dim3 gg((unsigned)want, (unsigned)nb);
         hipLaunchKernelGGL(k_grid_sum<T>, gg, dim3(kBlock), 0, st, g + b0 * G, G, d_bg + b0);
     }
+    stage_mark(st);
     if (P > 0) {
         const int64_t pblocks = (P + kBlock - 1) / kBlock;
         // enough blocks to fill 256 CUs x 8: split poses into slices when P is small
@@ -166,6 +181,7 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
                            rot, trans, ow, pw, d_pts, d_rot, d_trans, d_ow, d_pw, poses_per_slice,
                            accumulate);
     }
+    stage_mark(st);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }
@@ -193,7 +209,8 @@ static int pullback_impl(void* stream, int algo, int n_in, int n_out, const int6
     if (!rot || !trans) return fail(DPR_ERR_INVALID_ARG, "rotation/translation is NULL");
     if (!d_rot || !d_trans || !d_bg || !d_ow)
         return fail(DPR_ERR_INVALID_ARG, "a per-pose output pointer is NULL");
-    algo = resolve_algo(algo, DPR_OP_PULLBACK, n_out, P, B, G);
+    algo = resolve_algo(algo, DPR_OP_PULLBACK, n_out, grid, P, B, G);
+    stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                         \
     if (n_in == NI && n_out == NO) {                                                             \
         if (algo == DPR_ALGO_ATOMIC)                                                             \
@@ -220,7 +237,7 @@ static size_t workspace_impl(int op, int algo, int n_in, int n_out, const int64_
         fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
         return (size_t)-1;
     }
-    algo = resolve_algo(algo, op, n_out, P, B, G);
+    algo = resolve_algo(algo, op, n_out, grid, P, B, G);
     if (algo == DPR_ALGO_ATOMIC) return 0;
     if (algo == DPR_ALGO_TILED) return tiled_workspace_bytes(sizeof(T), op, n_in, n_out, grid, P, B);
     fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
@@ -234,6 +251,29 @@ extern "C" {
 int dpr_version(void) { return DPR_VERSION; }
 
 const char* dpr_last_error(void) { return dpr::g_last_error.c_str(); }
+
+int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B) {
+    int64_t G = 0;
+    if (int rc = dpr::check_common(n_in, n_out, grid, P, B, &G)) return rc;
+    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK)
+        return dpr::fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
+    return dpr::resolve_algo(DPR_ALGO_AUTO, op, n_out, grid, P, B, G);
+}
+
+int dpr_stage_timing_begin(void** events, int capacity) {
+    if (!events || capacity < 1) return dpr::fail(DPR_ERR_INVALID_ARG, "stage timing: no events");
+    dpr::g_stage_events = (hipEvent_t*)events;
+    dpr::g_stage_cap = capacity;
+    dpr::g_stage_n = 0;
+    return DPR_OK;
+}
+
+int dpr_stage_timing_end(void) {
+    const int n = dpr::g_stage_n;
+    dpr::g_stage_events = nullptr;
+    dpr::g_stage_cap = dpr::g_stage_n = 0;
+    return n;
+}
 
 size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t* grid,
                                int64_t P, int64_t B) {

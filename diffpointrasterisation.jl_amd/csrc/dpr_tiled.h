@@ -7,7 +7,11 @@ namespace dpr {
 
 int fail(int code, const char* fmt, ...);
 
-bool tiled_preferred(int op, int n_out, int64_t P, int64_t B, int64_t G);
+// records hipEvent k (if stage timing is armed, see dpr_stage_timing_begin) on `st`
+void stage_mark(hipStream_t st);
+
+bool tiled_supported(int n_out, const int64_t* grid);
+bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G);
 size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
                              int64_t P, int64_t B);
 

@@ -1,23 +1,735 @@
-// DPR_ALGO_TILED -- placeholder translation unit (filled in below in later commits)
+// DPR_ALGO_TILED: per-pose binning of the points into voxel tiles, then one workgroup per
+// tile that keeps the tile in LDS.  No global float atomics anywhere on this path.
+//
+// Per pose b (sequential launches on the caller's stream, workspace reused):
+//   K1 k_count    each block histograms its slice of the points by PRIMARY tile (the tile
+//                 holding max(ref,0)) in LDS and stores one row of the counts table
+//   K2 k_colscan  column-wise exclusive prefix of the table (per tile over blocks) + totals
+//      k_tilescan exclusive scan of the tile totals -> tile_start[]
+//   K3 k_scatter  each block re-reads its slice and writes one record {p, point_weight}
+//                 (+ original index for the pullback) per in-range point at its final
+//                 position (LDS cursors seeded from the table: no global atomics, exact
+//                 capacity P, placement deterministic per block)
+//   forward  K4 k_tile_splat   LDS tile (+1 upper halo) of f64 accumulators, ds_add_f64;
+//                              owned voxels leave with plain coalesced stores fused with the
+//                              background; the halo goes to a compact per-tile halo buffer
+//            K5 k_halo_gather  every low-face voxel adds the (<= 2^N-1) neighbour halos
+//   pullback K4 k_tile_gather  ds_dout tile (+halo) staged in LDS, per-point gathers from
+//                              LDS, ds_dpoints/ds_dpoint_weight written by the single owner
+//                              of each point, per-tile partial sums of the per-pose scalars
+//            K5 k_pose_reduce  sums the per-tile partials (f64) into ds_drotation etc.
+//
+// Why f64 accumulators for fp32 data: on gfx950 ds_add_f32 retires ~1 lane per 3 cycles
+// (193 cycles per wave-instruction, measured), while ds_add_f64 takes ~26 cycles per
+// wave-instruction (profiles/r01_microbench.txt).  It also makes fp32 results practically
+// independent of the accumulation order.
+#include <hip/hip_runtime.h>
+
 #include "../../include/dpr.h"
+#include "dpr_device.h"
 #include "dpr_tiled.h"
 
 namespace dpr {
 
-bool tiled_preferred(int, int, int64_t, int64_t, int64_t) { return false; }
+// ------------------------------------------------------------------ tile geometry
+template <int NO> struct TileDims;
+template <> struct TileDims<3> {
+    static constexpr int T[3] = {32, 16, 8};
+};
+template <> struct TileDims<2> {
+    static constexpr int T[3] = {32, 32, 1};
+};
+constexpr int kMaxTiles = 32768;     // LDS cursor table: 4 B per tile, <= 128 KiB
+constexpr int kBinThreads = 1024;    // K1 / K3 block
+constexpr int kTileThreads = 512;    // K4 block
+constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
 
-size_t tiled_workspace_bytes(size_t, int, int, int, const int64_t*, int64_t, int64_t) { return 0; }
+template <int NO> struct TileGeom {
+    int nt[NO];  // tiles per axis
+    int NT;      // tiles per pose
+};
 
+template <int NO> __host__ __device__ constexpr int tile_voxels() {
+    int v = 1;
+    for (int d = 0; d < NO; ++d) v *= TileDims<NO>::T[d];
+    return v;
+}
+template <int NO> __host__ __device__ constexpr int tile_voxels_halo() {
+    int v = 1;
+    for (int d = 0; d < NO; ++d) v *= TileDims<NO>::T[d] + 1;
+    return v;
+}
+template <int NO> __host__ __device__ constexpr int halo_count() {
+    return tile_voxels_halo<NO>() - tile_voxels<NO>();
+}
+
+template <int NO> static bool make_geom(const int64_t* grid, TileGeom<NO>* tg) {
+    int64_t NT = 1;
+    for (int d = 0; d < NO; ++d) {
+        tg->nt[d] = (int)((grid[d] + TileDims<NO>::T[d] - 1) / TileDims<NO>::T[d]);
+        NT *= tg->nt[d];
+    }
+    if (NT > kMaxTiles) return false;
+    tg->NT = (int)NT;
+    return true;
+}
+
+// primary tile of a point: tile of max(ref0, 0) per axis (ref0 in [-1, n-1])
+template <int NO>
+__device__ __forceinline__ int primary_tile(const int (&ref0)[NO], const TileGeom<NO>& tg) {
+    int t = 0, stride = 1;
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        const int r = ref0[d] < 0 ? 0 : ref0[d];
+        t += (r / TileDims<NO>::T[d]) * stride;
+        stride *= tg.nt[d];
+    }
+    return t;
+}
+
+template <int NO>
+__device__ __forceinline__ void tile_origin(int tile, const TileGeom<NO>& tg, int (&x0)[NO],
+                                            int (&tc)[NO]) {
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        tc[d] = tile % tg.nt[d];
+        tile /= tg.nt[d];
+        x0[d] = tc[d] * TileDims<NO>::T[d];
+    }
+}
+
+// index inside the (T+1)^N LDS tile
+template <int NO> __device__ __forceinline__ int lds_index(const int (&l)[NO]) {
+    int idx = 0, stride = 1;
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        idx += l[d] * stride;
+        stride *= TileDims<NO>::T[d] + 1;
+    }
+    return idx;
+}
+
+// Compact halo layout of one tile.  h has at least one coordinate equal to T[d].
+//   3-D: X-face (h_x == TX)            (TY+1)(TZ+1) values, index h_y + (TY+1) h_z
+//        Y-face (h_y == TY, h_x < TX)  TX (TZ+1)    values, index h_x + TX h_z
+//        Z-face (h_z == TZ, rest low)  TX TY        values, index h_x + TX h_y
+//   2-D: X-face (TY+1) values, then Y-face TX values.
+template <int NO> __device__ __forceinline__ int halo_index(const int (&h)[NO]) {
+    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+    if constexpr (NO == 2) {
+        return (h[0] == TX) ? h[1] : (TY + 1) + h[0];
+    } else {
+        constexpr int TZ = TileDims<NO>::T[2];
+        if (h[0] == TX) return h[1] + (TY + 1) * h[2];
+        if (h[1] == TY) return (TY + 1) * (TZ + 1) + h[0] + TX * h[2];
+        return (TY + 1) * (TZ + 1) + TX * (TZ + 1) + h[0] + TX * h[1];
+    }
+}
+
+// One binned record: {p_1..p_NI (0-padded to 3), point_weight}, 4 values of T moved as one
+// 16-byte (fp32) / 32-byte (fp64) aligned vector.
+template <typename T> struct alignas(4 * sizeof(T)) Rec4 {
+    T v[4];
+};
+
+// ------------------------------------------------------------------ K1: count
 template <typename T, int NI, int NO>
-int raster_tiled(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, T*, const T*, const T*,
-                 const T*, const T*, const T*, const T*, void*, size_t) {
-    return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED not built");
+__global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom<NO> tg, int64_t P,
+                                                       int64_t chunk, const T* __restrict__ points,
+                                                       const T* __restrict__ rot,
+                                                       const T* __restrict__ trans, int64_t b,
+                                                       uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t hist[];
+    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) hist[i] = 0;
+    __syncthreads();
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
+    for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
+        T pt[NI];
+        load_point<T, NI>(points, p, pt);
+        int ref0[NO];
+        T dlo[NO];
+        if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo))
+            atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = counts + (size_t)blockIdx.x * tg.NT;
+    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) row[i] = hist[i];
+}
+
+// ------------------------------------------------------------------ K2: scans
+// counts[nblk][NT] -> in place exclusive prefix down each column; totals[NT].
+// Block = 64 tiles x 16 row groups.
+__global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
+                                                  uint32_t* __restrict__ totals) {
+    __shared__ uint32_t part[16][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 64 + j;
+    const int rows = (nblk + 15) / 16;
+    const int r0 = g * rows, r1 = (r0 + rows < nblk) ? r0 + rows : nblk;
+    uint32_t s = 0;
+    if (tile < NT)
+        for (int r = r0; r < r1; ++r) s += counts[(size_t)r * NT + tile];
+    part[g][j] = s;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t v = part[k][j];
+        if (k < g) base += v;
+        total += v;
+    }
+    if (tile < NT) {
+        for (int r = r0; r < r1; ++r) {
+            const uint32_t c = counts[(size_t)r * NT + tile];
+            counts[(size_t)r * NT + tile] = base;
+            base += c;
+        }
+        if (g == 0) totals[tile] = total;
+    }
+}
+
+// exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768)
+__global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ totals, int NT,
+                                                   uint32_t* __restrict__ tile_start) {
+    __shared__ uint32_t wsum[16];
+    const int per = (NT + 1023) / 1024;
+    const int i0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (int i = i0; i < i0 + per && i < NT; ++i) s += totals[i];
+    // block exclusive scan of s
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= o) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += wsum[w];
+    uint32_t run = wbase + incl - s;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        tile_start[i] = run;
+        run += totals[i];
+    }
+    if (threadIdx.x == 1023) tile_start[NT] = wbase + incl;
+}
+
+// ------------------------------------------------------------------ K3: scatter
+// Record = NI coordinates + point weight (REC = NI + 1 values of T); idx separately.
+template <typename T, int NI, int NO, bool PULLBACK>
+__global__ __launch_bounds__(kBinThreads) void k_scatter(
+    GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
+    const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
+    Rec4<T>* __restrict__ rec, uint32_t* __restrict__ rec_idx, T* __restrict__ ds_dpoints,
+    T* __restrict__ ds_dpw, int zero_dropped) {
+    extern __shared__ uint32_t cursor[];
+    const uint32_t* row = prefix + (size_t)blockIdx.x * tg.NT;
+    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) cursor[i] = tile_start[i] + row[i];
+    __syncthreads();
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
+    for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
+        T pt[NI];
+        load_point<T, NI>(points, p, pt);
+        int ref0[NO];
+        T dlo[NO];
+        if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
+            const uint32_t pos = atomicAdd(&cursor[primary_tile<NO>(ref0, tg)], 1u);
+            Rec4<T> r;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[(j < NI) ? j : 0] : T(0);
+            r.v[3] = pw ? pw[p] : T(1);
+            rec[pos] = r;
+            if (PULLBACK) rec_idx[pos] = (uint32_t)p;
+        } else if (PULLBACK && zero_dropped) {
+            // no in-range voxel: empty gradient (written once, by the first pose)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
+            ds_dpw[p] = T(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ forward K4
+template <typename T, int NI, int NO>
+__global__ __launch_bounds__(kTileThreads) void k_tile_splat(
+    GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
+    const uint32_t* __restrict__ tile_start, const T* __restrict__ rot,
+    const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b,
+    T* __restrict__ out, T* __restrict__ halo) {
+    constexpr int NVH = tile_voxels_halo<NO>();
+    constexpr int NV = tile_voxels<NO>();
+    __shared__ double acc[NVH];
+    for (int i = threadIdx.x; i < NVH; i += kTileThreads) acc[i] = 0.0;
+    __syncthreads();
+    const int tile = blockIdx.x;
+    int x0[NO], tc[NO];
+    tile_origin<NO>(tile, tg, x0, tc);
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += kTileThreads) {
+        T pt[NI];
+        const Rec4<T> rc = rec[r];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
+        const T w = ps.ow * rc.v[3];  // src/raster.jl:52
+        int ref0[NO];
+        T dlo[NO];
+        ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) {
+            int l[NO];
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int i = ref0[d] + ((s >> d) & 1);
+                ok = ok && (i >= 0) && (i < gd.n[d]);  // individual drop, src/raster.jl:62
+                l[d] = i - x0[d];
+            }
+            if (ok) atomicAdd(&acc[lds_index<NO>(l)], (double)voxel_weight<T, NO>(dlo, s, w));
+        }
+    }
+    __syncthreads();
+    // owned voxels: out = background + acc   (plain stores, rows of TX contiguous values)
+    const double bgv = bg ? (double)bg[b] : 0.0;
+    T* o = out + b * gd.G;
+    for (int i = threadIdx.x; i < NV; i += kTileThreads) {
+        int l[NO], rem = i;
+        int off = 0, stride = 1;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            l[d] = rem % TileDims<NO>::T[d];
+            rem /= TileDims<NO>::T[d];
+            const int gcoord = x0[d] + l[d];
+            ok = ok && gcoord < gd.n[d];
+            off += gcoord * stride;
+            stride *= gd.n[d];
+        }
+        if (ok) o[off] = (T)(bgv + acc[lds_index<NO>(l)]);
+    }
+    // upper halo -> compact per-tile buffer (always fully written, zeros included)
+    T* hb = halo + (size_t)tile * halo_count<NO>();
+    for (int i = threadIdx.x; i < NVH; i += kTileThreads) {
+        int h[NO], rem = i;
+        bool is_halo = false;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            h[d] = rem % (TileDims<NO>::T[d] + 1);
+            rem /= TileDims<NO>::T[d] + 1;
+            is_halo = is_halo || (h[d] == TileDims<NO>::T[d]);
+        }
+        if (is_halo) hb[halo_index<NO>(h)] = (T)acc[i];
+    }
+}
+
+// ------------------------------------------------------------------ forward K5
+// One block per tile; threads walk the tile's low-face voxels and add what the lower
+// neighbours accumulated for them.  Gather form: each voxel has exactly one writer.
+template <typename T, int NO>
+__global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<NO> tg,
+                                                     const T* __restrict__ halo, int64_t b,
+                                                     T* __restrict__ out) {
+    constexpr int NV = tile_voxels<NO>();
+    const int tile = blockIdx.x;
+    int x0[NO], tc[NO];
+    tile_origin<NO>(tile, tg, x0, tc);
+    T* o = out + b * gd.G;
+    for (int i = threadIdx.x; i < NV; i += 256) {
+        int l[NO], rem = i;
+        int off = 0, stride = 1;
+        bool ok = true, low = false;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            l[d] = rem % TileDims<NO>::T[d];
+            rem /= TileDims<NO>::T[d];
+            const int gcoord = x0[d] + l[d];
+            ok = ok && gcoord < gd.n[d];
+            low = low || (l[d] == 0 && tc[d] > 0);
+            off += gcoord * stride;
+            stride *= gd.n[d];
+        }
+        if (!ok || !low) continue;
+        double add = 0.0;
+#pragma unroll
+        for (int m = 1; m < (1 << NO); ++m) {
+            bool valid = true;
+            int h[NO];
+            int src = 0, tstride = 1;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const bool in_m = (m >> d) & 1;
+                valid = valid && (!in_m || (l[d] == 0 && tc[d] > 0));
+                h[d] = in_m ? TileDims<NO>::T[d] : l[d];
+                src += (tc[d] - (in_m ? 1 : 0)) * tstride;
+                tstride *= tg.nt[d];
+            }
+            if (valid) add += (double)halo[(size_t)src * halo_count<NO>() + halo_index<NO>(h)];
+        }
+        o[off] = (T)((double)o[off] + add);
+    }
+}
+
+// ------------------------------------------------------------------ pullback K4
+template <typename T, int NI, int NO>
+__global__ __launch_bounds__(kTileThreads) void k_tile_gather(
+    GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
+    const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
+    const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
+    const T* __restrict__ ow, int64_t b, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
+    double* __restrict__ partials, int first_pose) {
+    constexpr int NVH = tile_voxels_halo<NO>();
+    constexpr int NVAL = NO * NI + NO + 2;  // dR | dt | d out_weight | d background
+    constexpr int NW = kTileThreads / kWave;
+    __shared__ T tile_g[NVH];
+    __shared__ double red[NW][NVAL];
+    const int tile = blockIdx.x;
+    int x0[NO], tc[NO];
+    tile_origin<NO>(tile, tg, x0, tc);
+    const T* gb = g + b * gd.G;
+    // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground
+    double bg_sum = 0.0;
+    for (int i = threadIdx.x; i < NVH; i += kTileThreads) {
+        int rem = i, off = 0, stride = 1;
+        bool ok = true, owned = true;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            const int l = rem % (TileDims<NO>::T[d] + 1);
+            rem /= TileDims<NO>::T[d] + 1;
+            const int gcoord = x0[d] + l;
+            ok = ok && gcoord < gd.n[d];
+            owned = owned && l < TileDims<NO>::T[d];
+            off += gcoord * stride;
+            stride *= gd.n[d];
+        }
+        const T v = ok ? gb[off] : T(0);
+        tile_g[i] = v;
+        if (owned) bg_sum += (double)v;
+    }
+    __syncthreads();
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    double vals[NVAL];
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) vals[k] = 0.0;
+    vals[NVAL - 1] = bg_sum;
+    const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += kTileThreads) {
+        T pt[NI];
+        const Rec4<T> rc = rec[r];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
+        const T pwi = rc.v[3];
+        const uint32_t p = rec_idx[r];
+        int ref0[NO];
+        T dlo[NO];
+        ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        // neighbour offsets are looked up in the LDS tile; nbr_offset() only decides validity
+        T scaled[NO], dow_part, dpw_part;
+        int lbase[NO];
+#pragma unroll
+        for (int d = 0; d < NO; ++d) lbase[d] = ref0[d] - x0[d];
+        // point_backward wants a fetch(off) on the global offset; remap through a closure that
+        // recomputes the local index from the neighbour id instead (cheaper): inline variant.
+        {
+            T dcoord[NO];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
+            dow_part = T(0);
+            dpw_part = T(0);
+#pragma unroll
+            for (int s = 0; s < (1 << NO); ++s) {
+                int l[NO];
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < NO; ++d) {
+                    const int i = ref0[d] + ((s >> d) & 1);
+                    ok = ok && (i >= 0) && (i < gd.n[d]);
+                    l[d] = lbase[d] + ((s >> d) & 1);
+                }
+                if (!ok) continue;  // src/raster_pullback.jl:51
+                const T gi = tile_g[lds_index<NO>(l)];
+                const T dweight = voxel_weight<T, NO>(dlo, s, gi);  // :55
+                dow_part += dweight * pwi;                          // :57
+                dpw_part += dweight * ps.ow;                        // :58
+                const T factor = gi * ps.ow * pwi;                  // :60
+#pragma unroll
+                for (int n = 0; n < NO; ++n) dcoord[n] += factor * interp_weight<T, NO>(n, dlo, s);
+            }
+#pragma unroll
+            for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));  // :67
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) vals[n + j * NO] += (double)(scaled[n] * pt[j]);  // :69
+            vals[NO * NI + n] += (double)scaled[n];                                       // :68
+        }
+        vals[NO * NI + NO] += (double)dow_part;
+        T dp[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {  // rotation' * scaled (:70)
+            T v = ps.R[0 + j * NO] * scaled[0];
+#pragma unroll
+            for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
+            dp[j] = v;
+        }
+        // this thread is the only writer of point p for this pose
+        if (first_pose) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] = dp[j];
+            ds_dpw[p] = dpw_part;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] += dp[j];
+            ds_dpw[p] += dpw_part;
+        }
+    }
+    // per-tile partial sums of the per-pose scalars (f64), reduced later by k_pose_reduce
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) {
+        const double s = wave_sum<double>(vals[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NVAL) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
+        partials[(size_t)tile * 16 + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------ pullback K5
+// partials[NT][16] (f64) -> the per-pose outputs of pose b.  Block = 16 x 64 threads.
+template <typename T, int NI, int NO>
+__global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__ partials, int NT,
+                                                      int64_t b, T* __restrict__ ds_drotation,
+                                                      T* __restrict__ ds_dtranslation,
+                                                      T* __restrict__ ds_dbackground,
+                                                      T* __restrict__ ds_dout_weight) {
+    constexpr int NVAL = NO * NI + NO + 2;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s = 0.0;
+    if (k < NVAL)
+        for (int t = lane; t < NT; t += 64) s += partials[(size_t)t * 16 + k];
+    s = wave_sum<double>(s);
+    if (lane == 0 && k < NVAL) {
+        if (k < NO * NI)
+            ds_drotation[b * (NO * NI) + k] = (T)s;
+        else if (k < NO * NI + NO)
+            ds_dtranslation[b * NO + (k - NO * NI)] = (T)s;
+        else if (k == NO * NI + NO)
+            ds_dout_weight[b] = (T)s;
+        else
+            ds_dbackground[b] = (T)s;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Plan {
+    int nblk;
+    int64_t chunk;
+    size_t off_counts, off_totals, off_tile_start, off_rec, off_idx, off_aux, total;
+};
+
+static Plan make_plan(size_t elem, int op, int n_in, int n_out, int NT, int64_t P) {
+    Plan pl;
+    int64_t nblk = (P + 8191) / 8192;
+    if (nblk < 1) nblk = 1;
+    if (nblk > kMaxBinBlocks) nblk = kMaxBinBlocks;
+    int64_t chunk = (P + nblk - 1) / nblk;
+    chunk = (chunk + kBinThreads - 1) / kBinThreads * kBinThreads;
+    if (chunk < kBinThreads) chunk = kBinThreads;
+    nblk = (P + chunk - 1) / chunk;
+    if (nblk < 1) nblk = 1;
+    pl.nblk = (int)nblk;
+    pl.chunk = chunk;
+    size_t o = 0;
+    pl.off_counts = o;
+    o += align_up((size_t)nblk * NT * 4);
+    pl.off_totals = o;
+    o += align_up((size_t)NT * 4);
+    pl.off_tile_start = o;
+    o += align_up((size_t)(NT + 1) * 4);
+    pl.off_rec = o;
+    (void)n_in;
+    o += align_up((size_t)P * 4 * elem);
+    pl.off_idx = o;
+    if (op == DPR_OP_PULLBACK) o += align_up((size_t)P * 4);
+    pl.off_aux = o;
+    const int halo = (n_out == 3) ? halo_count<3>() : halo_count<2>();
+    o += (op == DPR_OP_RASTER) ? align_up((size_t)NT * halo * elem)   // halo buffer
+                               : align_up((size_t)NT * 16 * 8);      // per-tile partials
+    pl.total = o;
+    return pl;
+}
+
+bool tiled_supported(int n_out, const int64_t* grid) {
+    if (n_out == 3) {
+        TileGeom<3> tg;
+        return make_geom<3>(grid, &tg);
+    }
+    TileGeom<2> tg;
+    return make_geom<2>(grid, &tg);
+}
+
+bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G) {
+    if (!tiled_supported(n_out, grid)) return false;
+    if (P >= (int64_t)1 << 32) return false;
+    // Fixed cost: ~6 launches per pose.  The direct path costs ~0.4 ns/point forward
+    // (scattered global atomics) and ~0.1 ns/point backward (scattered gathers).
+    (void)G;
+    (void)B;
+    return op == DPR_OP_RASTER ? P >= 300000 : P >= 2000000;
+}
+
+size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
+                             int64_t P, int64_t B) {
+    (void)B;
+    int NT;
+    if (n_out == 3) {
+        TileGeom<3> tg;
+        if (!make_geom<3>(grid, &tg)) return (size_t)-1;
+        NT = tg.NT;
+    } else {
+        TileGeom<2> tg;
+        if (!make_geom<2>(grid, &tg)) return (size_t)-1;
+        NT = tg.NT;
+    }
+    return make_plan(elem, op, n_in, n_out, NT, P).total;
+}
+
+#define DPR_HIP(expr)                                                                \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        DPR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    return DPR_OK;
 }
 
 template <typename T, int NI, int NO>
-int pullback_tiled(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, const T*, const T*,
-                   const T*, const T*, const T*, const T*, T*, T*, T*, T*, T*, T*, void*, size_t) {
-    return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED not built");
+static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
+                      const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
+                      const T* rot, const T* trans, int64_t b, bool pullback, T* d_pts, T* d_pw,
+                      int zero_dropped) {
+    uint32_t* counts = (uint32_t*)(ws + pl.off_counts);
+    uint32_t* totals = (uint32_t*)(ws + pl.off_totals);
+    uint32_t* tile_start = (uint32_t*)(ws + pl.off_tile_start);
+    Rec4<T>* rec = (Rec4<T>*)(ws + pl.off_rec);
+    uint32_t* rec_idx = (uint32_t*)(ws + pl.off_idx);
+    const size_t lds = (size_t)tg.NT * 4;
+    if (int rc = allow_big_lds(k_count<T, NI, NO>, lds)) return rc;
+    hipLaunchKernelGGL((k_count<T, NI, NO>), dim3(pl.nblk), dim3(kBinThreads), lds, st, gd, tg, P,
+                       pl.chunk, points, rot, trans, b, counts);
+    stage_mark(st);
+    hipLaunchKernelGGL(k_colscan, dim3((tg.NT + 63) / 64), dim3(1024), 0, st, counts, pl.nblk,
+                       tg.NT, totals);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, tile_start);
+    stage_mark(st);
+    if (pullback) {
+        if (int rc = allow_big_lds(k_scatter<T, NI, NO, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_scatter<T, NI, NO, true>), dim3(pl.nblk), dim3(kBinThreads), lds, st,
+                           gd, tg, P, pl.chunk, points, pw, rot, trans, b, counts, tile_start, rec,
+                           rec_idx, d_pts, d_pw, zero_dropped);
+    } else {
+        if (int rc = allow_big_lds(k_scatter<T, NI, NO, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_scatter<T, NI, NO, false>), dim3(pl.nblk), dim3(kBinThreads), lds,
+                           st, gd, tg, P, pl.chunk, points, pw, rot, trans, b, counts, tile_start,
+                           rec, rec_idx, (T*)nullptr, (T*)nullptr, 0);
+    }
+    stage_mark(st);
+    return DPR_OK;
+}
+
+template <int NO> static GridDesc<NO> make_grid_desc(const int64_t* grid, int64_t G) {
+    GridDesc<NO> gd;
+    for (int d = 0; d < NO; ++d) gd.n[d] = (int)grid[d];
+    gd.G = G;
+    return gd;
+}
+
+template <typename T, int NI, int NO>
+int raster_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B, T* out,
+                 const T* points, const T* rot, const T* trans, const T* bg, const T* ow,
+                 const T* pw, void* ws_, size_t ws_bytes) {
+    TileGeom<NO> tg;
+    if (!make_geom<NO>(grid, &tg))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
+                    kMaxTiles);
+    if (P >= (int64_t)1 << 32)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
+    const Plan pl = make_plan(sizeof(T), DPR_OP_RASTER, NI, NO, tg.NT, P);
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
+                    pl.total, ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
+    T* halo = (T*)(ws + pl.off_aux);
+    for (int64_t b = 0; b < B; ++b) {
+        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, false,
+                                           (T*)nullptr, (T*)nullptr, 0))
+            return rc;
+        hipLaunchKernelGGL((k_tile_splat<T, NI, NO>), dim3(tg.NT), dim3(kTileThreads), 0, st, gd,
+                           tg, (const Rec4<T>*)(ws + pl.off_rec),
+                           (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b, out,
+                           halo);
+        stage_mark(st);
+        hipLaunchKernelGGL((k_halo_gather<T, NO>), dim3(tg.NT), dim3(256), 0, st, gd, tg,
+                           (const T*)halo, b, out);
+        stage_mark(st);
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+template <typename T, int NI, int NO>
+int pullback_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                   const T* g, const T* points, const T* rot, const T* trans, const T* ow,
+                   const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw,
+                   void* ws_, size_t ws_bytes) {
+    TileGeom<NO> tg;
+    if (!make_geom<NO>(grid, &tg))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
+                    kMaxTiles);
+    if (P >= (int64_t)1 << 32)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
+    const Plan pl = make_plan(sizeof(T), DPR_OP_PULLBACK, NI, NO, tg.NT, P);
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE,
+                    "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
+                    ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
+    double* partials = (double*)(ws + pl.off_aux);
+    for (int64_t b = 0; b < B; ++b) {
+        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, true,
+                                           d_pts, d_pw, b == 0))
+            return rc;
+        hipLaunchKernelGGL((k_tile_gather<T, NI, NO>), dim3(tg.NT), dim3(kTileThreads), 0, st, gd,
+                           tg, (const Rec4<T>*)(ws + pl.off_rec), (const uint32_t*)(ws + pl.off_idx),
+                           (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b, d_pts,
+                           d_pw, partials, b == 0);
+        stage_mark(st);
+        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(1), dim3(1024), 0, st,
+                           (const double*)partials, tg.NT, b, d_rot, d_trans, d_bg, d_ow);
+        stage_mark(st);
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
 }
 
 #define DPR_INST(T, NI, NO)                                                                      \

@@ -101,6 +101,14 @@ def _as(t, dtype, device, shape=None, name="argument") -> torch.Tensor:
     return t.contiguous()
 
 
+def _scalar(x) -> torch.Tensor:
+    """Single-pose scalar argument -> 1-element vector (src/interface.jl:113-116) without
+    rounding a Python float through float32."""
+    if isinstance(x, torch.Tensor):
+        return x.reshape(1)
+    return torch.as_tensor(x, dtype=torch.float64).reshape(1)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -138,6 +146,19 @@ def workspace_bytes(op: str, grid_size, n_points: int, batch: int, n_in: int, dt
     return int(need)
 
 
+def resolve_algo(op: str, grid_size, n_points: int, batch: int, n_in: int) -> str:
+    """Name of the algorithm `algo="auto"` picks for this problem."""
+    import numpy as np
+
+    grid_arr = np.asarray(grid_size, dtype=np.int64)
+    opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
+    rc = _lib.lib().dpr_resolve_algo(opc, n_in, len(grid_size),
+                                     grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
+    if rc < 0:
+        _lib.check(rc)
+    return {v: k for k, v in _lib.ALGOS.items()}[rc]
+
+
 def _check_dims(n_in_pts, rot_shape, trans_shape):
     """Step 5 of the reference funnel: explicit dimension errors
     (src/interface.jl:137-162, 315-366)."""
@@ -168,8 +189,8 @@ def _canonicalise(points, rotation, translation, background, out_weight, point_w
         if translation_t.ndim != 1:
             raise DimensionMismatch("single-pose translation must be a vector")
         translation_t = translation_t[None]
-        background = None if background is None else torch.as_tensor(background).reshape(1)
-        out_weight = None if out_weight is None else torch.as_tensor(out_weight).reshape(1)
+        background = None if background is None else _scalar(background)
+        out_weight = None if out_weight is None else _scalar(out_weight)
     if translation_t.ndim != 2:
         raise DimensionMismatch("batched translation must be (B, N_out)")
     P, n_in = points.shape

@@ -1,0 +1,64 @@
+"""Per-stage device timing of one raster / pullback call through the library's
+dpr_stage_timing_begin/end hooks (include/dpr.h).  The events are raw hipEvent_t objects
+recorded by libdpr on the very stream its kernels are enqueued on."""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List
+
+from . import _lib
+
+STAGES = {
+    ("raster", "atomic"): ["fill", "splat"],
+    ("pullback", "atomic"): ["zero+grid_sum", "gather"],
+    ("raster", "tiled"): ["count", "scan", "scatter", "tile_splat", "halo"],
+    ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "pose_reduce"],
+}
+
+_hip = None
+
+
+def _hiprt():
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        _hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        _hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        _hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p,
+                                             ctypes.c_void_p]
+    return _hip
+
+
+def stage_times(call: Callable[[], None], op: str, algo: str, reps: int = 10,
+                max_events: int = 64) -> Dict[str, float]:
+    """Run `call` (ONE dpr raster/pullback invocation with B == 1) `reps` times with stage
+    timing armed; returns {stage: mean ms} plus "total"."""
+    hip = _hiprt()
+    L = _lib.lib()
+    names = STAGES[(op, algo)]
+    acc: List[float] = [0.0] * len(names)
+    events = (ctypes.c_void_p * max_events)()
+    for i in range(max_events):
+        ev = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(ev)) == 0
+        events[i] = ev
+    try:
+        for _ in range(reps):
+            _lib.check(L.dpr_stage_timing_begin(events, max_events))
+            try:
+                call()
+            finally:
+                n = L.dpr_stage_timing_end()
+            assert n == len(names) + 1, f"expected {len(names) + 1} stage marks, got {n}"
+            assert hip.hipEventSynchronize(events[n - 1]) == 0
+            for k in range(len(names)):
+                ms = ctypes.c_float()
+                assert hip.hipEventElapsedTime(ctypes.byref(ms), events[k], events[k + 1]) == 0
+                acc[k] += ms.value
+    finally:
+        for i in range(max_events):
+            hip.hipEventDestroy(events[i])
+    out = {nm: acc[k] / reps for k, nm in enumerate(names)}
+    out["total"] = sum(out.values())
+    return out

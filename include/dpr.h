@@ -76,6 +76,21 @@ int dpr_version(void);
 /* Thread-local message of the last failing call on this host thread ("" if none). */
 const char *dpr_last_error(void);
 
+/* Algorithm DPR_ALGO_AUTO resolves to for this problem (DPR_ALGO_ATOMIC or DPR_ALGO_TILED),
+ * or a negative status. */
+int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t *grid, int64_t P, int64_t B);
+
+/* Optional per-stage device timing (used by bench.py for the roofline numbers): arm an
+ * array of `capacity` hipEvent_t created by the caller; until dpr_stage_timing_end() every
+ * raster / pullback call on THIS host thread records events[0] when it starts enqueuing
+ * and the next event after each stage of its pipeline, on the call's stream.
+ * dpr_stage_timing_end() disarms and returns the number of events recorded.
+ * Stage order -- DPR_ALGO_ATOMIC raster: fill, splat; pullback: zero+grid_sum, gather.
+ * DPR_ALGO_TILED, per pose -- raster: count, scan, scatter, tile_splat, halo;
+ * pullback: count, scan, scatter, tile_gather, pose_reduce. */
+int dpr_stage_timing_begin(void **events, int capacity);
+int dpr_stage_timing_end(void);
+
 /* Bytes of caller-provided device workspace needed by `op` with `algo`
  * (may be 0).  Returns (size_t)-1 on invalid arguments. */
 size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t *grid,

@@ -3,9 +3,12 @@ oracle, the reference's golden vectors, and size-independent properties at BASEL
 
 Tolerances:
   fp64  norm-wise rtol 1e-10  (the reference's own `≈` would allow sqrt(eps) = 1.5e-8)
-  fp32  vs the fp32 oracle (identical per-contribution arithmetic, different summation
-        order): norm-wise 1e-5 for `out`, 1e-4 for ds_dpoints / ds_dpoint_weight,
-        1e-3 for the per-pose sums (rotation / translation / out_weight / background)
+  fp32  vs the fp32 oracle (identical per-contribution arithmetic, hence identical cell
+        choice; different summation order -- the oracle sums sequentially in fp32, the
+        tiled path accumulates in fp64): norm-wise 5e-5 for `out`, 1e-4 for ds_dpoints /
+        ds_dpoint_weight, 1e-3 for the per-pose sums (rotation / translation / out_weight /
+        background); `out` is additionally checked against the fp64 oracle on the same
+        fp32 inputs (continuous across cell flips) at 5e-5
 """
 import numpy as np
 import pytest
@@ -44,7 +47,7 @@ def grid_to_dev(a, dev):
 def tol(npdt, kind):
     if npdt == np.float64:
         return 1e-10
-    return {"out": 1e-5, "points": 1e-4, "pose": 1e-3}[kind]
+    return {"out": 5e-5, "points": 1e-4, "pose": 1e-3}[kind]
 
 
 def assert_close(actual, expected, rtol, what=""):
@@ -108,6 +111,9 @@ def _run_both(oracle, dev, d, npdt, algo, with_optional=True):
     pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), T(d.points, dev),
                                   T(d.rotations, dev), T(d.translations, dev), T(opt[0], dev),
                                   T(opt[1], dev), T(opt[2], dev), algo=algo)
+    if npdt == np.float32:
+        ref64 = oracle.raster(d.grid, d.points, d.rotations, d.translations, *opt, dtype=np.float64)
+        assert_close(out, ref64.astype(np.float32), 5e-5, "out vs fp64 oracle")
     return ref_out, ref_pb, out, pb
 
 

@@ -1,0 +1,83 @@
+// LDS atomic rate probes (design aid, not product).  Each kernel: 256-thread blocks,
+// 8 per CU, every thread issues ITERS x 8 LDS ops with precomputed addresses.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+constexpr int TILE = 4096;  // 16 KB of floats
+
+// MODE 0: ds_add_f32 random   1: ds_add_f32 conflict-free (lane-linear)   2: ds_add_f32 same addr
+// 3: ds_add_u32 random   4: ds_write_b32 random   5: ds_add_rtn_f32 random  6: ds_add_f64 random (half tile)
+// 7: ds_add_f32 "splat-like": 4 x-adjacent pairs around a random base  8: ds_pk_add? (skip)
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* outp, int iters) {
+    __shared__ double tile_d[TILE / 2];
+    float* tile = (float*)tile_d;
+    uint32_t* tile_u = (uint32_t*)tile_d;
+    for (int i = threadIdx.x; i < TILE; i += 256) tile[i] = 0;
+    __syncthreads();
+    uint32_t h = hash32(blockIdx.x * 256 + threadIdx.x + 1);
+    int a[8];
+    for (int s = 0; s < 8; ++s) {
+        h = hash32(h);
+        if (MODE == 1) a[s] = (threadIdx.x + 64 * s) & (TILE - 1);
+        else if (MODE == 2) a[s] = s;
+        else if (MODE == 7) a[s] = ((h % (TILE - 320))) ;  // base, reused below
+        else a[s] = h & (TILE - 1);
+    }
+    float acc = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int idx;
+            if (MODE == 7) idx = a[it & 7] + (s & 1) + 17 * ((s >> 1) & 1) + 289 * (s >> 2);
+            else idx = (a[s] + it * 67) & (TILE - 1);
+            if (MODE == 1) idx = (a[s] + it * 64) & (TILE - 1);
+            if (MODE == 2) idx = a[s];
+            if (MODE == 0 || MODE == 1 || MODE == 2 || MODE == 7) atomicAdd(&tile[idx], 0.5f);
+            if (MODE == 3) atomicAdd(&tile_u[idx], 3u);
+            if (MODE == 4) tile[idx] = (float)it;
+            if (MODE == 5) acc += atomicAdd(&tile[idx], 0.5f);
+            if (MODE == 6) atomicAdd(&tile_d[idx >> 1], 0.5);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE; i += 256) acc += tile[i];
+    if (acc == 1.2345f) outp[0] = acc;
+}
+
+template <int MODE> void run(const char* name, float* sink, int blocks_per_cu) {
+    const int iters = 256, blocks = 256 * blocks_per_cu;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    k<MODE><<<blocks, 256>>>(sink, iters); CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(a)); k<MODE><<<blocks, 256>>>(sink, iters); CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+    }
+    double ops = (double)blocks * 256 * iters * 8;
+    // cycles per wave-instruction per CU at 2.4 GHz
+    double wave_instr_per_cu = ops / 64 / 256;
+    printf("%-34s blk/CU=%d : %8.3f ms  %8.1f G op/s  ~%6.1f cyc/wave-instr/CU\n", name, blocks_per_cu, best,
+           ops / best * 1e-6, best * 1e-3 * 2.4e9 / wave_instr_per_cu);
+}
+
+int main() {
+    float* sink; CK(hipMalloc(&sink, 1024));
+    for (int bpc : {1, 4, 8}) {
+        run<0>("ds_add_f32 random", sink, bpc);
+        run<1>("ds_add_f32 conflict-free", sink, bpc);
+        run<2>("ds_add_f32 8 hot addresses", sink, bpc);
+        run<3>("ds_add_u32 random", sink, bpc);
+        run<4>("ds_write_b32 random", sink, bpc);
+        run<5>("ds_add_rtn_f32 random", sink, bpc);
+        run<6>("ds_add_f64 random", sink, bpc);
+        run<7>("ds_add_f32 splat-like", sink, bpc);
+    }
+    return 0;
+}
