@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="point order in memory: as generated, or pre-sorted (pose-independent)")
     ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform"])
+    ap.add_argument("--no-share-binning", action="store_true",
+                    help="make the pullback redo the binning instead of reusing the forward's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -163,13 +165,20 @@ def main():
                    dpr_amd.workspace_bytes("pullback", grid, P, 1, n_in, tdt, args.algo))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
 
-    def fwd():
-        dpr_amd.raster_(out, inp["points"], inp["R"], inp["t"], algo=args.algo, workspace=ws)
+    algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P, 1, n_in)
+    algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P, 1, n_in)
+    # The pullback reuses the tile binning its forward call built in the same step (what an
+    # rrule caches between `raster` and its pullback closure); nothing is carried across steps.
+    share = (not args.no_share_binning) and algo_f == "tiled" and algo_b == "tiled"
 
-    def bwd():
+    def fwd(keep=share):
+        dpr_amd.raster_(out, inp["points"], inp["R"], inp["t"], algo=algo_f, workspace=ws,
+                        keep_binning=keep)
+
+    def bwd(reuse=share):
         dpr_amd.raster_pullback_(inp["ds_dout"], inp["points"], inp["R"], inp["t"],
-                                 ds_dpoints=d_pts, ds_dpoint_weight=d_pw, algo=args.algo,
-                                 workspace=ws)
+                                 ds_dpoints=d_pts, ds_dpoint_weight=d_pw, algo=algo_b,
+                                 workspace=ws, reuse_binning=reuse)
 
     def step():
         fwd()
@@ -212,8 +221,6 @@ def main():
     ms_fwd = event_time(fwd, reps)
     ms_bwd = event_time(bwd, reps)
     a_fwd, a_bwd = algorithmic_bytes(args.config)
-    algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P, 1, n_in)
-    algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P, 1, n_in)
     st_f = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
     st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps)
     stages = {"raster": {"algo": algo_f, **{k: round(v, 4) for k, v in st_f.items()}},
@@ -240,7 +247,8 @@ def main():
         "config": {"workload": f"{args.config}: {P} 3-D points ({'0.4*N(0,I)' if args.dist == 'gauss' else 'uniform(-.55,.55)'}, {args.order} order) -> "
                                f"{'x'.join(map(str, grid))} {dt} grid, one pose per GPU, "
                                f"raster! + raster_pullback!",
-                   "algo": args.algo, "poses_global": world, "point_order": args.order,
+                   "algo": {"raster": algo_f, "pullback": algo_b}, "pullback_reuses_forward_binning": share,
+                   "poses_global": world, "point_order": args.order,
                    "exchange": "all-reduce(sum) of [ds_dpoints|ds_dpoint_weight]" if world > 1 else "none"},
         "roofline": roof,
     }

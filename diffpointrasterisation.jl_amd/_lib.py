@@ -23,6 +23,8 @@ OP_PULLBACK = 1
 ALGO_AUTO = 0
 ALGO_ATOMIC = 1
 ALGO_TILED = 2
+FLAG_KEEP_BINNING = 1
+FLAG_REUSE_BINNING = 2
 ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED}
 
 EXPORTS = [
@@ -88,14 +90,14 @@ def lib() -> ctypes.CDLL:
         f.argtypes = [vp, i, i, vp, i64, i64] + [vp] * 7 + [vp, sz]
         f = getattr(L, f"dpr_raster_ex_{suf}")
         f.restype = i
-        f.argtypes = [vp, i, i, i, vp, i64, i64] + [vp] * 7 + [vp, sz]
+        f.argtypes = [vp, i, ctypes.c_uint, i, i, vp, i64, i64] + [vp] * 7 + [vp, sz]
         # stream, n_in, n_out, grid, P, B, ds_dout, points, rot, trans, ow, pw, 6 outputs, ws, ws_bytes
         f = getattr(L, f"dpr_raster_pullback_{suf}")
         f.restype = i
         f.argtypes = [vp, i, i, vp, i64, i64] + [vp] * 12 + [vp, sz]
         f = getattr(L, f"dpr_raster_pullback_ex_{suf}")
         f.restype = i
-        f.argtypes = [vp, i, i, i, vp, i64, i64] + [vp] * 12 + [vp, sz]
+        f.argtypes = [vp, i, ctypes.c_uint, i, i, vp, i64, i64] + [vp] * 12 + [vp, sz]
     _lib = L
     return L
 

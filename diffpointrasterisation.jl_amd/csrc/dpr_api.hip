@@ -110,7 +110,7 @@ static int raster_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t
 }
 
 template <typename T>
-static int raster_impl(void* stream, int algo, int n_in, int n_out, const int64_t* grid, int64_t P,
+static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid, int64_t P,
                        int64_t B, T* out, const T* points, const T* rot, const T* trans,
                        const T* bg, const T* ow, const T* pw, void* ws, size_t ws_bytes) {
     int64_t G = 0;
@@ -126,18 +126,19 @@ static int raster_impl(void* stream, int algo, int n_in, int n_out, const int64_
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                       \
     if (n_in == NI && n_out == NO) {                                                           \
-        if (algo == DPR_ALGO_ATOMIC)                                                           \
+        if (algo == DPR_ALGO_ATOMIC && flags == 0)                                             \
             return raster_atomic<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow, \
                                             pw);                                               \
         if (algo == DPR_ALGO_TILED)                                                            \
-            return raster_tiled<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow,  \
+            return raster_tiled<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot, trans, bg, ow,  \
                                            pw, ws, ws_bytes);                                  \
     }
     DPR_CASE(2, 2)
     DPR_CASE(3, 3)
     DPR_CASE(3, 2)
 #undef DPR_CASE
-    return fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
+    return fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d (flags %u need DPR_ALGO_TILED)", algo,
+                flags);
 }
 
 // ---------------------------------------------------------------- pullback
@@ -187,7 +188,7 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
 }
 
 template <typename T>
-static int pullback_impl(void* stream, int algo, int n_in, int n_out, const int64_t* grid,
+static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid,
                          int64_t P, int64_t B, const T* g, const T* points, const T* rot,
                          const T* trans, const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans,
                          T* d_bg, T* d_ow, T* d_pw, void* ws, size_t ws_bytes) {
@@ -213,11 +214,11 @@ static int pullback_impl(void* stream, int algo, int n_in, int n_out, const int6
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                         \
     if (n_in == NI && n_out == NO) {                                                             \
-        if (algo == DPR_ALGO_ATOMIC)                                                             \
+        if (algo == DPR_ALGO_ATOMIC && flags == 0)                                               \
             return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw,   \
                                               d_pts, d_rot, d_trans, d_bg, d_ow, d_pw);          \
         if (algo == DPR_ALGO_TILED)                                                              \
-            return pullback_tiled<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw,    \
+            return pullback_tiled<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans, ow, pw,    \
                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
                                              ws_bytes);                                          \
     }
@@ -285,11 +286,13 @@ size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int6
 }
 
 #define DPR_DEFINE(SUF, T)                                                                        \
-    int dpr_raster_ex_##SUF(void* stream, int algo, int n_in, int n_out, const int64_t* grid,     \
+    int dpr_raster_ex_##SUF(void* stream, int algo, unsigned flags, int n_in, int n_out,         \
+                            const int64_t* grid,                                                  \
                             int64_t P, int64_t B, T* out, const T* points, const T* rotation,     \
                             const T* translation, const T* background, const T* out_weight,       \
                             const T* point_weight, void* workspace, size_t workspace_bytes) {     \
-        return dpr::raster_impl<T>(stream, algo, n_in, n_out, grid, P, B, out, points, rotation,  \
+        return dpr::raster_impl<T>(stream, algo, flags, n_in, n_out, grid, P, B, out, points,     \
+                                   rotation,                                                      \
                                    translation, background, out_weight, point_weight, workspace,  \
                                    workspace_bytes);                                              \
     }                                                                                             \
@@ -297,17 +300,20 @@ size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int6
                          int64_t B, T* out, const T* points, const T* rotation,                   \
                          const T* translation, const T* background, const T* out_weight,          \
                          const T* point_weight, void* workspace, size_t workspace_bytes) {        \
-        return dpr::raster_impl<T>(stream, DPR_ALGO_AUTO, n_in, n_out, grid, P, B, out, points,   \
+        return dpr::raster_impl<T>(stream, DPR_ALGO_AUTO, 0u, n_in, n_out, grid, P, B, out,      \
+                                   points,                                                        \
                                    rotation, translation, background, out_weight, point_weight,   \
                                    workspace, workspace_bytes);                                   \
     }                                                                                             \
     int dpr_raster_pullback_ex_##SUF(                                                             \
-        void* stream, int algo, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B,   \
+        void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid,         \
+        int64_t P, int64_t B,                                                                     \
         const T* ds_dout, const T* points, const T* rotation, const T* translation,               \
         const T* out_weight, const T* point_weight, T* ds_dpoints, T* ds_drotation,               \
         T* ds_dtranslation, T* ds_dbackground, T* ds_dout_weight, T* ds_dpoint_weight,            \
         void* workspace, size_t workspace_bytes) {                                                \
-        return dpr::pullback_impl<T>(stream, algo, n_in, n_out, grid, P, B, ds_dout, points,      \
+        return dpr::pullback_impl<T>(stream, algo, flags, n_in, n_out, grid, P, B, ds_dout,       \
+                                     points,                                                      \
                                      rotation, translation, out_weight, point_weight, ds_dpoints, \
                                      ds_drotation, ds_dtranslation, ds_dbackground,               \
                                      ds_dout_weight, ds_dpoint_weight, workspace,                 \
@@ -319,7 +325,8 @@ size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int6
         const T* out_weight, const T* point_weight, T* ds_dpoints, T* ds_drotation,               \
         T* ds_dtranslation, T* ds_dbackground, T* ds_dout_weight, T* ds_dpoint_weight,            \
         void* workspace, size_t workspace_bytes) {                                                \
-        return dpr::pullback_impl<T>(stream, DPR_ALGO_AUTO, n_in, n_out, grid, P, B, ds_dout,     \
+        return dpr::pullback_impl<T>(stream, DPR_ALGO_AUTO, 0u, n_in, n_out, grid, P, B,         \
+                                     ds_dout,                                                     \
                                      points, rotation, translation, out_weight, point_weight,     \
                                      ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,   \
                                      ds_dout_weight, ds_dpoint_weight, workspace,                 \

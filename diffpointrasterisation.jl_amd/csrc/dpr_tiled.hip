@@ -126,11 +126,22 @@ template <int NO> __device__ __forceinline__ int halo_index(const int (&h)[NO]) 
     }
 }
 
-// One binned record: {p_1..p_NI (0-padded to 3), point_weight}, 4 values of T moved as one
-// 16-byte (fp32) / 32-byte (fp64) aligned vector.
+// One binned record, moved as one 16-byte (fp32) / 32-byte (fp64) aligned vector:
+//   v[0..2] = point coordinates (0-padded), v[3] = point weight            (HAS_PW)
+//                                           v[3] = bits of the point index (!HAS_PW;
+//   the default point_weight == 1 needs no storage, so the index rides for free)
+// With HAS_PW the original index lives in the separate rec_idx[] array.
 template <typename T> struct alignas(4 * sizeof(T)) Rec4 {
     T v[4];
 };
+__device__ __forceinline__ float idx_to_slot(uint32_t i, float) { return __uint_as_float(i); }
+__device__ __forceinline__ double idx_to_slot(uint32_t i, double) {
+    return __longlong_as_double((long long)i);
+}
+__device__ __forceinline__ uint32_t slot_to_idx(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t slot_to_idx(double v) {
+    return (uint32_t)__double_as_longlong(v);
+}
 
 // ------------------------------------------------------------------ K1: count
 template <typename T, int NI, int NO>
@@ -198,7 +209,6 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
     const int i0 = threadIdx.x * per;
     uint32_t s = 0;
     for (int i = i0; i < i0 + per && i < NT; ++i) s += totals[i];
-    // block exclusive scan of s
     uint32_t incl = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -218,8 +228,10 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------ K3: scatter
-// Record = NI coordinates + point weight (REC = NI + 1 values of T); idx separately.
-template <typename T, int NI, int NO, bool PULLBACK>
+// WANT_IDX: the binning will feed a pullback (original indices needed).
+// The next point is fetched before the current record is stored so that the wait for
+// it never includes the scattered store (vmcnt retires in issue order).
+template <typename T, int NI, int NO, bool HAS_PW, bool WANT_IDX>
 __global__ __launch_bounds__(kBinThreads) void k_scatter(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
@@ -233,9 +245,23 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
     const int64_t lo = (int64_t)blockIdx.x * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
-    for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
+    int64_t p = lo + threadIdx.x;
+    T nxt[NI], nxt_w = T(1);
+    if (p < hi) {
+        load_point<T, NI>(points, p, nxt);
+        if (HAS_PW) nxt_w = pw[p];
+    }
+    while (p < hi) {
         T pt[NI];
-        load_point<T, NI>(points, p, pt);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pt[j] = nxt[j];
+        const T w = nxt_w;
+        const int64_t pc = p;
+        p += kBinThreads;
+        if (p < hi) {
+            load_point<T, NI>(points, p, nxt);
+            if (HAS_PW) nxt_w = pw[p];
+        }
         int ref0[NO];
         T dlo[NO];
         if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
@@ -243,20 +269,20 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
             Rec4<T> r;
 #pragma unroll
             for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[(j < NI) ? j : 0] : T(0);
-            r.v[3] = pw ? pw[p] : T(1);
+            r.v[3] = HAS_PW ? w : idx_to_slot((uint32_t)pc, T(0));
             rec[pos] = r;
-            if (PULLBACK) rec_idx[pos] = (uint32_t)p;
-        } else if (PULLBACK && zero_dropped) {
+            if (HAS_PW && WANT_IDX) rec_idx[pos] = (uint32_t)pc;
+        } else if (zero_dropped) {
             // no in-range voxel: empty gradient (written once, by the first pose)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-            ds_dpw[p] = T(0);
+            for (int j = 0; j < NI; ++j) ds_dpoints[pc * NI + j] = T(0);
+            ds_dpw[pc] = T(0);
         }
     }
 }
 
 // ------------------------------------------------------------------ forward K4
-template <typename T, int NI, int NO>
+template <typename T, int NI, int NO, bool HAS_PW>
 __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
     const uint32_t* __restrict__ tile_start, const T* __restrict__ rot,
@@ -266,18 +292,23 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     constexpr int NV = tile_voxels<NO>();
     __shared__ double acc[NVH];
     for (int i = threadIdx.x; i < NVH; i += kTileThreads) acc[i] = 0.0;
-    __syncthreads();
     const int tile = blockIdx.x;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
-    const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += kTileThreads) {
+    const uint32_t r1 = tile_start[tile + 1];
+    uint32_t r = tile_start[tile] + threadIdx.x;
+    Rec4<T> nxt;
+    if (r < r1) nxt = rec[r];
+    __syncthreads();
+    while (r < r1) {
+        const Rec4<T> rc = nxt;
+        r += kTileThreads;
+        if (r < r1) nxt = rec[r];
         T pt[NI];
-        const Rec4<T> rc = rec[r];
 #pragma unroll
         for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
-        const T w = ps.ow * rc.v[3];  // src/raster.jl:52
+        const T w = HAS_PW ? ps.ow * rc.v[3] : ps.ow * T(1);  // src/raster.jl:52
         int ref0[NO];
         T dlo[NO];
         ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
@@ -329,25 +360,61 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
 }
 
 // ------------------------------------------------------------------ forward K5
+// Low-face voxels of a tile, enumerated compactly:
+//   3-D: [0, TX*TY) the z == 0 face; then y == 0 (z > 0); then x == 0 (y > 0, z > 0)
+//   2-D: [0, TX) the y == 0 row; then x == 0 (y > 0)
+template <int NO> __host__ __device__ constexpr int low_face_count() {
+    if (NO == 2) return TileDims<2>::T[0] + TileDims<2>::T[1] - 1;
+    return TileDims<3>::T[0] * TileDims<3>::T[1] + TileDims<3>::T[0] * (TileDims<3>::T[2] - 1) +
+           (TileDims<3>::T[1] - 1) * (TileDims<3>::T[2] - 1);
+}
+template <int NO> __device__ __forceinline__ void low_face_coords(int i, int (&l)[NO]) {
+    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+    if constexpr (NO == 2) {
+        if (i < TX) {
+            l[0] = i;
+            l[1] = 0;
+        } else {
+            l[0] = 0;
+            l[1] = 1 + (i - TX);
+        }
+    } else {
+        constexpr int TZ = TileDims<NO>::T[2];
+        if (i < TX * TY) {
+            l[0] = i % TX;
+            l[1] = i / TX;
+            l[2] = 0;
+        } else if (i < TX * TY + TX * (TZ - 1)) {
+            const int j = i - TX * TY;
+            l[0] = j % TX;
+            l[1] = 0;
+            l[2] = 1 + j / TX;
+        } else {
+            const int j = i - TX * TY - TX * (TZ - 1);
+            l[0] = 0;
+            l[1] = 1 + j % (TY - 1);
+            l[2] = 1 + j / (TY - 1);
+        }
+    }
+}
+
 // One block per tile; threads walk the tile's low-face voxels and add what the lower
 // neighbours accumulated for them.  Gather form: each voxel has exactly one writer.
 template <typename T, int NO>
 __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<NO> tg,
                                                      const T* __restrict__ halo, int64_t b,
                                                      T* __restrict__ out) {
-    constexpr int NV = tile_voxels<NO>();
     const int tile = blockIdx.x;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     T* o = out + b * gd.G;
-    for (int i = threadIdx.x; i < NV; i += 256) {
-        int l[NO], rem = i;
+    for (int i = threadIdx.x; i < low_face_count<NO>(); i += 256) {
+        int l[NO];
+        low_face_coords<NO>(i, l);
         int off = 0, stride = 1;
         bool ok = true, low = false;
 #pragma unroll
         for (int d = 0; d < NO; ++d) {
-            l[d] = rem % TileDims<NO>::T[d];
-            rem /= TileDims<NO>::T[d];
             const int gcoord = x0[d] + l[d];
             ok = ok && gcoord < gd.n[d];
             low = low || (l[d] == 0 && tc[d] > 0);
@@ -376,7 +443,7 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
 }
 
 // ------------------------------------------------------------------ pullback K4
-template <typename T, int NI, int NO>
+template <typename T, int NI, int NO, bool HAS_PW>
 __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
     const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
@@ -392,6 +459,14 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const T* gb = g + b * gd.G;
+    const uint32_t r1 = tile_start[tile + 1];
+    uint32_t r = tile_start[tile] + threadIdx.x;
+    Rec4<T> nxt;
+    uint32_t nxt_idx = 0;
+    if (r < r1) {
+        nxt = rec[r];
+        if (HAS_PW) nxt_idx = rec_idx[r];
+    }
     // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground
     double bg_sum = 0.0;
     for (int i = threadIdx.x; i < NVH; i += kTileThreads) {
@@ -413,34 +488,31 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     }
     __syncthreads();
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
-    double vals[NVAL];
+    // per-thread sums of the per-pose scalars: T within the thread (few records each),
+    // f64 across threads / tiles
+    T vals[NVAL - 1];
 #pragma unroll
-    for (int k = 0; k < NVAL; ++k) vals[k] = 0.0;
-    vals[NVAL - 1] = bg_sum;
-    const uint32_t r0 = tile_start[tile], r1 = tile_start[tile + 1];
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += kTileThreads) {
+    for (int k = 0; k < NVAL - 1; ++k) vals[k] = T(0);
+    while (r < r1) {
+        const Rec4<T> rc = nxt;
+        const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
+        r += kTileThreads;
+        if (r < r1) {
+            nxt = rec[r];
+            if (HAS_PW) nxt_idx = rec_idx[r];
+        }
         T pt[NI];
-        const Rec4<T> rc = rec[r];
 #pragma unroll
         for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
-        const T pwi = rc.v[3];
-        const uint32_t p = rec_idx[r];
+        const T pwi = HAS_PW ? rc.v[3] : T(1);
         int ref0[NO];
         T dlo[NO];
         ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
-        // neighbour offsets are looked up in the LDS tile; nbr_offset() only decides validity
-        T scaled[NO], dow_part, dpw_part;
-        int lbase[NO];
-#pragma unroll
-        for (int d = 0; d < NO; ++d) lbase[d] = ref0[d] - x0[d];
-        // point_backward wants a fetch(off) on the global offset; remap through a closure that
-        // recomputes the local index from the neighbour id instead (cheaper): inline variant.
+        T scaled[NO], dow_part = T(0), dpw_part = T(0);
         {
             T dcoord[NO];
 #pragma unroll
             for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
-            dow_part = T(0);
-            dpw_part = T(0);
 #pragma unroll
             for (int s = 0; s < (1 << NO); ++s) {
                 int l[NO];
@@ -449,7 +521,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
                 for (int d = 0; d < NO; ++d) {
                     const int i = ref0[d] + ((s >> d) & 1);
                     ok = ok && (i >= 0) && (i < gd.n[d]);
-                    l[d] = lbase[d] + ((s >> d) & 1);
+                    l[d] = i - x0[d];
                 }
                 if (!ok) continue;  // src/raster_pullback.jl:51
                 const T gi = tile_g[lds_index<NO>(l)];
@@ -466,10 +538,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
 #pragma unroll
         for (int n = 0; n < NO; ++n) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) vals[n + j * NO] += (double)(scaled[n] * pt[j]);  // :69
-            vals[NO * NI + n] += (double)scaled[n];                                       // :68
+            for (int j = 0; j < NI; ++j) vals[n + j * NO] += scaled[n] * pt[j];  // :69
+            vals[NO * NI + n] += scaled[n];                                     // :68
         }
-        vals[NO * NI + NO] += (double)dow_part;
+        vals[NO * NI + NO] += dow_part;
         T dp[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {  // rotation' * scaled (:70)
@@ -493,7 +565,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < NVAL; ++k) {
-        const double s = wave_sum<double>(vals[k]);
+        const double v = (k < NVAL - 1) ? (double)vals[k < NVAL - 1 ? k : 0] : bg_sum;
+        const double s = wave_sum<double>(v);
         if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
@@ -501,46 +574,53 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
-        partials[(size_t)tile * 16 + threadIdx.x] = s;
+        partials[(size_t)threadIdx.x * tg.NT + tile] = s;
     }
 }
 
 // ------------------------------------------------------------------ pullback K5
-// partials[NT][16] (f64) -> the per-pose outputs of pose b.  Block = 16 x 64 threads.
+// partials[NVAL][NT] (f64) -> the per-pose outputs of pose b.  One block per scalar.
 template <typename T, int NI, int NO>
 __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__ partials, int NT,
                                                       int64_t b, T* __restrict__ ds_drotation,
                                                       T* __restrict__ ds_dtranslation,
                                                       T* __restrict__ ds_dbackground,
                                                       T* __restrict__ ds_dout_weight) {
-    constexpr int NVAL = NO * NI + NO + 2;
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double wsum[16];
+    const int k = blockIdx.x;
     double s = 0.0;
-    if (k < NVAL)
-        for (int t = lane; t < NT; t += 64) s += partials[(size_t)t * 16 + k];
+    for (int t = threadIdx.x; t < NT; t += 1024) s += partials[(size_t)k * NT + t];
     s = wave_sum<double>(s);
-    if (lane == 0 && k < NVAL) {
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
         if (k < NO * NI)
-            ds_drotation[b * (NO * NI) + k] = (T)s;
+            ds_drotation[b * (NO * NI) + k] = (T)tot;
         else if (k < NO * NI + NO)
-            ds_dtranslation[b * NO + (k - NO * NI)] = (T)s;
+            ds_dtranslation[b * NO + (k - NO * NI)] = (T)tot;
         else if (k == NO * NI + NO)
-            ds_dout_weight[b] = (T)s;
+            ds_dout_weight[b] = (T)tot;
         else
-            ds_dbackground[b] = (T)s;
+            ds_dbackground[b] = (T)tot;
     }
 }
 
 // ------------------------------------------------------------------ host side
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Workspace layout (identical for raster and pullback so that a pullback can reuse the
+// binning a raster call left behind, DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING):
+//   counts table | totals | tile_start | records | indices | aux (halo buffer / partials)
 struct Plan {
     int nblk;
     int64_t chunk;
     size_t off_counts, off_totals, off_tile_start, off_rec, off_idx, off_aux, total;
 };
 
-static Plan make_plan(size_t elem, int op, int n_in, int n_out, int NT, int64_t P) {
+static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     Plan pl;
     int64_t nblk = (P + 8191) / 8192;
     if (nblk < 1) nblk = 1;
@@ -560,14 +640,13 @@ static Plan make_plan(size_t elem, int op, int n_in, int n_out, int NT, int64_t 
     pl.off_tile_start = o;
     o += align_up((size_t)(NT + 1) * 4);
     pl.off_rec = o;
-    (void)n_in;
     o += align_up((size_t)P * 4 * elem);
     pl.off_idx = o;
-    if (op == DPR_OP_PULLBACK) o += align_up((size_t)P * 4);
+    o += align_up((size_t)P * 4);
     pl.off_aux = o;
-    const int halo = (n_out == 3) ? halo_count<3>() : halo_count<2>();
-    o += (op == DPR_OP_RASTER) ? align_up((size_t)NT * halo * elem)   // halo buffer
-                               : align_up((size_t)NT * 16 * 8);      // per-tile partials
+    const size_t halo = (size_t)NT * ((n_out == 3) ? halo_count<3>() : halo_count<2>()) * elem;
+    const size_t partials = (size_t)NT * 16 * 8;
+    o += align_up(halo > partials ? halo : partials);
     pl.total = o;
     return pl;
 }
@@ -594,6 +673,8 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
 size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
                              int64_t P, int64_t B) {
     (void)B;
+    (void)op;
+    (void)n_in;
     int NT;
     if (n_out == 3) {
         TileGeom<3> tg;
@@ -604,7 +685,7 @@ size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int
         if (!make_geom<2>(grid, &tg)) return (size_t)-1;
         NT = tg.NT;
     }
-    return make_plan(elem, op, n_in, n_out, NT, P).total;
+    return make_plan(elem, n_out, NT, P).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -621,16 +702,30 @@ template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
     return DPR_OK;
 }
 
+template <typename T, int NI, int NO, bool HAS_PW, bool WANT_IDX>
+static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
+                          const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
+                          const T* rot, const T* trans, int64_t b, T* d_pts, T* d_pw,
+                          int zero_dropped) {
+    const size_t lds = (size_t)tg.NT * 4;
+    if (int rc = allow_big_lds(k_scatter<T, NI, NO, HAS_PW, WANT_IDX>, lds)) return rc;
+    hipLaunchKernelGGL((k_scatter<T, NI, NO, HAS_PW, WANT_IDX>), dim3(pl.nblk), dim3(kBinThreads),
+                       lds, st, gd, tg, P, pl.chunk, points, pw, rot, trans, b,
+                       (const uint32_t*)(ws + pl.off_counts),
+                       (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),
+                       (uint32_t*)(ws + pl.off_idx), d_pts, d_pw, zero_dropped);
+    return DPR_OK;
+}
+
+// K1-K3 for pose b.  want_idx: a pullback will consume the binning.
 template <typename T, int NI, int NO>
 static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                       const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
-                      const T* rot, const T* trans, int64_t b, bool pullback, T* d_pts, T* d_pw,
+                      const T* rot, const T* trans, int64_t b, bool want_idx, T* d_pts, T* d_pw,
                       int zero_dropped) {
     uint32_t* counts = (uint32_t*)(ws + pl.off_counts);
     uint32_t* totals = (uint32_t*)(ws + pl.off_totals);
     uint32_t* tile_start = (uint32_t*)(ws + pl.off_tile_start);
-    Rec4<T>* rec = (Rec4<T>*)(ws + pl.off_rec);
-    uint32_t* rec_idx = (uint32_t*)(ws + pl.off_idx);
     const size_t lds = (size_t)tg.NT * 4;
     if (int rc = allow_big_lds(k_count<T, NI, NO>, lds)) return rc;
     hipLaunchKernelGGL((k_count<T, NI, NO>), dim3(pl.nblk), dim3(kBinThreads), lds, st, gd, tg, P,
@@ -640,19 +735,20 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
                        tg.NT, totals);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, tile_start);
     stage_mark(st);
-    if (pullback) {
-        if (int rc = allow_big_lds(k_scatter<T, NI, NO, true>, lds)) return rc;
-        hipLaunchKernelGGL((k_scatter<T, NI, NO, true>), dim3(pl.nblk), dim3(kBinThreads), lds, st,
-                           gd, tg, P, pl.chunk, points, pw, rot, trans, b, counts, tile_start, rec,
-                           rec_idx, d_pts, d_pw, zero_dropped);
+    int rc;
+    if (pw) {
+        rc = want_idx ? launch_scatter<T, NI, NO, true, true>(st, gd, tg, pl, ws, P, points, pw,
+                                                              rot, trans, b, d_pts, d_pw,
+                                                              zero_dropped)
+                      : launch_scatter<T, NI, NO, true, false>(st, gd, tg, pl, ws, P, points, pw,
+                                                               rot, trans, b, d_pts, d_pw,
+                                                               zero_dropped);
     } else {
-        if (int rc = allow_big_lds(k_scatter<T, NI, NO, false>, lds)) return rc;
-        hipLaunchKernelGGL((k_scatter<T, NI, NO, false>), dim3(pl.nblk), dim3(kBinThreads), lds,
-                           st, gd, tg, P, pl.chunk, points, pw, rot, trans, b, counts, tile_start,
-                           rec, rec_idx, (T*)nullptr, (T*)nullptr, 0);
+        rc = launch_scatter<T, NI, NO, false, true>(st, gd, tg, pl, ws, P, points, pw, rot, trans,
+                                                    b, d_pts, d_pw, zero_dropped);
     }
     stage_mark(st);
-    return DPR_OK;
+    return rc;
 }
 
 template <int NO> static GridDesc<NO> make_grid_desc(const int64_t* grid, int64_t G) {
@@ -663,16 +759,20 @@ template <int NO> static GridDesc<NO> make_grid_desc(const int64_t* grid, int64_
 }
 
 template <typename T, int NI, int NO>
-int raster_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B, T* out,
-                 const T* points, const T* rot, const T* trans, const T* bg, const T* ow,
-                 const T* pw, void* ws_, size_t ws_bytes) {
+int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                 int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                 const T* ow, const T* pw, void* ws_, size_t ws_bytes) {
     TileGeom<NO> tg;
     if (!make_geom<NO>(grid, &tg))
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
                     kMaxTiles);
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
-    const Plan pl = make_plan(sizeof(T), DPR_OP_RASTER, NI, NO, tg.NT, P);
+    const bool keep = flags & DPR_FLAG_KEEP_BINNING;
+    if (keep && B != 1)
+        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
+                    (long long)B);
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
@@ -680,13 +780,19 @@ int raster_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int6
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     T* halo = (T*)(ws + pl.off_aux);
     for (int64_t b = 0; b < B; ++b) {
-        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, false,
+        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, keep,
                                            (T*)nullptr, (T*)nullptr, 0))
             return rc;
-        hipLaunchKernelGGL((k_tile_splat<T, NI, NO>), dim3(tg.NT), dim3(kTileThreads), 0, st, gd,
-                           tg, (const Rec4<T>*)(ws + pl.off_rec),
-                           (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b, out,
-                           halo);
+        if (pw)
+            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, true>), dim3(tg.NT), dim3(kTileThreads), 0,
+                               st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
+                               (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b,
+                               out, halo);
+        else
+            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, false>), dim3(tg.NT), dim3(kTileThreads),
+                               0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
+                               (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b,
+                               out, halo);
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>), dim3(tg.NT), dim3(256), 0, st, gd, tg,
                            (const T*)halo, b, out);
@@ -697,17 +803,21 @@ int raster_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int6
 }
 
 template <typename T, int NI, int NO>
-int pullback_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B,
-                   const T* g, const T* points, const T* rot, const T* trans, const T* ow,
-                   const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw,
-                   void* ws_, size_t ws_bytes) {
+int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                   int64_t B, const T* g, const T* points, const T* rot, const T* trans,
+                   const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                   T* d_pw, void* ws_, size_t ws_bytes) {
     TileGeom<NO> tg;
     if (!make_geom<NO>(grid, &tg))
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
                     kMaxTiles);
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
-    const Plan pl = make_plan(sizeof(T), DPR_OP_PULLBACK, NI, NO, tg.NT, P);
+    const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
+    if (reuse && B != 1)
+        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
+                    (long long)B);
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -715,16 +825,35 @@ int pullback_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, in
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     double* partials = (double*)(ws + pl.off_aux);
+    constexpr int NVAL = NO * NI + NO + 2;
     for (int64_t b = 0; b < B; ++b) {
-        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, true,
-                                           d_pts, d_pw, b == 0))
+        if (reuse) {
+            // The binning of the preceding raster call (same points / pose / grid) is in the
+            // workspace.  Points without an in-range voxel are not in any tile: clear first.
+            if (P > 0) {
+                DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * NI), st));
+                DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
+            }
+            stage_mark(st);
+            stage_mark(st);
+            stage_mark(st);
+        } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
+                                                  true, d_pts, d_pw, b == 0))
             return rc;
-        hipLaunchKernelGGL((k_tile_gather<T, NI, NO>), dim3(tg.NT), dim3(kTileThreads), 0, st, gd,
-                           tg, (const Rec4<T>*)(ws + pl.off_rec), (const uint32_t*)(ws + pl.off_idx),
-                           (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b, d_pts,
-                           d_pw, partials, b == 0);
+        if (pw)
+            hipLaunchKernelGGL((k_tile_gather<T, NI, NO, true>), dim3(tg.NT), dim3(kTileThreads),
+                               0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
+                               (const uint32_t*)(ws + pl.off_idx),
+                               (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b,
+                               d_pts, d_pw, partials, b == 0);
+        else
+            hipLaunchKernelGGL((k_tile_gather<T, NI, NO, false>), dim3(tg.NT), dim3(kTileThreads),
+                               0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
+                               (const uint32_t*)(ws + pl.off_idx),
+                               (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b,
+                               d_pts, d_pw, partials, b == 0);
         stage_mark(st);
-        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(1), dim3(1024), 0, st,
+        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(NVAL), dim3(1024), 0, st,
                            (const double*)partials, tg.NT, b, d_rot, d_trans, d_bg, d_ow);
         stage_mark(st);
     }
@@ -732,14 +861,14 @@ int pullback_tiled(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, in
     return DPR_OK;
 }
 
-#define DPR_INST(T, NI, NO)                                                                      \
-    template int raster_tiled<T, NI, NO>(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, \
-                                         T*, const T*, const T*, const T*, const T*, const T*,   \
-                                         const T*, void*, size_t);                               \
-    template int pullback_tiled<T, NI, NO>(hipStream_t, const int64_t*, int64_t, int64_t,        \
-                                           int64_t, const T*, const T*, const T*, const T*,      \
-                                           const T*, const T*, T*, T*, T*, T*, T*, T*, void*,    \
-                                           size_t);
+#define DPR_INST(T, NI, NO)                                                                       \
+    template int raster_tiled<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, \
+                                         int64_t, T*, const T*, const T*, const T*, const T*,     \
+                                         const T*, const T*, void*, size_t);                      \
+    template int pullback_tiled<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t,        \
+                                           int64_t, int64_t, const T*, const T*, const T*,        \
+                                           const T*, const T*, const T*, T*, T*, T*, T*, T*, T*,  \
+                                           void*, size_t);
 DPR_INST(float, 2, 2)
 DPR_INST(float, 3, 3)
 DPR_INST(float, 3, 2)

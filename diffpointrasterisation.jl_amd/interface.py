@@ -229,9 +229,12 @@ def raster(grid_size, points, rotation, translation, background=None, out_weight
 
 
 def raster_(out, points, rotation, translation, background=None, out_weight=None,
-            point_weight=None, *, algo: str = "auto", workspace=None) -> torch.Tensor:
+            point_weight=None, *, algo: str = "auto", workspace=None,
+            keep_binning: bool = False) -> torch.Tensor:
     """In-place forward, the reference's `raster!`.  `out` is fully overwritten and
-    returned (same object).  Enqueued on torch's current stream; not synchronised."""
+    returned (same object).  Enqueued on torch's current stream; not synchronised.
+    `keep_binning=True` (tiled algorithm, one pose, explicit `workspace`) leaves the binning
+    in `workspace` for `raster_pullback_(..., reuse_binning=True)` with the same arguments."""
     import numpy as np
 
     c = _canonicalise(points, rotation, translation, background, out_weight, point_weight)
@@ -255,7 +258,10 @@ def raster_(out, points, rotation, translation, background=None, out_weight=None
         ws, ws_bytes = _workspace(_lib.OP_RASTER, algo_c, suf, c["n_in"], c["n_out"], grid_arr,
                                   c["P"], c["B"], c["device"], workspace)
         fn = getattr(_lib.lib(), f"dpr_raster_ex_{suf}")
-        _lib.check(fn(_stream_ptr(c["device"]), algo_c, c["n_in"], c["n_out"],
+        flags = _lib.FLAG_KEEP_BINNING if keep_binning else 0
+        if keep_binning and workspace is None:
+            raise ValueError("keep_binning needs a caller-owned workspace")
+        _lib.check(fn(_stream_ptr(c["device"]), algo_c, flags, c["n_in"], c["n_out"],
                       grid_arr.ctypes.data_as(ctypes.c_void_p), c["P"], c["B"], _ptr(out),
                       _ptr(c["points"]), _ptr(c["rot"]), _ptr(c["trans"]), _ptr(c["bg"]),
                       _ptr(c["ow"]), _ptr(c["pw"]), _ptr(ws), ws_bytes))
@@ -266,7 +272,8 @@ def raster_(out, points, rotation, translation, background=None, out_weight=None
 def raster_pullback_(ds_dout, points, rotation, translation, background=None, out_weight=None,
                      point_weight=None, *, ds_dpoints=None, ds_drotation=None,
                      ds_dtranslation=None, ds_dbackground=None, ds_dout_weight=None,
-                     ds_dpoint_weight=None, algo: str = "auto", workspace=None) -> PullbackResult:
+                     ds_dpoint_weight=None, algo: str = "auto", workspace=None,
+                     reuse_binning: bool = False) -> PullbackResult:
     """The reference's `raster_pullback!` (src/interface.jl:196-308).  Optional keyword
     arguments are pre-allocated outputs (the reference's `points=`, `rotation=`, ... kwargs,
     src/interface.jl:278-291); they are OVERWRITTEN and returned by identity.  Unlike the
@@ -328,7 +335,10 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
         ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
                                   workspace)
         fn = getattr(_lib.lib(), f"dpr_raster_pullback_ex_{suf}")
-        _lib.check(fn(_stream_ptr(dev), algo_c, n_in, n_out,
+        flags = _lib.FLAG_REUSE_BINNING if reuse_binning else 0
+        if reuse_binning and workspace is None:
+            raise ValueError("reuse_binning needs the workspace of the preceding raster_ call")
+        _lib.check(fn(_stream_ptr(dev), algo_c, flags, n_in, n_out,
                       grid_arr.ctypes.data_as(ctypes.c_void_p), P, B, _ptr(g), _ptr(c["points"]),
                       _ptr(c["rot"]), _ptr(c["trans"]), _ptr(c["ow"]), _ptr(c["pw"]),
                       _ptr(d_pts), _ptr(d_rot), _ptr(d_trans), _ptr(d_bg), _ptr(d_ow),

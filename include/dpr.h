@@ -71,6 +71,18 @@ extern "C" {
 #define DPR_ALGO_TILED 2  /* per-pose binning of points into voxel tiles, LDS-resident
                              tile accumulation, plain-store flush (no global atomics) */
 
+/* flags (the *_ex entry points), DPR_ALGO_TILED with B == 1 only:
+ * KEEP_BINNING  (raster)   leave the per-tile binning of the points (incl. original
+ *                          indices) in the workspace for the pullback of the same call pair
+ * REUSE_BINNING (pullback) the workspace still holds the binning written by the preceding
+ *                          raster call with the SAME points, pose, grid and point_weight
+ *                          pointer-ness; skips the count/scan/scatter stages.
+ * This is the cache an rrule keeps between `raster` and its pullback closure
+ * (ext/DiffPointRasterisationChainRulesCoreExt.jl:6-27); the reference itself recomputes
+ * (src/raster_pullback.jl:20-22). */
+#define DPR_FLAG_KEEP_BINNING 1u
+#define DPR_FLAG_REUSE_BINNING 2u
+
 int dpr_version(void);
 
 /* Thread-local message of the last failing call on this host thread ("" if none). */
@@ -108,11 +120,11 @@ int dpr_raster_f64(void *stream, int n_in, int n_out, const int64_t *grid, int64
                    double *out, const double *points, const double *rotation,
                    const double *translation, const double *background, const double *out_weight,
                    const double *point_weight, void *workspace, size_t workspace_bytes);
-int dpr_raster_ex_f32(void *stream, int algo, int n_in, int n_out, const int64_t *grid, int64_t P,
+int dpr_raster_ex_f32(void *stream, int algo, unsigned flags, int n_in, int n_out, const int64_t *grid, int64_t P,
                       int64_t B, float *out, const float *points, const float *rotation,
                       const float *translation, const float *background, const float *out_weight,
                       const float *point_weight, void *workspace, size_t workspace_bytes);
-int dpr_raster_ex_f64(void *stream, int algo, int n_in, int n_out, const int64_t *grid, int64_t P,
+int dpr_raster_ex_f64(void *stream, int algo, unsigned flags, int n_in, int n_out, const int64_t *grid, int64_t P,
                       int64_t B, double *out, const double *points, const double *rotation,
                       const double *translation, const double *background,
                       const double *out_weight, const double *point_weight, void *workspace,
@@ -134,14 +146,14 @@ int dpr_raster_pullback_f64(void *stream, int n_in, int n_out, const int64_t *gr
                             double *ds_dpoints, double *ds_drotation, double *ds_dtranslation,
                             double *ds_dbackground, double *ds_dout_weight,
                             double *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
-int dpr_raster_pullback_ex_f32(void *stream, int algo, int n_in, int n_out, const int64_t *grid,
+int dpr_raster_pullback_ex_f32(void *stream, int algo, unsigned flags, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B, const float *ds_dout, const float *points,
                                const float *rotation, const float *translation,
                                const float *out_weight, const float *point_weight,
                                float *ds_dpoints, float *ds_drotation, float *ds_dtranslation,
                                float *ds_dbackground, float *ds_dout_weight,
                                float *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
-int dpr_raster_pullback_ex_f64(void *stream, int algo, int n_in, int n_out, const int64_t *grid,
+int dpr_raster_pullback_ex_f64(void *stream, int algo, unsigned flags, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B, const double *ds_dout, const double *points,
                                const double *rotation, const double *translation,
                                const double *out_weight, const double *point_weight,

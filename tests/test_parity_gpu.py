@@ -252,6 +252,33 @@ def test_pullback_matches_central_differences_on_device(dev, algo, n_in, n_out):
         np.testing.assert_allclose(grad.cpu().numpy(), fd, rtol=1e-5, atol=1e-6, err_msg=name)
 
 
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out", SHAPES)
+@pytest.mark.parametrize("with_pw", [False, True])
+def test_pullback_reusing_forward_binning(oracle, dev, npdt, tdt, n_in, n_out, with_pw):
+    """DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING: the pullback consumes the tile binning
+    the forward call left in the workspace (the rrule pairing, ChainRulesCoreExt.jl:6-27).
+    Some points lie outside the grid: their gradients must come back as zeros."""
+    d = D.make(n_points=30_000, n_in=n_in, n_out=n_out, batch=1, grid_n=40, seed=21, dtype=npdt)
+    d.points[::7] *= 4.0  # a good fraction far outside (-1, 1)
+    pw = d.point_weights if with_pw else None
+    ws = torch.empty(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 1, n_in, tdt, "tiled"),
+                     dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, 1, tdt, dev)
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(pw, dev))
+    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=True)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), *args, algo="tiled", workspace=ws,
+                                  reuse_binning=True)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds,
+                            d.weights, pw, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                    pw, dtype=npdt)
+    _compare(ref_out, ref_pb, out, pb, npdt)
+    with pytest.raises(dpr_amd.DprError):  # flags are a tiled-path, single-pose feature
+        dpr_amd.raster_(out, *args, algo="atomic", workspace=ws, keep_binning=True)
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
