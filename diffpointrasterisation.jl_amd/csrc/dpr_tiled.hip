@@ -245,11 +245,16 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
     const int64_t lo = (int64_t)blockIdx.x * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
+    // Fixed memory-op pattern per iteration (one clamped prefetch, one record store, the
+    // latter to the spare slot P when the point has no in-range voxel) so that the wait for
+    // the prefetched point is a counted vmcnt that never covers the scattered store.
+    if (lo >= hi) return;
     int64_t p = lo + threadIdx.x;
     T nxt[NI], nxt_w = T(1);
-    if (p < hi) {
-        load_point<T, NI>(points, p, nxt);
-        if (HAS_PW) nxt_w = pw[p];
+    {
+        const int64_t pl = p < hi ? p : hi - 1;
+        load_point<T, NI>(points, pl, nxt);
+        if (HAS_PW) nxt_w = pw[pl];
     }
     while (p < hi) {
         T pt[NI];
@@ -258,21 +263,23 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
         const T w = nxt_w;
         const int64_t pc = p;
         p += kBinThreads;
-        if (p < hi) {
-            load_point<T, NI>(points, p, nxt);
-            if (HAS_PW) nxt_w = pw[p];
+        {
+            const int64_t pl = p < hi ? p : hi - 1;
+            load_point<T, NI>(points, pl, nxt);
+            if (HAS_PW) nxt_w = pw[pl];
         }
         int ref0[NO];
         T dlo[NO];
-        if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
-            const uint32_t pos = atomicAdd(&cursor[primary_tile<NO>(ref0, tg)], 1u);
-            Rec4<T> r;
+        const bool valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        uint32_t pos = (uint32_t)P;  // spare slot
+        if (valid) pos = atomicAdd(&cursor[primary_tile<NO>(ref0, tg)], 1u);
+        Rec4<T> r;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[(j < NI) ? j : 0] : T(0);
-            r.v[3] = HAS_PW ? w : idx_to_slot((uint32_t)pc, T(0));
-            rec[pos] = r;
-            if (HAS_PW && WANT_IDX) rec_idx[pos] = (uint32_t)pc;
-        } else if (zero_dropped) {
+        for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[(j < NI) ? j : 0] : T(0);
+        r.v[3] = HAS_PW ? w : idx_to_slot((uint32_t)pc, T(0));
+        rec[pos] = r;
+        if (HAS_PW && WANT_IDX) rec_idx[pos] = (uint32_t)pc;
+        if (zero_dropped && !valid) {
             // no in-range voxel: empty gradient (written once, by the first pose)
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[pc * NI + j] = T(0);
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     while (r < r1) {
         const Rec4<T> rc = nxt;
         r += kTileThreads;
-        if (r < r1) nxt = rec[r];
+        nxt = rec[r < r1 ? r : r1 - 1];  // clamped prefetch (branch-free loop body)
         T pt[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
@@ -312,17 +319,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
         int ref0[NO];
         T dlo[NO];
         ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
+        // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
+        // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
+        // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
+        int lb[NO];
+        bool low_ok[NO];
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            lb[d] = ref0[d] - x0[d];
+            low_ok[d] = lb[d] >= 0;
+        }
 #pragma unroll
         for (int s = 0; s < (1 << NO); ++s) {
             int l[NO];
             bool ok = true;
 #pragma unroll
             for (int d = 0; d < NO; ++d) {
-                const int i = ref0[d] + ((s >> d) & 1);
-                ok = ok && (i >= 0) && (i < gd.n[d]);  // individual drop, src/raster.jl:62
-                l[d] = i - x0[d];
+                const int sd = (s >> d) & 1;
+                ok = ok && (sd || low_ok[d]);
+                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
             }
-            if (ok) atomicAdd(&acc[lds_index<NO>(l)], (double)voxel_weight<T, NO>(dlo, s, w));
+            const T v = voxel_weight<T, NO>(dlo, s, w);
+            atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
         }
     }
     __syncthreads();
@@ -443,13 +461,13 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
 }
 
 // ------------------------------------------------------------------ pullback K4
-template <typename T, int NI, int NO, bool HAS_PW>
+template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE>
 __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
     const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
     const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
     const T* __restrict__ ow, int64_t b, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
-    double* __restrict__ partials, int first_pose) {
+    double* __restrict__ partials) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NVAL = NO * NI + NO + 2;  // dR | dt | d out_weight | d background
     constexpr int NW = kTileThreads / kWave;
@@ -497,9 +515,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
         r += kTileThreads;
-        if (r < r1) {
-            nxt = rec[r];
-            if (HAS_PW) nxt_idx = rec_idx[r];
+        {
+            const uint32_t rl = r < r1 ? r : r1 - 1;  // clamped prefetch
+            nxt = rec[rl];
+            if (HAS_PW) nxt_idx = rec_idx[rl];
         }
         T pt[NI];
 #pragma unroll
@@ -508,6 +527,30 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
         int ref0[NO];
         T dlo[NO];
         ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        // Branch-free neighbour loop: cells beyond the grid were staged as 0 (they add
+        // nothing, which equals dropping them, src/raster_pullback.jl:51); a lower neighbour
+        // at -1 reads cell 0 and is zeroed.
+        int lb[NO];
+        bool low_ok[NO];
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            lb[d] = ref0[d] - x0[d];
+            low_ok[d] = lb[d] >= 0;
+        }
+        T gv[1 << NO];
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) {
+            int l[NO];
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int sd = (s >> d) & 1;
+                ok = ok && (sd || low_ok[d]);
+                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+            }
+            const T gi = tile_g[lds_index<NO>(l)];
+            gv[s] = ok ? gi : T(0);
+        }
         T scaled[NO], dow_part = T(0), dpw_part = T(0);
         {
             T dcoord[NO];
@@ -515,16 +558,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
             for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
 #pragma unroll
             for (int s = 0; s < (1 << NO); ++s) {
-                int l[NO];
-                bool ok = true;
-#pragma unroll
-                for (int d = 0; d < NO; ++d) {
-                    const int i = ref0[d] + ((s >> d) & 1);
-                    ok = ok && (i >= 0) && (i < gd.n[d]);
-                    l[d] = i - x0[d];
-                }
-                if (!ok) continue;  // src/raster_pullback.jl:51
-                const T gi = tile_g[lds_index<NO>(l)];
+                const T gi = gv[s];
                 const T dweight = voxel_weight<T, NO>(dlo, s, gi);  // :55
                 dow_part += dweight * pwi;                          // :57
                 dpw_part += dweight * ps.ow;                        // :58
@@ -551,7 +585,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
             dp[j] = v;
         }
         // this thread is the only writer of point p for this pose
-        if (first_pose) {
+        if (FIRST_POSE) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] = dp[j];
             ds_dpw[p] = dpw_part;
@@ -640,9 +674,9 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     pl.off_tile_start = o;
     o += align_up((size_t)(NT + 1) * 4);
     pl.off_rec = o;
-    o += align_up((size_t)P * 4 * elem);
+    o += align_up((size_t)(P + 1) * 4 * elem);  // + spare slot for rejected points
     pl.off_idx = o;
-    o += align_up((size_t)P * 4);
+    o += align_up((size_t)(P + 1) * 4);
     pl.off_aux = o;
     const size_t halo = (size_t)NT * ((n_out == 3) ? halo_count<3>() : halo_count<2>()) * elem;
     const size_t partials = (size_t)NT * 16 * 8;
@@ -840,18 +874,20 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
                                                   true, d_pts, d_pw, b == 0))
             return rc;
-        if (pw)
-            hipLaunchKernelGGL((k_tile_gather<T, NI, NO, true>), dim3(tg.NT), dim3(kTileThreads),
-                               0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
-                               (const uint32_t*)(ws + pl.off_idx),
-                               (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b,
-                               d_pts, d_pw, partials, b == 0);
-        else
-            hipLaunchKernelGGL((k_tile_gather<T, NI, NO, false>), dim3(tg.NT), dim3(kTileThreads),
-                               0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
-                               (const uint32_t*)(ws + pl.off_idx),
-                               (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b,
-                               d_pts, d_pw, partials, b == 0);
+#define DPR_LAUNCH_GATHER(HAS_PW, FIRST)                                                        \
+    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST>), dim3(tg.NT),                  \
+                       dim3(kTileThreads), 0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),    \
+                       (const uint32_t*)(ws + pl.off_idx),                                      \
+                       (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b, d_pts,  \
+                       d_pw, partials)
+        if (pw) {
+            if (b == 0) DPR_LAUNCH_GATHER(true, true);
+            else DPR_LAUNCH_GATHER(true, false);
+        } else {
+            if (b == 0) DPR_LAUNCH_GATHER(false, true);
+            else DPR_LAUNCH_GATHER(false, false);
+        }
+#undef DPR_LAUNCH_GATHER
         stage_mark(st);
         hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(NVAL), dim3(1024), 0, st,
                            (const double*)partials, tg.NT, b, d_rot, d_trans, d_bg, d_ow);
