@@ -25,6 +25,8 @@
 // independent of the accumulation order.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/dpr.h"
 #include "dpr_device.h"
 #include "dpr_tiled.h"
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
     const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
-    Rec4<T>* __restrict__ rec, uint32_t* __restrict__ rec_idx, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, int zero_dropped) {
+    Rec4<T>* __restrict__ rec, uint32_t* __restrict__ rec_idx, uint32_t* __restrict__ slot_of,
+    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, int zero_dropped) {
     extern __shared__ uint32_t cursor[];
     const uint32_t* row = prefix + (size_t)blockIdx.x * tg.NT;
     for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) cursor[i] = tile_start[i] + row[i];
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
         r.v[3] = HAS_PW ? w : idx_to_slot((uint32_t)pc, T(0));
         rec[pos] = r;
         if (HAS_PW && WANT_IDX) rec_idx[pos] = (uint32_t)pc;
+        if (WANT_IDX) slot_of[pc] = pos;  // coalesced; rejected points map to the spare slot
         if (zero_dropped && !valid) {
             // no in-range voxel: empty gradient (written once, by the first pose)
 #pragma unroll
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
     const uint32_t* __restrict__ tile_start, const T* __restrict__ rot,
     const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b,
-    T* __restrict__ out, T* __restrict__ halo) {
+    T* __restrict__ out, T* __restrict__ halo, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NV = tile_voxels<NO>();
     __shared__ double acc[NVH];
@@ -303,14 +306,26 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
-    const uint32_t r1 = tile_start[tile + 1];
-    uint32_t r = tile_start[tile] + threadIdx.x;
+    // Record assignment: strided (lane-adjacent records, coalesced) or blocked (each thread
+    // owns a contiguous run, so lanes are far apart in the list: with spatially sorted input
+    // lane-adjacent records hit the same voxel and same-address LDS atomics serialise).
+    uint32_t r1 = tile_start[tile + 1];
+    uint32_t r = tile_start[tile];
+    uint32_t step = kTileThreads;
+    if (blocked) {
+        const uint32_t per = (r1 - r + kTileThreads - 1) / kTileThreads;
+        r += threadIdx.x * per;
+        r1 = (r + per < r1) ? r + per : r1;
+        step = 1;
+    } else {
+        r += threadIdx.x;
+    }
     Rec4<T> nxt;
     if (r < r1) nxt = rec[r];
     __syncthreads();
     while (r < r1) {
         const Rec4<T> rc = nxt;
-        r += kTileThreads;
+        r += step;
         nxt = rec[r < r1 ? r : r1 - 1];  // clamped prefetch (branch-free loop body)
         T pt[NI];
 #pragma unroll
@@ -461,9 +476,13 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
 }
 
 // ------------------------------------------------------------------ pullback K4
-template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE>
+// UNPERM: the per-point gradient {d point, d point_weight} overwrites the point's record in
+// place (coalesced 16/32-byte stores in binned order); k_unpermute then brings it back to the
+// original order with one random read per point.  !UNPERM: the owner thread stores straight
+// to ds_dpoints[idx] / ds_dpoint_weight[idx] (good when the input order is spatially coherent).
+template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM>
 __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
-    GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
+    GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, int64_t P,
     const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
     const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
     const T* __restrict__ ow, int64_t b, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
@@ -483,7 +502,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     uint32_t nxt_idx = 0;
     if (r < r1) {
         nxt = rec[r];
-        if (HAS_PW) nxt_idx = rec_idx[r];
+        if (HAS_PW && !UNPERM) nxt_idx = rec_idx[r];
+    }
+    if (UNPERM && blockIdx.x == 0 && threadIdx.x == 0) {
+        Rec4<T> z;
+        z.v[0] = z.v[1] = z.v[2] = z.v[3] = T(0);
+        rec[P] = z;  // spare slot: the gradient of every rejected point
     }
     // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground
     double bg_sum = 0.0;
@@ -514,11 +538,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     while (r < r1) {
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
+        const uint32_t rcur = r;
         r += kTileThreads;
         {
             const uint32_t rl = r < r1 ? r : r1 - 1;  // clamped prefetch
             nxt = rec[rl];
-            if (HAS_PW) nxt_idx = rec_idx[rl];
+            if (HAS_PW && !UNPERM) nxt_idx = rec_idx[rl];
         }
         T pt[NI];
 #pragma unroll
@@ -584,8 +609,13 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
             for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
             dp[j] = v;
         }
-        // this thread is the only writer of point p for this pose
-        if (FIRST_POSE) {
+        if (UNPERM) {
+            Rec4<T> gr;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gr.v[j] = (j < NI) ? dp[(j < NI) ? j : 0] : T(0);
+            gr.v[3] = dpw_part;
+            rec[rcur] = gr;
+        } else if (FIRST_POSE) {  // this thread is the only writer of point p for this pose
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] = dp[j];
             ds_dpw[p] = dpw_part;
@@ -609,6 +639,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
         partials[(size_t)threadIdx.x * tg.NT + tile] = s;
+    }
+}
+
+// ------------------------------------------------------------------ pullback un-permute
+// thread per ORIGINAL point: gradient record of its slot -> ds_dpoints / ds_dpoint_weight
+// (coalesced stores; accumulating over poses when !FIRST_POSE).
+template <typename T, int NI, bool FIRST_POSE>
+__global__ __launch_bounds__(256) void k_unpermute(int64_t P, const Rec4<T>* __restrict__ grad,
+                                                   const uint32_t* __restrict__ slot_of,
+                                                   T* __restrict__ ds_dpoints,
+                                                   T* __restrict__ ds_dpw) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const Rec4<T> g = grad[slot_of[p]];
+    if (FIRST_POSE) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = g.v[j];
+        ds_dpw[p] = g.v[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] += g.v[j];
+        ds_dpw[p] += g.v[3];
     }
 }
 
@@ -645,13 +697,19 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
 // ------------------------------------------------------------------ host side
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// experiment knobs (environment overrides of compiled-in defaults)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 // Workspace layout (identical for raster and pullback so that a pullback can reuse the
 // binning a raster call left behind, DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING):
-//   counts table | totals | tile_start | records | indices | aux (halo buffer / partials)
+//   counts table | totals | tile_start | records | indices | slot_of | aux (halo / partials)
 struct Plan {
     int nblk;
     int64_t chunk;
-    size_t off_counts, off_totals, off_tile_start, off_rec, off_idx, off_aux, total;
+    size_t off_counts, off_totals, off_tile_start, off_rec, off_idx, off_slot, off_aux, total;
 };
 
 static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
@@ -676,6 +734,8 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     pl.off_rec = o;
     o += align_up((size_t)(P + 1) * 4 * elem);  // + spare slot for rejected points
     pl.off_idx = o;
+    o += align_up((size_t)(P + 1) * 4);
+    pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
     pl.off_aux = o;
     const size_t halo = (size_t)NT * ((n_out == 3) ? halo_count<3>() : halo_count<2>()) * elem;
@@ -747,7 +807,8 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
                        lds, st, gd, tg, P, pl.chunk, points, pw, rot, trans, b,
                        (const uint32_t*)(ws + pl.off_counts),
                        (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),
-                       (uint32_t*)(ws + pl.off_idx), d_pts, d_pw, zero_dropped);
+                       (uint32_t*)(ws + pl.off_idx), (uint32_t*)(ws + pl.off_slot), d_pts, d_pw,
+                       zero_dropped);
     return DPR_OK;
 }
 
@@ -813,6 +874,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     T* halo = (T*)(ws + pl.off_aux);
+    const int blocked = env_int("DPR_SPLAT_BLOCKED", 1);
     for (int64_t b = 0; b < B; ++b) {
         if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, keep,
                                            (T*)nullptr, (T*)nullptr, 0))
@@ -821,12 +883,12 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
             hipLaunchKernelGGL((k_tile_splat<T, NI, NO, true>), dim3(tg.NT), dim3(kTileThreads), 0,
                                st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
                                (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b,
-                               out, halo);
+                               out, halo, blocked);
         else
             hipLaunchKernelGGL((k_tile_splat<T, NI, NO, false>), dim3(tg.NT), dim3(kTileThreads),
                                0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
                                (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b,
-                               out, halo);
+                               out, halo, blocked);
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>), dim3(tg.NT), dim3(256), 0, st, gd, tg,
                            (const T*)halo, b, out);
@@ -860,11 +922,13 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     double* partials = (double*)(ws + pl.off_aux);
     constexpr int NVAL = NO * NI + NO + 2;
+    const bool unperm = env_int("DPR_BWD_UNPERMUTE", 1) != 0;
     for (int64_t b = 0; b < B; ++b) {
         if (reuse) {
             // The binning of the preceding raster call (same points / pose / grid) is in the
-            // workspace.  Points without an in-range voxel are not in any tile: clear first.
-            if (P > 0) {
+            // workspace.  Direct-store mode: points without an in-range voxel are in no tile,
+            // clear the outputs first (the un-permute mode reads zeros from the spare slot).
+            if (P > 0 && !unperm) {
                 DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * NI), st));
                 DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
             }
@@ -872,20 +936,38 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             stage_mark(st);
             stage_mark(st);
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
-                                                  true, d_pts, d_pw, b == 0))
+                                                  true, d_pts, d_pw, (b == 0 && !unperm) ? 1 : 0))
             return rc;
-#define DPR_LAUNCH_GATHER(HAS_PW, FIRST)                                                        \
-    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST>), dim3(tg.NT),                  \
-                       dim3(kTileThreads), 0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),    \
+#define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                                                   \
+    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(tg.NT),             \
+                       dim3(kTileThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,       \
                        (const uint32_t*)(ws + pl.off_idx),                                      \
                        (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b, d_pts,  \
                        d_pw, partials)
-        if (pw) {
-            if (b == 0) DPR_LAUNCH_GATHER(true, true);
-            else DPR_LAUNCH_GATHER(true, false);
+        if (unperm) {
+            if (pw) DPR_LAUNCH_GATHER(true, true, true);
+            else DPR_LAUNCH_GATHER(false, true, true);
+            stage_mark(st);
+            if (P > 0) {
+                const dim3 ug((unsigned)((P + 255) / 256));
+                if (b == 0)
+                    hipLaunchKernelGGL((k_unpermute<T, NI, true>), ug, dim3(256), 0, st, P,
+                                       (const Rec4<T>*)(ws + pl.off_rec),
+                                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
+                else
+                    hipLaunchKernelGGL((k_unpermute<T, NI, false>), ug, dim3(256), 0, st, P,
+                                       (const Rec4<T>*)(ws + pl.off_rec),
+                                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
+            }
         } else {
-            if (b == 0) DPR_LAUNCH_GATHER(false, true);
-            else DPR_LAUNCH_GATHER(false, false);
+            if (pw) {
+                if (b == 0) DPR_LAUNCH_GATHER(true, true, false);
+                else DPR_LAUNCH_GATHER(true, false, false);
+            } else {
+                if (b == 0) DPR_LAUNCH_GATHER(false, true, false);
+                else DPR_LAUNCH_GATHER(false, false, false);
+            }
+            stage_mark(st);
         }
 #undef DPR_LAUNCH_GATHER
         stage_mark(st);

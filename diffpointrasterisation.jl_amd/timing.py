@@ -12,7 +12,7 @@ STAGES = {
     ("raster", "atomic"): ["fill", "splat"],
     ("pullback", "atomic"): ["zero+grid_sum", "gather"],
     ("raster", "tiled"): ["count", "scan", "scatter", "tile_splat", "halo"],
-    ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "pose_reduce"],
+    ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "unpermute", "pose_reduce"],
 }
 
 _hip = None

@@ -99,7 +99,7 @@ int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t *grid, int64_t P
  * dpr_stage_timing_end() disarms and returns the number of events recorded.
  * Stage order -- DPR_ALGO_ATOMIC raster: fill, splat; pullback: zero+grid_sum, gather.
  * DPR_ALGO_TILED, per pose -- raster: count, scan, scatter, tile_splat, halo;
- * pullback: count, scan, scatter, tile_gather, pose_reduce. */
+ * pullback: count, scan, scatter, tile_gather, unpermute, pose_reduce. */
 int dpr_stage_timing_begin(void **events, int capacity);
 int dpr_stage_timing_end(void);
 
