@@ -204,9 +204,32 @@ __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts,
 }
 
 // exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768)
+// Also emits tile_order[]: tile ids by decreasing record count (bucketed by log2), so the
+// heaviest tiles of the following one-block-per-tile kernels are dispatched first.
 __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ totals, int NT,
-                                                   uint32_t* __restrict__ tile_start) {
+                                                   uint32_t* __restrict__ tile_start,
+                                                   uint32_t* __restrict__ tile_order) {
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t bcount[33], bstart[33];
+    if (threadIdx.x < 33) bcount[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT; i += 1024) {
+        const uint32_t c = totals[i];
+        atomicAdd(&bcount[c ? 32 - __clz(c) : 0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t start = 0;
+        for (int k = 32; k >= 0; --k) {
+            bstart[k] = start;
+            start += bcount[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT; i += 1024) {
+        const uint32_t c = totals[i];
+        tile_order[atomicAdd(&bstart[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)i;
+    }
     const int per = (NT + 1023) / 1024;
     const int i0 = threadIdx.x * per;
     uint32_t s = 0;
@@ -295,14 +318,14 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
 template <typename T, int NI, int NO, bool HAS_PW>
 __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
-    const uint32_t* __restrict__ tile_start, const T* __restrict__ rot,
-    const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b,
-    T* __restrict__ out, T* __restrict__ halo, int blocked) {
+    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_order,
+    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
+    const T* __restrict__ bg, int64_t b, T* __restrict__ out, T* __restrict__ halo, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NV = tile_voxels<NO>();
     __shared__ double acc[NVH];
     for (int i = threadIdx.x; i < NVH; i += kTileThreads) acc[i] = 0.0;
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
@@ -484,7 +507,7 @@ template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM>
 __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, int64_t P,
     const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
-    const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
+    const uint32_t* __restrict__ tile_order, const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
     const T* __restrict__ ow, int64_t b, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
     double* __restrict__ partials) {
     constexpr int NVH = tile_voxels_halo<NO>();
@@ -492,7 +515,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     constexpr int NW = kTileThreads / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const T* gb = g + b * gd.G;
@@ -511,22 +534,36 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     }
     // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground
     double bg_sum = 0.0;
-    for (int i = threadIdx.x; i < NVH; i += kTileThreads) {
-        int rem = i, off = 0, stride = 1;
-        bool ok = true, owned = true;
+    {
+        // all loads are issued (clamped addresses, no branches) before the first LDS write
+        constexpr int IT = (NVH + kTileThreads - 1) / kTileThreads;
+        T v[IT];
+        bool own[IT];
 #pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            const int l = rem % (TileDims<NO>::T[d] + 1);
-            rem /= TileDims<NO>::T[d] + 1;
-            const int gcoord = x0[d] + l;
-            ok = ok && gcoord < gd.n[d];
-            owned = owned && l < TileDims<NO>::T[d];
-            off += gcoord * stride;
-            stride *= gd.n[d];
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * kTileThreads;
+            int rem = i, off = 0, stride = 1;
+            bool ok = i < NVH, owned = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int l = rem % (TileDims<NO>::T[d] + 1);
+                rem /= TileDims<NO>::T[d] + 1;
+                const int gcoord = x0[d] + l;
+                ok = ok && gcoord < gd.n[d];
+                owned = owned && l < TileDims<NO>::T[d];
+                off += gcoord * stride;
+                stride *= gd.n[d];
+            }
+            const T x = gb[ok ? off : 0];
+            v[k] = ok ? x : T(0);
+            own[k] = owned && ok;
         }
-        const T v = ok ? gb[off] : T(0);
-        tile_g[i] = v;
-        if (owned) bg_sum += (double)v;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * kTileThreads;
+            if (i < NVH) tile_g[i] = v[k];
+            if (own[k]) bg_sum += (double)v[k];
+        }
     }
     __syncthreads();
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
@@ -705,11 +742,11 @@ static int env_int(const char* name, int dflt) {
 
 // Workspace layout (identical for raster and pullback so that a pullback can reuse the
 // binning a raster call left behind, DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING):
-//   counts table | totals | tile_start | records | indices | slot_of | aux (halo / partials)
+//   counts table | totals | tile_start | tile_order | records | indices | slot_of | aux (halo / partials)
 struct Plan {
     int nblk;
     int64_t chunk;
-    size_t off_counts, off_totals, off_tile_start, off_rec, off_idx, off_slot, off_aux, total;
+    size_t off_counts, off_totals, off_tile_start, off_order, off_rec, off_idx, off_slot, off_aux, total;
 };
 
 static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
@@ -731,6 +768,8 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     o += align_up((size_t)NT * 4);
     pl.off_tile_start = o;
     o += align_up((size_t)(NT + 1) * 4);
+    pl.off_order = o;
+    o += align_up((size_t)NT * 4);
     pl.off_rec = o;
     o += align_up((size_t)(P + 1) * 4 * elem);  // + spare slot for rejected points
     pl.off_idx = o;
@@ -828,7 +867,8 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     stage_mark(st);
     hipLaunchKernelGGL(k_colscan, dim3((tg.NT + 63) / 64), dim3(1024), 0, st, counts, pl.nblk,
                        tg.NT, totals);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, tile_start);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, tile_start,
+                       (uint32_t*)(ws + pl.off_order));
     stage_mark(st);
     int rc;
     if (pw) {
@@ -882,13 +922,15 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
         if (pw)
             hipLaunchKernelGGL((k_tile_splat<T, NI, NO, true>), dim3(tg.NT), dim3(kTileThreads), 0,
                                st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
-                               (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b,
-                               out, halo, blocked);
+                               (const uint32_t*)(ws + pl.off_tile_start),
+                               (const uint32_t*)(ws + pl.off_order), rot, trans, ow, bg, b, out,
+                               halo, blocked);
         else
             hipLaunchKernelGGL((k_tile_splat<T, NI, NO, false>), dim3(tg.NT), dim3(kTileThreads),
                                0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
-                               (const uint32_t*)(ws + pl.off_tile_start), rot, trans, ow, bg, b,
-                               out, halo, blocked);
+                               (const uint32_t*)(ws + pl.off_tile_start),
+                               (const uint32_t*)(ws + pl.off_order), rot, trans, ow, bg, b, out,
+                               halo, blocked);
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>), dim3(tg.NT), dim3(256), 0, st, gd, tg,
                            (const T*)halo, b, out);
@@ -942,8 +984,9 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(tg.NT),             \
                        dim3(kTileThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,       \
                        (const uint32_t*)(ws + pl.off_idx),                                      \
-                       (const uint32_t*)(ws + pl.off_tile_start), g, rot, trans, ow, b, d_pts,  \
-                       d_pw, partials)
+                       (const uint32_t*)(ws + pl.off_tile_start),                               \
+                       (const uint32_t*)(ws + pl.off_order), g, rot, trans, ow, b, d_pts, d_pw, \
+                       partials)
         if (unperm) {
             if (pw) DPR_LAUNCH_GATHER(true, true, true);
             else DPR_LAUNCH_GATHER(false, true, true);
