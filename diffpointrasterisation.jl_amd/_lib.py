@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpr.so")
+# DPR_LIB_OVERRIDE: experiment hook to A/B differently compiled builds of the same library
+LIB_PATH = os.environ.get("DPR_LIB_OVERRIDE") or os.path.join(_HERE, "libdpr.so")
 
 # status codes / enums of include/dpr.h
 OK = 0

@@ -35,15 +35,25 @@ namespace dpr {
 
 // ------------------------------------------------------------------ tile geometry
 template <int NO> struct TileDims;
+// 3-D tile shape and K4 block size (A/B measured on C3, profiles/r01_tile_shape_sweep.txt)
+#ifndef DPR_TY3
+#define DPR_TY3 16
+#endif
+#ifndef DPR_TZ3
+#define DPR_TZ3 16
+#endif
+#ifndef DPR_TILE_THREADS
+#define DPR_TILE_THREADS 512
+#endif
 template <> struct TileDims<3> {
-    static constexpr int T[3] = {32, 16, 8};
+    static constexpr int T[3] = {32, DPR_TY3, DPR_TZ3};
 };
 template <> struct TileDims<2> {
     static constexpr int T[3] = {32, 32, 1};
 };
 constexpr int kMaxTiles = 32768;     // LDS cursor table: 4 B per tile, <= 128 KiB
 constexpr int kBinThreads = 1024;    // K1 / K3 block
-constexpr int kTileThreads = 512;    // K4 block
+constexpr int kTileThreads = DPR_TILE_THREADS;  // K4 block
 constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
 
 template <int NO> struct TileGeom {
