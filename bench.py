@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled", "chunked"])
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="point order in memory: as generated, or pre-sorted (pose-independent)")
     ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform"])
@@ -169,7 +169,7 @@ def main():
     algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P, 1, n_in)
     # The pullback reuses the tile binning its forward call built in the same step (what an
     # rrule caches between `raster` and its pullback closure); nothing is carried across steps.
-    share = (not args.no_share_binning) and algo_f == "tiled" and algo_b == "tiled"
+    share = (not args.no_share_binning) and algo_f == algo_b and algo_f in ("tiled", "chunked")
 
     def fwd(keep=share):
         dpr_amd.raster_(out, inp["points"], inp["R"], inp["t"], algo=algo_f, workspace=ws,

@@ -24,9 +24,10 @@ OP_PULLBACK = 1
 ALGO_AUTO = 0
 ALGO_ATOMIC = 1
 ALGO_TILED = 2
+ALGO_CHUNKED = 3
 FLAG_KEEP_BINNING = 1
 FLAG_REUSE_BINNING = 2
-ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED}
+ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED, "chunked": ALGO_CHUNKED}
 
 EXPORTS = [
     "dpr_version", "dpr_last_error", "dpr_stage_timing_begin", "dpr_stage_timing_end",

@@ -132,6 +132,9 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
         if (algo == DPR_ALGO_TILED)                                                            \
             return raster_tiled<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot, trans, bg, ow,  \
                                            pw, ws, ws_bytes);                                  \
+        if (algo == DPR_ALGO_CHUNKED)                                                          \
+            return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot, trans, \
+                                             bg, ow, pw, ws, ws_bytes);                        \
     }
     DPR_CASE(2, 2)
     DPR_CASE(3, 3)
@@ -221,6 +224,10 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
             return pullback_tiled<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans, ow, pw,    \
                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
                                              ws_bytes);                                          \
+        if (algo == DPR_ALGO_CHUNKED)                                                            \
+            return pullback_chunked<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans,   \
+                                               ow, pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw,  \
+                                               ws, ws_bytes);                                    \
     }
     DPR_CASE(2, 2)
     DPR_CASE(3, 3)
@@ -241,6 +248,7 @@ static size_t workspace_impl(int op, int algo, int n_in, int n_out, const int64_
     algo = resolve_algo(algo, op, n_out, grid, P, B, G);
     if (algo == DPR_ALGO_ATOMIC) return 0;
     if (algo == DPR_ALGO_TILED) return tiled_workspace_bytes(sizeof(T), op, n_in, n_out, grid, P, B);
+    if (algo == DPR_ALGO_CHUNKED) return chunked_workspace_bytes(n_out, grid, P, B);
     fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
     return (size_t)-1;
 }

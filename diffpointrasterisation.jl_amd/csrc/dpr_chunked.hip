@@ -1,0 +1,860 @@
+// DPR_ALGO_CHUNKED: owner-computes voxel tiles fed by CHUNK LISTS instead of binned records.
+//
+// For spatially coherent point order (e.g. Morton-sorted in the model frame -- pose
+// independent, so the sort is amortised over poses and iterations) 256 consecutive points
+// cover a small box of the output grid.  Instead of permuting the points per pose
+// (DPR_ALGO_TILED), only the chunk ids are binned:
+//
+//   boxes        k_chunk_boxes   per (chunk, pose): voxel bounding box of the chunk's
+//                                neighbours -> range of tiles it touches; per-tile counters
+//   lists        k_list_scan     per pose: tile list offsets (+ heaviest-first tile order)
+//                k_list_fill     chunk ids into the per-tile lists (<= 8 tiles per chunk)
+//   forward      k_chunk_splat   block per (tile, pose): walks its chunk list, reads the
+//                                points straight from the caller's array (coalesced), keeps
+//                                ONLY the contributions that land in voxels the tile owns in
+//                                an LDS tile of f64 accumulators; out = background + acc with
+//                                plain stores.  No halo exchange, no global atomics.
+//   pullback     k_chunk_gather  block per tile: ds_dout tile (+1 halo) in LDS; handles the
+//                                points whose primary tile it is; stores ds_dpoints in place
+//                                (original order == coherent order -> mergeable writes)
+//   divert       k_chunk_divert_* chunks touching more than 8 tiles (incoherent input) go
+//                                through direct global atomics / gathers; always correct,
+//                                slow only for input that should not use this algorithm.
+//
+// Points are read (1 + tiles-per-chunk) times, but the point array of the headline configs
+// (120 MB) lives in the 256 MiB Infinity Cache, and nothing per-point is ever written in the
+// forward pass.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdlib>
+
+#include "../../include/dpr.h"
+#include "dpr_device.h"
+#include "dpr_tiled.h"
+
+namespace dpr {
+
+constexpr int kChunk = 256;         // points per chunk (= block size of the per-chunk kernels)
+constexpr int kMaxTilesPerChunk = 8;
+constexpr int kCThreads = 512;      // tile kernels: two chunks per iteration
+constexpr int kCMaxTiles = 65536;
+
+template <int NO> struct CTile;
+template <> struct CTile<3> {
+    static constexpr int T[3] = {32, 16, 8};
+};
+template <> struct CTile<2> {
+    static constexpr int T[3] = {32, 32, 1};
+};
+
+template <int NO> struct CGeom {
+    int nt[NO];
+    int NT;
+};
+
+template <int NO> static bool make_cgeom(const int64_t* grid, CGeom<NO>* tg) {
+    int64_t NT = 1;
+    for (int d = 0; d < NO; ++d) {
+        tg->nt[d] = (int)((grid[d] + CTile<NO>::T[d] - 1) / CTile<NO>::T[d]);
+        NT *= tg->nt[d];
+    }
+    if (NT > kCMaxTiles) return false;
+    tg->NT = (int)NT;
+    return true;
+}
+
+template <int NO> __host__ __device__ constexpr int ctile_voxels() {
+    int v = 1;
+    for (int d = 0; d < NO; ++d) v *= CTile<NO>::T[d];
+    return v;
+}
+template <int NO> __host__ __device__ constexpr int ctile_voxels_halo() {
+    int v = 1;
+    for (int d = 0; d < NO; ++d) v *= CTile<NO>::T[d] + 1;
+    return v;
+}
+
+struct alignas(16) ChunkBox {
+    short tlo[3];
+    short thi[3];
+    short state;  // 0 = no point with an in-range voxel, 1 = listed, 2 = diverted
+    short pad;
+};
+
+template <int NO>
+__device__ __forceinline__ void ctile_origin(int tile, const CGeom<NO>& tg, int (&x0)[NO],
+                                             int (&tc)[NO]) {
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        tc[d] = tile % tg.nt[d];
+        tile /= tg.nt[d];
+        x0[d] = tc[d] * CTile<NO>::T[d];
+    }
+}
+
+// ------------------------------------------------------------------ boxes
+template <typename T, int NI, int NO>
+__global__ __launch_bounds__(kChunk) void k_chunk_boxes(GridDesc<NO> gd, CGeom<NO> tg, int64_t P,
+                                                        int64_t n_chunks,
+                                                        const T* __restrict__ points,
+                                                        const T* __restrict__ rot,
+                                                        const T* __restrict__ trans, int64_t b0,
+                                                        ChunkBox* __restrict__ boxes,
+                                                        uint32_t* __restrict__ tile_count) {
+    __shared__ int red[kChunk / kWave][2 * NO];
+    const int64_t c = blockIdx.x;
+    const int64_t bl = blockIdx.y;  // pose index local to the workspace
+    const int64_t p = c * kChunk + threadIdx.x;
+    int lo[NO], hi[NO];
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        lo[d] = INT_MAX;
+        hi[d] = -1;
+    }
+    if (p < P) {
+        const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + bl);
+        T pt[NI];
+        load_point<T, NI>(points, p, pt);
+        int ref0[NO];
+        T dlo[NO];
+        if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                lo[d] = ref0[d] < 0 ? 0 : ref0[d];
+                hi[d] = ref0[d] + 1 < gd.n[d] ? ref0[d] + 1 : gd.n[d] - 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const int a = __shfl_xor(lo[d], o, kWave), bb = __shfl_xor(hi[d], o, kWave);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = bb > hi[d] ? bb : hi[d];
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            red[wave][2 * d] = lo[d];
+            red[wave][2 * d + 1] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ChunkBox bx;
+        bx.pad = 0;
+        int count = 1;
+        bool any = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            bx.tlo[d] = 0;
+            bx.thi[d] = 0;
+        }
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            int l = red[0][2 * d], h = red[0][2 * d + 1];
+#pragma unroll
+            for (int w = 1; w < kChunk / kWave; ++w) {
+                l = red[w][2 * d] < l ? red[w][2 * d] : l;
+                h = red[w][2 * d + 1] > h ? red[w][2 * d + 1] : h;
+            }
+            any = any && h >= l;
+            const int tl = l / CTile<NO>::T[d], th = h / CTile<NO>::T[d];
+            bx.tlo[d] = (short)tl;
+            bx.thi[d] = (short)th;
+            count *= (th - tl + 1);
+        }
+        if (!any) {
+            bx.state = 0;
+        } else if (count > kMaxTilesPerChunk) {
+            bx.state = 2;
+        } else {
+            bx.state = 1;
+            uint32_t* tcnt = tile_count + bl * tg.NT;
+            int t[3] = {0, 0, 0};
+            for (t[2] = bx.tlo[2]; t[2] <= bx.thi[2]; ++t[2])
+                for (t[1] = bx.tlo[1]; t[1] <= bx.thi[1]; ++t[1])
+                    for (t[0] = bx.tlo[0]; t[0] <= bx.thi[0]; ++t[0]) {
+                        int tile = 0, stride = 1;
+#pragma unroll
+                        for (int d = 0; d < NO; ++d) {
+                            tile += t[d] * stride;
+                            stride *= tg.nt[d];
+                        }
+                        atomicAdd(&tcnt[tile], 1u);
+                    }
+        }
+        boxes[bl * n_chunks + c] = bx;
+    }
+}
+
+// ------------------------------------------------------------------ lists
+// per pose: exclusive scan of tile_count -> list_start[NT+1]; tile_order by decreasing count
+__global__ __launch_bounds__(1024) void k_list_scan(const uint32_t* __restrict__ tile_count,
+                                                    int NT, uint32_t* __restrict__ list_start,
+                                                    uint32_t* __restrict__ tile_order) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t bcount[33], bstart[33];
+    const uint32_t* totals = tile_count + (size_t)blockIdx.x * NT;
+    uint32_t* start = list_start + (size_t)blockIdx.x * (NT + 1);
+    uint32_t* order = tile_order + (size_t)blockIdx.x * NT;
+    if (threadIdx.x < 33) bcount[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT; i += 1024) {
+        const uint32_t c = totals[i];
+        atomicAdd(&bcount[c ? 32 - __clz(c) : 0], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int k = 32; k >= 0; --k) {
+            bstart[k] = s;
+            s += bcount[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT; i += 1024) {
+        const uint32_t c = totals[i];
+        order[atomicAdd(&bstart[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)i;
+    }
+    const int per = (NT + 1023) / 1024;
+    const int i0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (int i = i0; i < i0 + per && i < NT; ++i) s += totals[i];
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= o) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += wsum[w];
+    uint32_t run = wbase + incl - s;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        start[i] = run;
+        run += totals[i];
+    }
+    if (threadIdx.x == 1023) start[NT] = wbase + incl;
+}
+
+// chunk ids into the tile lists; tile_count is counted back down to zero
+template <int NO>
+__global__ __launch_bounds__(256) void k_list_fill(CGeom<NO> tg, int64_t n_chunks,
+                                                   const ChunkBox* __restrict__ boxes,
+                                                   uint32_t* __restrict__ tile_count,
+                                                   const uint32_t* __restrict__ list_start,
+                                                   uint32_t* __restrict__ list, int64_t cap) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t bl = blockIdx.y;
+    if (c >= n_chunks) return;
+    const ChunkBox bx = boxes[bl * n_chunks + c];
+    if (bx.state != 1) return;
+    uint32_t* tcnt = tile_count + bl * tg.NT;
+    const uint32_t* start = list_start + bl * (tg.NT + 1);
+    uint32_t* lst = list + bl * cap;
+    int t[3] = {0, 0, 0};
+    for (t[2] = bx.tlo[2]; t[2] <= bx.thi[2]; ++t[2])
+        for (t[1] = bx.tlo[1]; t[1] <= bx.thi[1]; ++t[1])
+            for (t[0] = bx.tlo[0]; t[0] <= bx.thi[0]; ++t[0]) {
+                int tile = 0, stride = 1;
+#pragma unroll
+                for (int d = 0; d < NO; ++d) {
+                    tile += t[d] * stride;
+                    stride *= tg.nt[d];
+                }
+                const uint32_t slot = atomicSub(&tcnt[tile], 1u) - 1u;
+                lst[start[tile] + slot] = (uint32_t)c;
+            }
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int NI, int NO, bool HAS_PW>
+__global__ __launch_bounds__(kCThreads) void k_chunk_splat(
+    GridDesc<NO> gd, CGeom<NO> tg, int64_t P, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans,
+    const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
+    const uint32_t* __restrict__ list_start, const uint32_t* __restrict__ tile_order,
+    const uint32_t* __restrict__ list, int64_t cap, T* __restrict__ out) {
+    constexpr int NV = ctile_voxels<NO>();
+    __shared__ double acc[NV];
+    for (int i = threadIdx.x; i < NV; i += kCThreads) acc[i] = 0.0;
+    const int64_t bl = blockIdx.y, b = b0 + bl;
+    const int tile = (int)tile_order[bl * tg.NT + blockIdx.x];
+    int x0[NO], tc[NO];
+    ctile_origin<NO>(tile, tg, x0, tc);
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    const uint32_t* start = list_start + bl * (tg.NT + 1);
+    const uint32_t l0 = start[tile], l1 = start[tile + 1];
+    const uint32_t* lst = list + bl * cap;
+    __syncthreads();
+    const int sub = threadIdx.x / kChunk, lane_in_chunk = threadIdx.x % kChunk;
+    for (uint32_t i = l0 + sub; i < l1; i += kCThreads / kChunk) {
+        const int64_t p = (int64_t)lst[i] * kChunk + lane_in_chunk;
+        if (p >= P) continue;
+        T pt[NI];
+        load_point<T, NI>(points, p, pt);
+        const T w = ps.ow * (HAS_PW ? pw[p] : T(1));  // src/raster.jl:52
+        int ref0[NO];
+        T dlo[NO];
+        if (!ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) continue;
+        int lb[NO];
+        bool touches = true;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            lb[d] = ref0[d] - x0[d];
+            touches = touches && lb[d] >= -1 && lb[d] < CTile<NO>::T[d];
+        }
+        if (!touches) continue;
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) {
+            int idx = 0, stride = 1;
+            bool owned = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int l = lb[d] + ((s >> d) & 1);
+                owned = owned && l >= 0 && l < CTile<NO>::T[d];
+                idx += l * stride;
+                stride *= CTile<NO>::T[d];
+            }
+            // owned cells beyond the grid edge (partial tiles) are never flushed, which is the
+            // individual drop of src/raster.jl:62; cells at -1 belong to no tile
+            if (owned) atomicAdd(&acc[idx], (double)voxel_weight<T, NO>(dlo, s, w));
+        }
+    }
+    __syncthreads();
+    const double bgv = bg ? (double)bg[b] : 0.0;
+    T* o = out + b * gd.G;
+    for (int i = threadIdx.x; i < NV; i += kCThreads) {
+        int rem = i, off = 0, stride = 1;
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            const int l = rem % CTile<NO>::T[d];
+            rem /= CTile<NO>::T[d];
+            const int gcoord = x0[d] + l;
+            ok = ok && gcoord < gd.n[d];
+            off += gcoord * stride;
+            stride *= gd.n[d];
+        }
+        if (ok) o[off] = (T)(bgv + acc[i]);
+    }
+}
+
+// chunks that touch too many tiles: direct global atomics onto the finished grid
+template <typename T, int NI, int NO>
+__global__ __launch_bounds__(kChunk) void k_chunk_divert_fwd(
+    GridDesc<NO> gd, int64_t P, int64_t n_chunks, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans,
+    const T* __restrict__ ow, int64_t b0, const ChunkBox* __restrict__ boxes,
+    T* __restrict__ out) {
+    const int64_t c = blockIdx.x, bl = blockIdx.y, b = b0 + bl;
+    if (boxes[bl * n_chunks + c].state != 2) return;
+    const int64_t p = c * kChunk + threadIdx.x;
+    if (p >= P) return;
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    T pt[NI];
+    load_point<T, NI>(points, p, pt);
+    int ref0[NO];
+    T dlo[NO];
+    if (!ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) return;
+    const T w = ps.ow * (pw ? pw[p] : T(1));
+    T* o = out + b * gd.G;
+#pragma unroll
+    for (int s = 0; s < (1 << NO); ++s) {
+        const int off = nbr_offset<NO>(ref0, s, gd);
+        if (off >= 0) atomic_add<T>(o + off, voxel_weight<T, NO>(dlo, s, w));
+    }
+}
+
+// ------------------------------------------------------------------ pullback
+template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE>
+__global__ __launch_bounds__(kCThreads) void k_chunk_gather(
+    GridDesc<NO> gd, CGeom<NO> tg, int64_t P, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ g, const T* __restrict__ rot,
+    const T* __restrict__ trans, const T* __restrict__ ow, int64_t b, int64_t bl,
+    const uint32_t* __restrict__ list_start, const uint32_t* __restrict__ tile_order,
+    const uint32_t* __restrict__ list, int64_t cap, T* __restrict__ ds_dpoints,
+    T* __restrict__ ds_dpw, double* __restrict__ partials) {
+    constexpr int NVH = ctile_voxels_halo<NO>();
+    constexpr int NVAL = NO * NI + NO + 2;
+    constexpr int NW = kCThreads / kWave;
+    __shared__ T tile_g[NVH];
+    __shared__ double red[NW][NVAL];
+    const int tile = (int)tile_order[bl * tg.NT + blockIdx.x];
+    int x0[NO], tc[NO];
+    ctile_origin<NO>(tile, tg, x0, tc);
+    const T* gb = g + b * gd.G;
+    double bg_sum = 0.0;
+    {
+        constexpr int IT = (NVH + kCThreads - 1) / kCThreads;
+        T v[IT];
+        bool own[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * kCThreads;
+            int rem = i, off = 0, stride = 1;
+            bool ok = i < NVH, owned = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int l = rem % (CTile<NO>::T[d] + 1);
+                rem /= CTile<NO>::T[d] + 1;
+                const int gcoord = x0[d] + l;
+                ok = ok && gcoord < gd.n[d];
+                owned = owned && l < CTile<NO>::T[d];
+                off += gcoord * stride;
+                stride *= gd.n[d];
+            }
+            const T x = gb[ok ? off : 0];
+            v[k] = ok ? x : T(0);
+            own[k] = owned && ok;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * kCThreads;
+            if (i < NVH) tile_g[i] = v[k];
+            if (own[k]) bg_sum += (double)v[k];
+        }
+    }
+    __syncthreads();
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    T vals[NVAL - 1];
+#pragma unroll
+    for (int k = 0; k < NVAL - 1; ++k) vals[k] = T(0);
+    const uint32_t* start = list_start + bl * (tg.NT + 1);
+    const uint32_t l0 = start[tile], l1 = start[tile + 1];
+    const uint32_t* lst = list + bl * cap;
+    const int sub = threadIdx.x / kChunk, lane_in_chunk = threadIdx.x % kChunk;
+    for (uint32_t i = l0 + sub; i < l1; i += kCThreads / kChunk) {
+        const int64_t p = (int64_t)lst[i] * kChunk + lane_in_chunk;
+        if (p >= P) continue;
+        T pt[NI];
+        load_point<T, NI>(points, p, pt);
+        int ref0[NO];
+        T dlo[NO];
+        const bool valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        // every point belongs to exactly one tile: the one holding max(ref0, 0); points
+        // without an in-range voxel are cleared by the first tile of their chunk's box
+        bool mine = true;
+        int lb[NO];
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            const int r = ref0[d] < 0 ? 0 : ref0[d];
+            mine = mine && (r / CTile<NO>::T[d] == tc[d]);
+            lb[d] = ref0[d] - x0[d];
+        }
+        if (!valid) {
+            continue;  // cleared by k_chunk_divert_bwd (state-independent pass over all chunks)
+        }
+        if (!mine) continue;
+        const T pwi = HAS_PW ? pw[p] : T(1);
+        T gv[1 << NO];
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) {
+            int idx = 0, stride = 1;
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int sd = (s >> d) & 1;
+                const bool low_ok = lb[d] >= 0;
+                ok = ok && (sd || low_ok);
+                idx += ((sd || low_ok) ? lb[d] + sd : 0) * stride;
+                stride *= CTile<NO>::T[d] + 1;
+            }
+            const T gi = tile_g[idx];
+            gv[s] = ok ? gi : T(0);  // cells beyond the grid were staged as 0
+        }
+        T scaled[NO], dow_part = T(0), dpw_part = T(0);
+        {
+            T dcoord[NO];
+#pragma unroll
+            for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
+#pragma unroll
+            for (int s = 0; s < (1 << NO); ++s) {
+                const T gi = gv[s];
+                const T dweight = voxel_weight<T, NO>(dlo, s, gi);  // raster_pullback.jl:55
+                dow_part += dweight * pwi;                          // :57
+                dpw_part += dweight * ps.ow;                        // :58
+                const T factor = gi * ps.ow * pwi;                  // :60
+#pragma unroll
+                for (int n = 0; n < NO; ++n) dcoord[n] += factor * interp_weight<T, NO>(n, dlo, s);
+            }
+#pragma unroll
+            for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));  // :67
+        }
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) vals[n + j * NO] += scaled[n] * pt[j];  // :69
+            vals[NO * NI + n] += scaled[n];                                     // :68
+        }
+        vals[NO * NI + NO] += dow_part;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {  // rotation' * scaled (:70)
+            T v = ps.R[0 + j * NO] * scaled[0];
+#pragma unroll
+            for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
+            if (FIRST_POSE)
+                ds_dpoints[p * NI + j] = v;
+            else
+                ds_dpoints[p * NI + j] += v;
+        }
+        if (FIRST_POSE)
+            ds_dpw[p] = dpw_part;
+        else
+            ds_dpw[p] += dpw_part;
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) {
+        const double v = (k < NVAL - 1) ? (double)vals[k < NVAL - 1 ? k : 0] : bg_sum;
+        const double s = wave_sum<double>(v);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NVAL) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
+        partials[(size_t)threadIdx.x * tg.NT + tile] = s;
+    }
+}
+
+template <typename T, int NI, int NO>
+__global__ __launch_bounds__(1024) void k_cpose_reduce(const double* __restrict__ partials, int NT,
+                                                       int64_t b, T* __restrict__ ds_drotation,
+                                                       T* __restrict__ ds_dtranslation,
+                                                       T* __restrict__ ds_dbackground,
+                                                       T* __restrict__ ds_dout_weight) {
+    __shared__ double wsum[16];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < NT; t += 1024) s += partials[(size_t)k * NT + t];
+    s = wave_sum<double>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (k < NO * NI)
+            ds_drotation[b * (NO * NI) + k] = (T)tot;
+        else if (k < NO * NI + NO)
+            ds_dtranslation[b * NO + (k - NO * NI)] = (T)tot;
+        else if (k == NO * NI + NO)
+            ds_dout_weight[b] = (T)tot;
+        else
+            ds_dbackground[b] = (T)tot;
+    }
+}
+
+// Pass over ALL chunks after the tile kernel of pose b:
+//   * points without an in-range voxel get their (first-pose) zero gradient here
+//   * diverted chunks (state 2) are processed with direct gathers; their per-pose sums are
+//     added atomically on top of what k_cpose_reduce stored.
+template <typename T, int NI, int NO, bool FIRST_POSE>
+__global__ __launch_bounds__(kChunk) void k_chunk_divert_bwd(
+    GridDesc<NO> gd, int64_t P, int64_t n_chunks, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ g, const T* __restrict__ rot,
+    const T* __restrict__ trans, const T* __restrict__ ow, int64_t b, int64_t bl,
+    const ChunkBox* __restrict__ boxes, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
+    T* __restrict__ ds_drotation, T* __restrict__ ds_dtranslation,
+    T* __restrict__ ds_dout_weight) {
+    constexpr int NV = NO * NI + NO + 1;
+    constexpr int NW = kChunk / kWave;
+    __shared__ T red[NW][NV];
+    const int64_t c = blockIdx.x;
+    const int state = boxes[bl * n_chunks + c].state;
+    const int64_t p = c * kChunk + threadIdx.x;
+    const bool live = p < P;
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    T pt[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pt[j] = T(0);
+    if (live) load_point<T, NI>(points, p, pt);
+    int ref0[NO];
+    T dlo[NO];
+    const bool valid = live && ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+    if (live && !valid && FIRST_POSE) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
+        ds_dpw[p] = T(0);
+    }
+    if (state != 2) return;  // block-uniform
+    T vals[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) vals[k] = T(0);
+    if (valid) {
+        const T pwi = pw ? pw[p] : T(1);
+        const T* gb = g + b * gd.G;
+        T scaled[NO], dow_part, dpw_part;
+        point_backward<T, NI, NO>(ref0, dlo, gd, ps.ow, pwi, [&](int off) { return gb[off]; },
+                                  scaled, dow_part, dpw_part);
+#pragma unroll
+        for (int n = 0; n < NO; ++n) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) vals[n + j * NO] = scaled[n] * pt[j];
+            vals[NO * NI + n] = scaled[n];
+        }
+        vals[NO * NI + NO] = dow_part;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            T v = ps.R[0 + j * NO] * scaled[0];
+#pragma unroll
+            for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
+            if (FIRST_POSE)
+                ds_dpoints[p * NI + j] = v;
+            else
+                ds_dpoints[p * NI + j] += v;
+        }
+        if (FIRST_POSE)
+            ds_dpw[p] = dpw_part;
+        else
+            ds_dpw[p] += dpw_part;
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const T s = wave_sum<T>(vals[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        T s = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][threadIdx.x];
+        const int k = threadIdx.x;
+        if (s != T(0)) {
+            if (k < NO * NI)
+                atomic_add<T>(ds_drotation + b * (NO * NI) + k, s);
+            else if (k < NO * NI + NO)
+                atomic_add<T>(ds_dtranslation + b * NO + (k - NO * NI), s);
+            else
+                atomic_add<T>(ds_dout_weight + b, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static size_t calign(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct CPlan {
+    int64_t n_chunks, cap, Bw;  // Bw = poses held in the workspace at once
+    size_t off_boxes, off_count, off_start, off_order, off_list, off_partials, total;
+};
+
+static CPlan make_cplan(int NT, int64_t P, int64_t B) {
+    CPlan pl;
+    pl.n_chunks = (P + kChunk - 1) / kChunk;
+    if (pl.n_chunks < 1) pl.n_chunks = 1;
+    pl.cap = pl.n_chunks * kMaxTilesPerChunk;
+    pl.Bw = B < 1 ? 1 : (B > 65535 ? 65535 : B);
+    // bound the per-call workspace: at most 64 poses of lists at a time
+    if (pl.Bw > 64) pl.Bw = 64;
+    size_t o = 0;
+    pl.off_boxes = o;
+    o += calign((size_t)pl.Bw * pl.n_chunks * sizeof(ChunkBox));
+    pl.off_count = o;
+    o += calign((size_t)pl.Bw * NT * 4);
+    pl.off_start = o;
+    o += calign((size_t)pl.Bw * (NT + 1) * 4);
+    pl.off_order = o;
+    o += calign((size_t)pl.Bw * NT * 4);
+    pl.off_list = o;
+    o += calign((size_t)pl.Bw * pl.cap * 4);
+    pl.off_partials = o;
+    o += calign((size_t)NT * 16 * 8);
+    pl.total = o;
+    return pl;
+}
+
+bool chunked_supported(int n_out, const int64_t* grid) {
+    if (n_out == 3) {
+        CGeom<3> tg;
+        return make_cgeom<3>(grid, &tg);
+    }
+    CGeom<2> tg;
+    return make_cgeom<2>(grid, &tg);
+}
+
+size_t chunked_workspace_bytes(int n_out, const int64_t* grid, int64_t P, int64_t B) {
+    int NT;
+    if (n_out == 3) {
+        CGeom<3> tg;
+        if (!make_cgeom<3>(grid, &tg)) return (size_t)-1;
+        NT = tg.NT;
+    } else {
+        CGeom<2> tg;
+        if (!make_cgeom<2>(grid, &tg)) return (size_t)-1;
+        NT = tg.NT;
+    }
+    return make_cplan(NT, P, B).total;
+}
+
+#define DPR_HIP(expr)                                                                \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <int NO> static GridDesc<NO> cgrid_desc(const int64_t* grid, int64_t G) {
+    GridDesc<NO> gd;
+    for (int d = 0; d < NO; ++d) gd.n[d] = (int)grid[d];
+    gd.G = G;
+    return gd;
+}
+
+// boxes + lists for poses [b0, b0 + nb)
+template <typename T, int NI, int NO>
+static int build_lists(hipStream_t st, const GridDesc<NO>& gd, const CGeom<NO>& tg, const CPlan& pl,
+                       char* ws, int64_t P, const T* points, const T* rot, const T* trans,
+                       int64_t b0, int64_t nb) {
+    ChunkBox* boxes = (ChunkBox*)(ws + pl.off_boxes);
+    uint32_t* count = (uint32_t*)(ws + pl.off_count);
+    uint32_t* start = (uint32_t*)(ws + pl.off_start);
+    uint32_t* order = (uint32_t*)(ws + pl.off_order);
+    uint32_t* list = (uint32_t*)(ws + pl.off_list);
+    DPR_HIP(hipMemsetAsync(count, 0, (size_t)nb * tg.NT * 4, st));
+    hipLaunchKernelGGL((k_chunk_boxes<T, NI, NO>), dim3((unsigned)pl.n_chunks, (unsigned)nb),
+                       dim3(kChunk), 0, st, gd, tg, P, pl.n_chunks, points, rot, trans, b0, boxes,
+                       count);
+    stage_mark(st);
+    hipLaunchKernelGGL(k_list_scan, dim3((unsigned)nb), dim3(1024), 0, st, count, tg.NT, start,
+                       order);
+    hipLaunchKernelGGL((k_list_fill<NO>), dim3((unsigned)((pl.n_chunks + 255) / 256), (unsigned)nb),
+                       dim3(256), 0, st, tg, pl.n_chunks, boxes, count, start, list, pl.cap);
+    stage_mark(st);
+    return DPR_OK;
+}
+
+template <typename T, int NI, int NO>
+int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                   int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                   const T* ow, const T* pw, void* ws_, size_t ws_bytes) {
+    CGeom<NO> tg;
+    if (!make_cgeom<NO>(grid, &tg))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles",
+                    kCMaxTiles);
+    if ((flags & DPR_FLAG_KEEP_BINNING) && B != 1)
+        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
+                    (long long)B);
+    const CPlan pl = make_cplan(tg.NT, P, B);
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED raster needs %zu workspace bytes, got %zu",
+                    pl.total, ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    const GridDesc<NO> gd = cgrid_desc<NO>(grid, G);
+    for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
+        const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
+        if (int rc = build_lists<T, NI, NO>(st, gd, tg, pl, ws, P, points, rot, trans, b0, nb))
+            return rc;
+        const dim3 tgrid((unsigned)tg.NT, (unsigned)nb);
+#define DPR_SPLAT(HAS_PW)                                                                        \
+    hipLaunchKernelGGL((k_chunk_splat<T, NI, NO, HAS_PW>), tgrid, dim3(kCThreads), 0, st, gd, tg, \
+                       P, points, pw, rot, trans, ow, bg, b0,                                    \
+                       (const uint32_t*)(ws + pl.off_start), (const uint32_t*)(ws + pl.off_order), \
+                       (const uint32_t*)(ws + pl.off_list), pl.cap, out)
+        if (pw) DPR_SPLAT(true);
+        else DPR_SPLAT(false);
+#undef DPR_SPLAT
+        stage_mark(st);
+        hipLaunchKernelGGL((k_chunk_divert_fwd<T, NI, NO>),
+                           dim3((unsigned)pl.n_chunks, (unsigned)nb), dim3(kChunk), 0, st, gd, P,
+                           pl.n_chunks, points, pw, rot, trans, ow, b0,
+                           (const ChunkBox*)(ws + pl.off_boxes), out);
+        stage_mark(st);
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+template <typename T, int NI, int NO>
+int pullback_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                     int64_t B, const T* g, const T* points, const T* rot, const T* trans,
+                     const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                     T* d_pw, void* ws_, size_t ws_bytes) {
+    CGeom<NO> tg;
+    if (!make_cgeom<NO>(grid, &tg))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles",
+                    kCMaxTiles);
+    const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
+    if (reuse && B != 1)
+        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
+                    (long long)B);
+    const CPlan pl = make_cplan(tg.NT, P, B);
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE,
+                    "DPR_ALGO_CHUNKED pullback needs %zu workspace bytes, got %zu", pl.total,
+                    ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    const GridDesc<NO> gd = cgrid_desc<NO>(grid, G);
+    double* partials = (double*)(ws + pl.off_partials);
+    constexpr int NVAL = NO * NI + NO + 2;
+    for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
+        const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
+        if (reuse) {
+            stage_mark(st);
+            stage_mark(st);
+        } else if (int rc = build_lists<T, NI, NO>(st, gd, tg, pl, ws, P, points, rot, trans, b0,
+                                                   nb))
+            return rc;
+        // the point gradients accumulate over poses: one pose per launch
+        for (int64_t bl = 0; bl < nb; ++bl) {
+            const int64_t b = b0 + bl;
+#define DPR_GATHER(HAS_PW, FIRST)                                                                 \
+    hipLaunchKernelGGL((k_chunk_gather<T, NI, NO, HAS_PW, FIRST>), dim3((unsigned)tg.NT),         \
+                       dim3(kCThreads), 0, st, gd, tg, P, points, pw, g, rot, trans, ow, b, bl,   \
+                       (const uint32_t*)(ws + pl.off_start), (const uint32_t*)(ws + pl.off_order), \
+                       (const uint32_t*)(ws + pl.off_list), pl.cap, d_pts, d_pw, partials)
+            if (pw) {
+                if (b == 0) DPR_GATHER(true, true);
+                else DPR_GATHER(true, false);
+            } else {
+                if (b == 0) DPR_GATHER(false, true);
+                else DPR_GATHER(false, false);
+            }
+#undef DPR_GATHER
+            stage_mark(st);
+            hipLaunchKernelGGL((k_cpose_reduce<T, NI, NO>), dim3(NVAL), dim3(1024), 0, st,
+                               (const double*)partials, tg.NT, b, d_rot, d_trans, d_bg, d_ow);
+            stage_mark(st);
+            if (b == 0)
+                hipLaunchKernelGGL((k_chunk_divert_bwd<T, NI, NO, true>),
+                                   dim3((unsigned)pl.n_chunks), dim3(kChunk), 0, st, gd, P,
+                                   pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
+                                   (const ChunkBox*)(ws + pl.off_boxes), d_pts, d_pw, d_rot,
+                                   d_trans, d_ow);
+            else
+                hipLaunchKernelGGL((k_chunk_divert_bwd<T, NI, NO, false>),
+                                   dim3((unsigned)pl.n_chunks), dim3(kChunk), 0, st, gd, P,
+                                   pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
+                                   (const ChunkBox*)(ws + pl.off_boxes), d_pts, d_pw, d_rot,
+                                   d_trans, d_ow);
+            stage_mark(st);
+        }
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+#define DPR_INST(T, NI, NO)                                                                        \
+    template int raster_chunked<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, \
+                                           int64_t, T*, const T*, const T*, const T*, const T*,    \
+                                           const T*, const T*, void*, size_t);                     \
+    template int pullback_chunked<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t,       \
+                                             int64_t, int64_t, const T*, const T*, const T*,       \
+                                             const T*, const T*, const T*, T*, T*, T*, T*, T*,     \
+                                             T*, void*, size_t);
+DPR_INST(float, 2, 2)
+DPR_INST(float, 3, 3)
+DPR_INST(float, 3, 2)
+DPR_INST(double, 2, 2)
+DPR_INST(double, 3, 3)
+DPR_INST(double, 3, 2)
+}  // namespace dpr

@@ -26,4 +26,19 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                    const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw,
                    void* ws, size_t ws_bytes);
 
+// DPR_ALGO_CHUNKED (dpr_chunked.hip)
+bool chunked_supported(int n_out, const int64_t* grid);
+size_t chunked_workspace_bytes(int n_out, const int64_t* grid, int64_t P, int64_t B);
+
+template <typename T, int NI, int NO>
+int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                   int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                   const T* ow, const T* pw, void* ws, size_t ws_bytes);
+
+template <typename T, int NI, int NO>
+int pullback_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                     int64_t B, const T* g, const T* points, const T* rot, const T* trans,
+                     const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                     T* d_pw, void* ws, size_t ws_bytes);
+
 }  // namespace dpr

@@ -12,6 +12,8 @@ STAGES = {
     ("raster", "atomic"): ["fill", "splat"],
     ("pullback", "atomic"): ["zero+grid_sum", "gather"],
     ("raster", "tiled"): ["count", "scan", "scatter", "tile_splat", "halo"],
+    ("raster", "chunked"): ["boxes", "lists", "chunk_splat", "divert"],
+    ("pullback", "chunked"): ["boxes", "lists", "chunk_gather", "pose_reduce", "divert"],
     ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "unpermute", "pose_reduce"],
 }
 

@@ -70,6 +70,11 @@ extern "C" {
 #define DPR_ALGO_ATOMIC 1 /* thread per point, direct global float atomics / gathers */
 #define DPR_ALGO_TILED 2  /* per-pose binning of points into voxel tiles, LDS-resident
                              tile accumulation, plain-store flush (no global atomics) */
+#define DPR_ALGO_CHUNKED 3 /* for spatially coherent point order (e.g. Morton-sorted once in
+                              the model frame): chunks of 256 consecutive points are listed
+                              per voxel tile, tiles read the points in place; no per-point
+                              permutation.  Correct for any order (incoherent chunks are
+                              diverted to direct atomics) but only fast for coherent input. */
 
 /* flags (the *_ex entry points), DPR_ALGO_TILED with B == 1 only:
  * KEEP_BINNING  (raster)   leave the per-tile binning of the points (incl. original
@@ -99,7 +104,9 @@ int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t *grid, int64_t P
  * dpr_stage_timing_end() disarms and returns the number of events recorded.
  * Stage order -- DPR_ALGO_ATOMIC raster: fill, splat; pullback: zero+grid_sum, gather.
  * DPR_ALGO_TILED, per pose -- raster: count, scan, scatter, tile_splat, halo;
- * pullback: count, scan, scatter, tile_gather, unpermute, pose_reduce. */
+ * pullback: count, scan, scatter, tile_gather, unpermute, pose_reduce.
+ * DPR_ALGO_CHUNKED -- raster: boxes, lists, chunk_splat, divert;
+ * pullback: boxes, lists, chunk_gather, pose_reduce, divert. */
 int dpr_stage_timing_begin(void **events, int capacity);
 int dpr_stage_timing_end(void);
 

@@ -19,7 +19,7 @@ from tests import data as D
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = ["atomic", "tiled"]
+ALGOS = ["atomic", "tiled", "chunked"]
 DTYPES = [(np.float64, torch.float64), (np.float32, torch.float32)]
 SHAPES = [(2, 2), (3, 3), (3, 2)]  # (n_in, n_out)
 
@@ -255,20 +255,21 @@ def test_pullback_matches_central_differences_on_device(dev, algo, n_in, n_out):
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
 @pytest.mark.parametrize("n_in,n_out", SHAPES)
 @pytest.mark.parametrize("with_pw", [False, True])
-def test_pullback_reusing_forward_binning(oracle, dev, npdt, tdt, n_in, n_out, with_pw):
+@pytest.mark.parametrize("algo", ["tiled", "chunked"])
+def test_pullback_reusing_forward_binning(oracle, dev, algo, npdt, tdt, n_in, n_out, with_pw):
     """DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING: the pullback consumes the tile binning
     the forward call left in the workspace (the rrule pairing, ChainRulesCoreExt.jl:6-27).
     Some points lie outside the grid: their gradients must come back as zeros."""
     d = D.make(n_points=30_000, n_in=n_in, n_out=n_out, batch=1, grid_n=40, seed=21, dtype=npdt)
     d.points[::7] *= 4.0  # a good fraction far outside (-1, 1)
     pw = d.point_weights if with_pw else None
-    ws = torch.empty(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 1, n_in, tdt, "tiled"),
+    ws = torch.empty(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 1, n_in, tdt, algo),
                      dtype=torch.uint8, device=dev)
     out = dpr_amd.empty_grid(d.grid, 1, tdt, dev)
     args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
             T(d.weights, dev), T(pw, dev))
-    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=True)
-    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), *args, algo="tiled", workspace=ws,
+    dpr_amd.raster_(out, *args, algo=algo, workspace=ws, keep_binning=True)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), *args, algo=algo, workspace=ws,
                                   reuse_binning=True)
     ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds,
                             d.weights, pw, dtype=npdt)
@@ -277,6 +278,23 @@ def test_pullback_reusing_forward_binning(oracle, dev, npdt, tdt, n_in, n_out, w
     _compare(ref_out, ref_pb, out, pb, npdt)
     with pytest.raises(dpr_amd.DprError):  # flags are a tiled-path, single-pose feature
         dpr_amd.raster_(out, *args, algo="atomic", workspace=ws, keep_binning=True)
+
+
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 96), (3, 2, 200), (2, 2, 150)])
+def test_chunked_on_spatially_sorted_points(oracle, dev, npdt, tdt, n_in, n_out, grid_n):
+    """DPR_ALGO_CHUNKED on its intended input: Morton-sorted points (chunk lists are used,
+    few chunks diverted), several poses, grids of many tiles with remainders."""
+    d = D.make(n_points=60_000, n_in=n_in, n_out=n_out, batch=3, grid_n=grid_n, seed=23, dtype=npdt)
+    q = np.clip(((d.points.astype(np.float64) * 0.5 + 0.5) * 1024).astype(np.int64), 0, 1023)
+    code = np.zeros(len(q), dtype=np.int64)
+    for bit in range(10):
+        for k in range(n_in):
+            code |= ((q[:, k] >> bit) & 1) << (n_in * bit + k)
+    order = np.argsort(code, kind="stable")
+    d.points = np.ascontiguousarray(d.points[order])
+    d.point_weights = np.ascontiguousarray(d.point_weights[order])
+    _compare(*_run_both(oracle, dev, d, npdt, "chunked"), npdt)
 
 
 # ------------------------------------------------------------------ edge cases
