@@ -1,14 +1,14 @@
 // DPR_ALGO_CHUNKED: owner-computes voxel tiles fed by CHUNK LISTS instead of binned records.
 //
 // For spatially coherent point order (e.g. Morton-sorted in the model frame -- pose
-// independent, so the sort is amortised over poses and iterations) 256 consecutive points
-// cover a small box of the output grid.  Instead of permuting the points per pose
+// independent, so the sort is amortised over poses and iterations) 64 consecutive points
+// touch only a handful of tiles of the output grid.  Instead of permuting the points per pose
 // (DPR_ALGO_TILED), only the chunk ids are binned:
 //
-//   boxes        k_chunk_boxes   per (chunk, pose): voxel bounding box of the chunk's
-//                                neighbours -> range of tiles it touches; per-tile counters
+//   sets         k_chunk_sets    per (chunk, pose): the exact set of tiles its points touch
+//                                (wave-level union, chunk = one wave); per-tile counters
 //   lists        k_list_scan     per pose: tile list offsets (+ heaviest-first tile order)
-//                k_list_fill     chunk ids into the per-tile lists (<= 8 tiles per chunk)
+//                k_list_fill     chunk ids into the per-tile lists (<= 16 tiles per chunk)
 //   forward      k_chunk_splat   block per (tile, pose): walks its chunk list, reads the
 //                                points straight from the caller's array (coalesced), keeps
 //                                ONLY the contributions that land in voxels the tile owns in
@@ -17,7 +17,7 @@
 //   pullback     k_chunk_gather  block per tile: ds_dout tile (+1 halo) in LDS; handles the
 //                                points whose primary tile it is; stores ds_dpoints in place
 //                                (original order == coherent order -> mergeable writes)
-//   divert       k_chunk_divert_* chunks touching more than 8 tiles (incoherent input) go
+//   divert       k_chunk_divert_* chunks touching more than 16 tiles (incoherent input) go
 //                                through direct global atomics / gathers; always correct,
 //                                slow only for input that should not use this algorithm.
 //
@@ -35,9 +35,11 @@
 
 namespace dpr {
 
-constexpr int kChunk = 256;         // points per chunk (= block size of the per-chunk kernels)
-constexpr int kMaxTilesPerChunk = 8;
-constexpr int kCThreads = 512;      // tile kernels: two chunks per iteration
+constexpr int kChunk = 64;          // points per chunk = one wavefront
+constexpr int kSetMax = 16;         // tiles a chunk may be listed in; more -> diverted
+constexpr int kDiverted = 255;
+constexpr int kCThreads = 512;      // tile kernels: eight chunks per iteration
+constexpr int kCWaves = kCThreads / kWave;
 constexpr int kCMaxTiles = 65536;
 
 template <int NO> struct CTile;
@@ -75,13 +77,6 @@ template <int NO> __host__ __device__ constexpr int ctile_voxels_halo() {
     return v;
 }
 
-struct alignas(16) ChunkBox {
-    short tlo[3];
-    short thi[3];
-    short state;  // 0 = no point with an in-range voxel, 1 = listed, 2 = diverted
-    short pad;
-};
-
 template <int NO>
 __device__ __forceinline__ void ctile_origin(int tile, const CGeom<NO>& tg, int (&x0)[NO],
                                              int (&tc)[NO]) {
@@ -93,103 +88,78 @@ __device__ __forceinline__ void ctile_origin(int tile, const CGeom<NO>& tg, int 
     }
 }
 
-// ------------------------------------------------------------------ boxes
+// ------------------------------------------------------------------ sets
+// Exact set of tiles touched by the in-range neighbours of a chunk's 64 points, built by a
+// wave-level union (no LDS, no block barrier).  Lane l keeps set element l.
 template <typename T, int NI, int NO>
-__global__ __launch_bounds__(kChunk) void k_chunk_boxes(GridDesc<NO> gd, CGeom<NO> tg, int64_t P,
-                                                        int64_t n_chunks,
-                                                        const T* __restrict__ points,
-                                                        const T* __restrict__ rot,
-                                                        const T* __restrict__ trans, int64_t b0,
-                                                        ChunkBox* __restrict__ boxes,
-                                                        uint32_t* __restrict__ tile_count) {
-    __shared__ int red[kChunk / kWave][2 * NO];
-    const int64_t c = blockIdx.x;
-    const int64_t bl = blockIdx.y;  // pose index local to the workspace
-    const int64_t p = c * kChunk + threadIdx.x;
-    int lo[NO], hi[NO];
-#pragma unroll
-    for (int d = 0; d < NO; ++d) {
-        lo[d] = INT_MAX;
-        hi[d] = -1;
-    }
+__global__ __launch_bounds__(256) void k_chunk_sets(GridDesc<NO> gd, CGeom<NO> tg, int64_t P,
+                                                    int64_t n_chunks, const T* __restrict__ points,
+                                                    const T* __restrict__ rot,
+                                                    const T* __restrict__ trans, int64_t b0,
+                                                    uint16_t* __restrict__ sets,
+                                                    uint8_t* __restrict__ nset,
+                                                    uint32_t* __restrict__ tile_count) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t c = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    const int64_t bl = blockIdx.y;
+    if (c >= n_chunks) return;  // wave-uniform
+    const int64_t p = c * kChunk + lane;
+    bool valid = false;
+    int base = 0, cross = 0;
     if (p < P) {
         const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + bl);
         T pt[NI];
         load_point<T, NI>(points, p, pt);
         int ref0[NO];
         T dlo[NO];
-        if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
+        valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        if (valid) {
+            int stride = 1;
 #pragma unroll
             for (int d = 0; d < NO; ++d) {
-                lo[d] = ref0[d] < 0 ? 0 : ref0[d];
-                hi[d] = ref0[d] + 1 < gd.n[d] ? ref0[d] + 1 : gd.n[d] - 1;
+                const int lo = ref0[d] < 0 ? 0 : ref0[d];  // lowest in-range neighbour
+                const int hi = ref0[d] + 1;                // upper neighbour (may be out of range)
+                base += (lo / CTile<NO>::T[d]) * stride;
+                if (hi < gd.n[d] && hi / CTile<NO>::T[d] != lo / CTile<NO>::T[d]) cross |= 1 << d;
+                stride *= tg.nt[d];
             }
         }
     }
+    int myset = -1, n = 0;
+    bool overflow = false;
 #pragma unroll
-    for (int d = 0; d < NO; ++d) {
+    for (int m = 0; m < (1 << NO); ++m) {
+        int cand = -1;
+        if (valid && (m & ~cross) == 0) {
+            cand = base;
+            int stride = 1;
 #pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) {
-            const int a = __shfl_xor(lo[d], o, kWave), bb = __shfl_xor(hi[d], o, kWave);
-            lo[d] = a < lo[d] ? a : lo[d];
-            hi[d] = bb > hi[d] ? bb : hi[d];
-        }
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) {
-#pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            red[wave][2 * d] = lo[d];
-            red[wave][2 * d + 1] = hi[d];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        ChunkBox bx;
-        bx.pad = 0;
-        int count = 1;
-        bool any = true;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            bx.tlo[d] = 0;
-            bx.thi[d] = 0;
-        }
-#pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            int l = red[0][2 * d], h = red[0][2 * d + 1];
-#pragma unroll
-            for (int w = 1; w < kChunk / kWave; ++w) {
-                l = red[w][2 * d] < l ? red[w][2 * d] : l;
-                h = red[w][2 * d + 1] > h ? red[w][2 * d + 1] : h;
+            for (int d = 0; d < NO; ++d) {
+                if ((m >> d) & 1) cand += stride;
+                stride *= tg.nt[d];
             }
-            any = any && h >= l;
-            const int tl = l / CTile<NO>::T[d], th = h / CTile<NO>::T[d];
-            bx.tlo[d] = (short)tl;
-            bx.thi[d] = (short)th;
-            count *= (th - tl + 1);
         }
-        if (!any) {
-            bx.state = 0;
-        } else if (count > kMaxTilesPerChunk) {
-            bx.state = 2;
-        } else {
-            bx.state = 1;
-            uint32_t* tcnt = tile_count + bl * tg.NT;
-            int t[3] = {0, 0, 0};
-            for (t[2] = bx.tlo[2]; t[2] <= bx.thi[2]; ++t[2])
-                for (t[1] = bx.tlo[1]; t[1] <= bx.thi[1]; ++t[1])
-                    for (t[0] = bx.tlo[0]; t[0] <= bx.thi[0]; ++t[0]) {
-                        int tile = 0, stride = 1;
-#pragma unroll
-                        for (int d = 0; d < NO; ++d) {
-                            tile += t[d] * stride;
-                            stride *= tg.nt[d];
-                        }
-                        atomicAdd(&tcnt[tile], 1u);
-                    }
+        unsigned long long mask = __ballot(cand >= 0);
+        while (mask) {
+            const int leader = __shfl(cand, __ffsll((long long)mask) - 1, kWave);
+            const bool present = __ballot(lane < n && myset == leader) != 0ull;
+            if (!present) {
+                if (n < kSetMax) {
+                    if (lane == n) myset = leader;
+                    ++n;
+                } else {
+                    overflow = true;
+                }
+            }
+            if (cand == leader) cand = -1;
+            mask = __ballot(cand >= 0);
         }
-        boxes[bl * n_chunks + c] = bx;
     }
+    if (!overflow && lane < n) {
+        atomicAdd(&tile_count[bl * tg.NT + myset], 1u);
+        sets[(bl * n_chunks + c) * kSetMax + lane] = (uint16_t)myset;
+    }
+    if (lane == 0) nset[bl * n_chunks + c] = overflow ? (uint8_t)kDiverted : (uint8_t)n;
 }
 
 // ------------------------------------------------------------------ lists
@@ -244,33 +214,25 @@ __global__ __launch_bounds__(1024) void k_list_scan(const uint32_t* __restrict__
 }
 
 // chunk ids into the tile lists; tile_count is counted back down to zero
-template <int NO>
-__global__ __launch_bounds__(256) void k_list_fill(CGeom<NO> tg, int64_t n_chunks,
-                                                   const ChunkBox* __restrict__ boxes,
+__global__ __launch_bounds__(256) void k_list_fill(int NT, int64_t n_chunks,
+                                                   const uint16_t* __restrict__ sets,
+                                                   const uint8_t* __restrict__ nset,
                                                    uint32_t* __restrict__ tile_count,
                                                    const uint32_t* __restrict__ list_start,
                                                    uint32_t* __restrict__ list, int64_t cap) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t bl = blockIdx.y;
     if (c >= n_chunks) return;
-    const ChunkBox bx = boxes[bl * n_chunks + c];
-    if (bx.state != 1) return;
-    uint32_t* tcnt = tile_count + bl * tg.NT;
-    const uint32_t* start = list_start + bl * (tg.NT + 1);
+    const int n = nset[bl * n_chunks + c];
+    if (n == 0 || n == kDiverted) return;
+    uint32_t* tcnt = tile_count + bl * NT;
+    const uint32_t* start = list_start + bl * (NT + 1);
     uint32_t* lst = list + bl * cap;
-    int t[3] = {0, 0, 0};
-    for (t[2] = bx.tlo[2]; t[2] <= bx.thi[2]; ++t[2])
-        for (t[1] = bx.tlo[1]; t[1] <= bx.thi[1]; ++t[1])
-            for (t[0] = bx.tlo[0]; t[0] <= bx.thi[0]; ++t[0]) {
-                int tile = 0, stride = 1;
-#pragma unroll
-                for (int d = 0; d < NO; ++d) {
-                    tile += t[d] * stride;
-                    stride *= tg.nt[d];
-                }
-                const uint32_t slot = atomicSub(&tcnt[tile], 1u) - 1u;
-                lst[start[tile] + slot] = (uint32_t)c;
-            }
+    for (int k = 0; k < n; ++k) {
+        const int tile = sets[(bl * n_chunks + c) * kSetMax + k];
+        const uint32_t slot = atomicSub(&tcnt[tile], 1u) - 1u;
+        lst[start[tile] + slot] = (uint32_t)c;
+    }
 }
 
 // ------------------------------------------------------------------ forward
@@ -283,6 +245,11 @@ __global__ __launch_bounds__(kCThreads) void k_chunk_splat(
     const uint32_t* __restrict__ list, int64_t cap, T* __restrict__ out) {
     constexpr int NV = ctile_voxels<NO>();
     __shared__ double acc[NV];
+    // Staging of the 8 x 64 points of one iteration.  Consecutive sorted points hit the same
+    // voxels, and same-address LDS atomics of one wave-instruction serialise; reading the
+    // staged points back through an odd-stride permutation puts lane neighbours ~a chunk
+    // apart.
+    __shared__ T stage[NI + 1][kCThreads];
     for (int i = threadIdx.x; i < NV; i += kCThreads) acc[i] = 0.0;
     const int64_t bl = blockIdx.y, b = b0 + bl;
     const int tile = (int)tile_order[bl * tg.NT + blockIdx.x];
@@ -292,40 +259,60 @@ __global__ __launch_bounds__(kCThreads) void k_chunk_splat(
     const uint32_t* start = list_start + bl * (tg.NT + 1);
     const uint32_t l0 = start[tile], l1 = start[tile + 1];
     const uint32_t* lst = list + bl * cap;
-    __syncthreads();
-    const int sub = threadIdx.x / kChunk, lane_in_chunk = threadIdx.x % kChunk;
-    for (uint32_t i = l0 + sub; i < l1; i += kCThreads / kChunk) {
-        const int64_t p = (int64_t)lst[i] * kChunk + lane_in_chunk;
-        if (p >= P) continue;
-        T pt[NI];
-        load_point<T, NI>(points, p, pt);
-        const T w = ps.ow * (HAS_PW ? pw[p] : T(1));  // src/raster.jl:52
-        int ref0[NO];
-        T dlo[NO];
-        if (!ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) continue;
-        int lb[NO];
-        bool touches = true;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int src = (threadIdx.x * 67) & (kCThreads - 1);  // 67 odd: a bijection on 512
+    for (uint32_t i0 = l0; i0 < l1; i0 += kCWaves) {
+        // stage: wave w loads chunk i0 + w (coalesced); absent points become NaN (rejected)
+        {
+            const uint32_t i = i0 + wave;
+            int64_t p = -1;
+            if (i < l1) p = (int64_t)lst[i] * kChunk + lane;
+            const bool have = p >= 0 && p < P;
+            const int64_t pl = have ? p : 0;
+            T pt[NI];
+            load_point<T, NI>(points, pl, pt);
+            const T w = HAS_PW ? pw[pl] : T(1);
+            const T nanv = T(__builtin_nanf(""));
 #pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            lb[d] = ref0[d] - x0[d];
-            touches = touches && lb[d] >= -1 && lb[d] < CTile<NO>::T[d];
+            for (int j = 0; j < NI; ++j) stage[j][threadIdx.x] = have ? pt[j] : nanv;
+            stage[NI][threadIdx.x] = w;
         }
-        if (!touches) continue;
+        __syncthreads();
+        {
+            T pt[NI];
 #pragma unroll
-        for (int s = 0; s < (1 << NO); ++s) {
-            int idx = 0, stride = 1;
-            bool owned = true;
+            for (int j = 0; j < NI; ++j) pt[j] = stage[j][src];
+            const T w = ps.ow * stage[NI][src];  // src/raster.jl:52
+            int ref0[NO];
+            T dlo[NO];
+            if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
+                int lb[NO];
+                bool touches = true;
 #pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                const int l = lb[d] + ((s >> d) & 1);
-                owned = owned && l >= 0 && l < CTile<NO>::T[d];
-                idx += l * stride;
-                stride *= CTile<NO>::T[d];
+                for (int d = 0; d < NO; ++d) {
+                    lb[d] = ref0[d] - x0[d];
+                    touches = touches && lb[d] >= -1 && lb[d] < CTile<NO>::T[d];
+                }
+                if (touches) {
+#pragma unroll
+                    for (int s = 0; s < (1 << NO); ++s) {
+                        int idx = 0, stride = 1;
+                        bool owned = true;
+#pragma unroll
+                        for (int d = 0; d < NO; ++d) {
+                            const int l = lb[d] + ((s >> d) & 1);
+                            owned = owned && l >= 0 && l < CTile<NO>::T[d];
+                            idx += l * stride;
+                            stride *= CTile<NO>::T[d];
+                        }
+                        // owned cells beyond the grid edge (partial tiles) are never flushed:
+                        // the individual drop of src/raster.jl:62
+                        if (owned) atomicAdd(&acc[idx], (double)voxel_weight<T, NO>(dlo, s, w));
+                    }
+                }
             }
-            // owned cells beyond the grid edge (partial tiles) are never flushed, which is the
-            // individual drop of src/raster.jl:62; cells at -1 belong to no tile
-            if (owned) atomicAdd(&acc[idx], (double)voxel_weight<T, NO>(dlo, s, w));
         }
+        __syncthreads();
     }
     __syncthreads();
     const double bgv = bg ? (double)bg[b] : 0.0;
@@ -348,14 +335,15 @@ __global__ __launch_bounds__(kCThreads) void k_chunk_splat(
 
 // chunks that touch too many tiles: direct global atomics onto the finished grid
 template <typename T, int NI, int NO>
-__global__ __launch_bounds__(kChunk) void k_chunk_divert_fwd(
+__global__ __launch_bounds__(256) void k_chunk_divert_fwd(
     GridDesc<NO> gd, int64_t P, int64_t n_chunks, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans,
-    const T* __restrict__ ow, int64_t b0, const ChunkBox* __restrict__ boxes,
+    const T* __restrict__ ow, int64_t b0, const uint8_t* __restrict__ nset,
     T* __restrict__ out) {
-    const int64_t c = blockIdx.x, bl = blockIdx.y, b = b0 + bl;
-    if (boxes[bl * n_chunks + c].state != 2) return;
-    const int64_t p = c * kChunk + threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    const int64_t bl = blockIdx.y, b = b0 + bl;
+    if (c >= n_chunks || nset[bl * n_chunks + c] != kDiverted) return;  // wave-uniform
+    const int64_t p = c * kChunk + (threadIdx.x & (kWave - 1));
     if (p >= P) return;
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     T pt[NI];
@@ -558,20 +546,20 @@ __global__ __launch_bounds__(1024) void k_cpose_reduce(const double* __restrict_
 //   * diverted chunks (state 2) are processed with direct gathers; their per-pose sums are
 //     added atomically on top of what k_cpose_reduce stored.
 template <typename T, int NI, int NO, bool FIRST_POSE>
-__global__ __launch_bounds__(kChunk) void k_chunk_divert_bwd(
+__global__ __launch_bounds__(256) void k_chunk_divert_bwd(
     GridDesc<NO> gd, int64_t P, int64_t n_chunks, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ g, const T* __restrict__ rot,
     const T* __restrict__ trans, const T* __restrict__ ow, int64_t b, int64_t bl,
-    const ChunkBox* __restrict__ boxes, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
+    const uint8_t* __restrict__ nset, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
     T* __restrict__ ds_drotation, T* __restrict__ ds_dtranslation,
     T* __restrict__ ds_dout_weight) {
     constexpr int NV = NO * NI + NO + 1;
-    constexpr int NW = kChunk / kWave;
+    constexpr int NW = 256 / kWave;
     __shared__ T red[NW][NV];
-    const int64_t c = blockIdx.x;
-    const int state = boxes[bl * n_chunks + c].state;
-    const int64_t p = c * kChunk + threadIdx.x;
-    const bool live = p < P;
+    const int64_t c = (int64_t)blockIdx.x * NW + threadIdx.x / kWave;
+    const int state = c < n_chunks ? nset[bl * n_chunks + c] : 0;
+    const int64_t p = c * kChunk + (threadIdx.x & (kWave - 1));
+    const bool live = c < n_chunks && p < P;
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     T pt[NI];
 #pragma unroll
@@ -585,11 +573,11 @@ __global__ __launch_bounds__(kChunk) void k_chunk_divert_bwd(
         for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
         ds_dpw[p] = T(0);
     }
-    if (state != 2) return;  // block-uniform
+    if (__syncthreads_or(state == kDiverted) == 0) return;  // no diverted chunk in this block
     T vals[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) vals[k] = T(0);
-    if (valid) {
+    if (valid && state == kDiverted) {
         const T pwi = pw ? pw[p] : T(1);
         const T* gb = g + b * gd.G;
         T scaled[NO], dow_part, dpw_part;
@@ -645,20 +633,22 @@ static size_t calign(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct CPlan {
     int64_t n_chunks, cap, Bw;  // Bw = poses held in the workspace at once
-    size_t off_boxes, off_count, off_start, off_order, off_list, off_partials, total;
+    size_t off_sets, off_nset, off_count, off_start, off_order, off_list, off_partials, total;
 };
 
 static CPlan make_cplan(int NT, int64_t P, int64_t B) {
     CPlan pl;
     pl.n_chunks = (P + kChunk - 1) / kChunk;
     if (pl.n_chunks < 1) pl.n_chunks = 1;
-    pl.cap = pl.n_chunks * kMaxTilesPerChunk;
-    pl.Bw = B < 1 ? 1 : (B > 65535 ? 65535 : B);
-    // bound the per-call workspace: at most 64 poses of lists at a time
-    if (pl.Bw > 64) pl.Bw = 64;
+    pl.cap = pl.n_chunks * kSetMax;
+    pl.Bw = B < 1 ? 1 : B;
+    // bound the per-call workspace: at most 16 poses of sets/lists at a time
+    if (pl.Bw > 16) pl.Bw = 16;
     size_t o = 0;
-    pl.off_boxes = o;
-    o += calign((size_t)pl.Bw * pl.n_chunks * sizeof(ChunkBox));
+    pl.off_sets = o;
+    o += calign((size_t)pl.Bw * pl.n_chunks * kSetMax * 2);
+    pl.off_nset = o;
+    o += calign((size_t)pl.Bw * pl.n_chunks);
     pl.off_count = o;
     o += calign((size_t)pl.Bw * NT * 4);
     pl.off_start = o;
@@ -710,25 +700,27 @@ template <int NO> static GridDesc<NO> cgrid_desc(const int64_t* grid, int64_t G)
     return gd;
 }
 
-// boxes + lists for poses [b0, b0 + nb)
+// tile sets + lists for poses [b0, b0 + nb)
 template <typename T, int NI, int NO>
 static int build_lists(hipStream_t st, const GridDesc<NO>& gd, const CGeom<NO>& tg, const CPlan& pl,
                        char* ws, int64_t P, const T* points, const T* rot, const T* trans,
                        int64_t b0, int64_t nb) {
-    ChunkBox* boxes = (ChunkBox*)(ws + pl.off_boxes);
+    uint16_t* sets = (uint16_t*)(ws + pl.off_sets);
+    uint8_t* nset = (uint8_t*)(ws + pl.off_nset);
     uint32_t* count = (uint32_t*)(ws + pl.off_count);
     uint32_t* start = (uint32_t*)(ws + pl.off_start);
     uint32_t* order = (uint32_t*)(ws + pl.off_order);
     uint32_t* list = (uint32_t*)(ws + pl.off_list);
     DPR_HIP(hipMemsetAsync(count, 0, (size_t)nb * tg.NT * 4, st));
-    hipLaunchKernelGGL((k_chunk_boxes<T, NI, NO>), dim3((unsigned)pl.n_chunks, (unsigned)nb),
-                       dim3(kChunk), 0, st, gd, tg, P, pl.n_chunks, points, rot, trans, b0, boxes,
-                       count);
+    const unsigned cblocks = (unsigned)((pl.n_chunks + 3) / 4);
+    hipLaunchKernelGGL((k_chunk_sets<T, NI, NO>), dim3(cblocks, (unsigned)nb), dim3(256), 0, st, gd,
+                       tg, P, pl.n_chunks, points, rot, trans, b0, sets, nset, count);
     stage_mark(st);
     hipLaunchKernelGGL(k_list_scan, dim3((unsigned)nb), dim3(1024), 0, st, count, tg.NT, start,
                        order);
-    hipLaunchKernelGGL((k_list_fill<NO>), dim3((unsigned)((pl.n_chunks + 255) / 256), (unsigned)nb),
-                       dim3(256), 0, st, tg, pl.n_chunks, boxes, count, start, list, pl.cap);
+    hipLaunchKernelGGL(k_list_fill, dim3((unsigned)((pl.n_chunks + 255) / 256), (unsigned)nb),
+                       dim3(256), 0, st, tg.NT, pl.n_chunks, (const uint16_t*)sets,
+                       (const uint8_t*)nset, count, start, list, pl.cap);
     stage_mark(st);
     return DPR_OK;
 }
@@ -765,9 +757,9 @@ int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
 #undef DPR_SPLAT
         stage_mark(st);
         hipLaunchKernelGGL((k_chunk_divert_fwd<T, NI, NO>),
-                           dim3((unsigned)pl.n_chunks, (unsigned)nb), dim3(kChunk), 0, st, gd, P,
-                           pl.n_chunks, points, pw, rot, trans, ow, b0,
-                           (const ChunkBox*)(ws + pl.off_boxes), out);
+                           dim3((unsigned)((pl.n_chunks + 3) / 4), (unsigned)nb), dim3(256), 0, st,
+                           gd, P, pl.n_chunks, points, pw, rot, trans, ow, b0,
+                           (const uint8_t*)(ws + pl.off_nset), out);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());
@@ -826,15 +818,15 @@ int pullback_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_
             stage_mark(st);
             if (b == 0)
                 hipLaunchKernelGGL((k_chunk_divert_bwd<T, NI, NO, true>),
-                                   dim3((unsigned)pl.n_chunks), dim3(kChunk), 0, st, gd, P,
-                                   pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
-                                   (const ChunkBox*)(ws + pl.off_boxes), d_pts, d_pw, d_rot,
+                                   dim3((unsigned)((pl.n_chunks + 3) / 4)), dim3(256), 0, st, gd,
+                                   P, pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
+                                   (const uint8_t*)(ws + pl.off_nset), d_pts, d_pw, d_rot,
                                    d_trans, d_ow);
             else
                 hipLaunchKernelGGL((k_chunk_divert_bwd<T, NI, NO, false>),
-                                   dim3((unsigned)pl.n_chunks), dim3(kChunk), 0, st, gd, P,
-                                   pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
-                                   (const ChunkBox*)(ws + pl.off_boxes), d_pts, d_pw, d_rot,
+                                   dim3((unsigned)((pl.n_chunks + 3) / 4)), dim3(256), 0, st, gd,
+                                   P, pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
+                                   (const uint8_t*)(ws + pl.off_nset), d_pts, d_pw, d_rot,
                                    d_trans, d_ow);
             stage_mark(st);
         }
