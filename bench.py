@@ -84,6 +84,22 @@ def algorithmic_bytes(cfg, with_point_weight=False):
     return a_fwd, a_bwd
 
 
+def load_traffic_profile(args, algo_f):
+    """HBM bytes per forward call from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in
+    separate rocprofv3 passes of this same command and corrected as MI355X_MICROARCH.md
+    prescribes); measured offline, committed under profiles/ -- bench.py cannot profile itself."""
+    path = os.path.join(ROOT, "profiles", "r01_c3_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    key = f"{args.config}/{algo_f}/{args.order}"
+    ent = prof.get("forward", {}).get(key)
+    if not ent:
+        return None
+    return {"bytes": ent["hbm_bytes_corrected"], "source": f"profiles/r01_c3_hbm_traffic.json[{key}]"}
+
+
 def cpu_baseline(cfg, inp, budget_s=20.0):
     """Threaded CPU port of the reference algorithm (oracle/, kind "port") on a bounded
     sample: the first `n` points of the same cloud into the same grid, n chosen so the
@@ -131,6 +147,8 @@ def main():
     ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform"])
     ap.add_argument("--no-share-binning", action="store_true",
                     help="make the pullback redo the binning instead of reusing the forward's")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurement on Morton-sorted points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -155,6 +173,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P, n_in, grid, dt = CONFIGS[args.config]
+    s_elem = 4 if dt == "f32" else 8
     inp = synth_inputs(args.config, rank, device, args.order, args.dist)
     tdt = inp["points"].dtype
     out = dpr_amd.empty_grid(grid, 1, tdt, device)
@@ -206,30 +225,45 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * P / (elapsed / args.steps) / 1e6  # M points/s, whole job
 
-    # ---- per-pass device time with HIP events on the launch stream (torch's current stream)
-    def event_time(fn, reps):
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(reps)]
-        for a, b in evs:
-            a.record()
-            fn()
-            b.record()
-        torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in evs]))  # ms
-
+    # ---- per-pass device time with HIP events on the launch stream (torch's current stream);
+    # forward and pullback are timed inside fwd+bwd pairs (the pullback consumes -- and, when it
+    # reuses the binning, destroys -- what its forward left in the workspace)
     reps = max(5, min(args.steps, 20))
-    ms_fwd = event_time(fwd, reps)
-    ms_bwd = event_time(bwd, reps)
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(reps)]
+    for e0, e1, e2 in evs:
+        e0.record()
+        fwd()
+        e1.record()
+        bwd()
+        e2.record()
+    torch.cuda.synchronize()
+    ms_fwd = float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in evs]))
+    ms_bwd = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in evs]))
     a_fwd, a_bwd = algorithmic_bytes(args.config)
     st_f = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
-    st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps)
+    st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps, prepare=fwd)
     stages = {"raster": {"algo": algo_f, **{k: round(v, 4) for k, v in st_f.items()}},
               "pullback": {"algo": algo_b, **{k: round(v, 4) for k, v in st_b.items()}}}
+    # dominant kernel of the forward call, with the bytes that kernel itself has to move
+    kernel_bytes = {  # tiled pipeline, fp32/fp64 record = 4 values
+        "count": s_elem * P * n_in, "scatter": s_elem * P * n_in + 4 * s_elem * P,
+        "tile_splat": 4 * s_elem * P + s_elem * int(np.prod(grid)), "splat": a_fwd,
+        "chunk_splat": a_fwd}
+    dom = max((k for k in st_f if k != "total"), key=lambda k: st_f[k])
+    dominant = {"stage": dom, "ms": round(st_f[dom], 4)}
+    if dom in kernel_bytes:
+        dominant["bytes_moved_by_this_kernel"] = kernel_bytes[dom]
+        dominant["GBps"] = round(kernel_bytes[dom] / (st_f[dom] * 1e-3) / 1e9, 1)
+        dominant["frac_of_peak"] = round(kernel_bytes[dom] / (st_f[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    traffic = load_traffic_profile(args, algo_f)
 
     roof = {
         "bound": "hbm", "kernel": "raster! (all launches of one forward call)",
         "achieved": round(a_fwd / (ms_fwd * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "traffic": traffic["bytes"] if traffic else None,
+        "traffic_source": traffic["source"] if traffic else None,
+        "dominant_kernel": dominant,
         "algorithmic_bytes": a_fwd, "ms": round(ms_fwd, 4),
         "frac_of_measured_copy_peak": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_COPY_GBS, 4),
         "pullback": {"algorithmic_bytes": a_bwd, "ms": round(ms_bwd, 4),
@@ -252,6 +286,26 @@ def main():
                    "exchange": "all-reduce(sum) of [ds_dpoints|ds_dpoint_weight]" if world > 1 else "none"},
         "roofline": roof,
     }
+    if world == 1 and args.order == "random" and not args.no_secondary:
+        # secondary line: the same cloud pre-sorted once in the model frame (Morton order; the
+        # sort is pose-independent, so a user amortises it over poses and iterations)
+        inp["points"] = torch.as_tensor(inp["np_points"][morton_order(inp["np_points"])],
+                                        device=device)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        st_fm = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
+        st_bm = dpr_amd.stage_times(bwd, "pullback", algo_b, reps, prepare=fwd)
+        line["coherent_input"] = {
+            "point_order": "morton (sorted once, not timed)", "value": round(P / el / 1e6, 3),
+            "unit": "M points/s", "ms_per_step": round(el * 1e3, 4),
+            "raster_ms": round(st_fm["total"], 4), "pullback_ms": round(st_bm["total"], 4),
+            "raster_frac_of_hbm_peak": round(a_fwd / (st_fm["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.config, inp, args.cpu_budget)
     if rank == 0:

@@ -375,6 +375,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
 #pragma unroll
         for (int d = 0; d < NO; ++d) {
             lb[d] = ref0[d] - x0[d];
+            // records of this tile have lb in [-1, T-1]; the clamp only matters if the caller
+            // breaks the REUSE_BINNING contract (stale workspace) and keeps LDS indices legal
+            lb[d] = lb[d] < -1 ? -1 : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
             low_ok[d] = lb[d] >= 0;
         }
 #pragma unroll
@@ -607,6 +610,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
 #pragma unroll
         for (int d = 0; d < NO; ++d) {
             lb[d] = ref0[d] - x0[d];
+            // records of this tile have lb in [-1, T-1]; the clamp only matters if the caller
+            // breaks the REUSE_BINNING contract (stale workspace) and keeps LDS indices legal
+            lb[d] = lb[d] < -1 ? -1 : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
             low_ok[d] = lb[d] >= 0;
         }
         T gv[1 << NO];

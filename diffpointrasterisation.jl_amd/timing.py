@@ -33,9 +33,10 @@ def _hiprt():
 
 
 def stage_times(call: Callable[[], None], op: str, algo: str, reps: int = 10,
-                max_events: int = 64) -> Dict[str, float]:
+                max_events: int = 64, prepare: Callable[[], None] = None) -> Dict[str, float]:
     """Run `call` (ONE dpr raster/pullback invocation with B == 1) `reps` times with stage
-    timing armed; returns {stage: mean ms} plus "total"."""
+    timing armed; returns {stage: mean ms} plus "total".  `prepare` (untimed) runs before
+    every armed call, e.g. the forward pass whose binning a reuse-pullback consumes."""
     hip = _hiprt()
     L = _lib.lib()
     names = STAGES[(op, algo)]
@@ -47,6 +48,8 @@ def stage_times(call: Callable[[], None], op: str, algo: str, reps: int = 10,
         events[i] = ev
     try:
         for _ in range(reps):
+            if prepare is not None:
+                prepare()
             _lib.check(L.dpr_stage_timing_begin(events, max_events))
             try:
                 call()

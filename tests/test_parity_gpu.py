@@ -424,3 +424,31 @@ def test_full_size_properties(dev, algo, config):
     lhs = float((g2.double() * (out.double() - 0.25)).sum())
     rhs = 1.5 * float(pb2.out_weight[0])
     assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), np.sqrt(P))
+
+
+@pytest.mark.parametrize("algo", ["tiled", "chunked"])
+def test_large_grid_fp64_properties(dev, algo):
+    """BASELINE.json config 5 shape per pose (512^3 fp64 grid, 16384 tiles: the binning
+    kernels need > 48 KiB of dynamic LDS) with 2 M points: mass conservation, constant-
+    sensitivity pullback and the forward/pullback adjoint identity."""
+    P, n = 2_000_000, 512
+    f64 = dict(device=dev, dtype=torch.float64)
+    pts = _ball_points(P, dev, torch.float64, seed=3)
+    rng = np.random.default_rng(2)
+    R = T(D.random_rotations(rng, 1), dev)
+    t = T((0.05 * rng.normal(size=(1, 3))).clip(-0.1, 0.1), dev)
+    ow = torch.tensor([0.75], **f64)
+    out = dpr_amd.raster((n, n, n), pts, R, t, None, ow, algo=algo)
+    assert abs(float(out.sum()) - 0.75 * P) <= 1e-9 * P
+    g = torch.randn(1, n, n, n, **f64).permute(3, 2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, None, ow, algo=algo)
+    assert abs(float(pb.background[0]) - float(g.sum())) <= 1e-8 * float(g.abs().sum())
+    lhs = float((g * out).sum())
+    rhs = 0.75 * float(pb.out_weight[0])
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.0)
+    del out, g
+    gc = dpr_amd.empty_grid((n, n, n), 1, torch.float64, dev)
+    gc.fill_(2.0)
+    pb = dpr_amd.raster_pullback_(gc, pts, R, t, None, ow, algo=algo)
+    assert float(pb.points.abs().max()) <= 1e-9 * n
+    assert_close(pb.point_weight, np.full(P, 1.5), 1e-12)
