@@ -812,11 +812,13 @@ bool tiled_supported(int n_out, const int64_t* grid) {
 bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G) {
     if (!tiled_supported(n_out, grid)) return false;
     if (P >= (int64_t)1 << 32) return false;
-    // Fixed cost: ~6 launches per pose.  The direct path costs ~0.4 ns/point forward
-    // (scattered global atomics) and ~0.1 ns/point backward (scattered gathers).
+    // Measured crossover (profiles/r01_algo_sweep.txt, 128^3 / 256^3 / 512^2 grids, random and
+    // Morton order): the tiled pipeline's fixed cost (6-7 launches per pose) is repaid from
+    // ~2-3e5 points on, forward and backward alike; below that the direct kernels win.
     (void)G;
     (void)B;
-    return op == DPR_OP_RASTER ? P >= 300000 : P >= 2000000;
+    (void)op;
+    return P >= 250000;
 }
 
 size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
