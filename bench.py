@@ -162,14 +162,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DPR_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs
+    # than ranks (ranks share devices, the all-reduce goes through host memory); never the
+    # measured configuration.
+    backend = os.environ.get("DPR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P, n_in, grid, dt = CONFIGS[args.config]
@@ -199,11 +207,19 @@ def main():
                                  ds_dpoints=d_pts, ds_dpoint_weight=d_pw, algo=algo_b,
                                  workspace=ws, reuse_binning=reuse)
 
+    def exchange():
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(fused, op=dist.ReduceOp.SUM)
+            else:
+                host = fused.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                fused.copy_(host)
+
     def step():
         fwd()
         bwd()
-        if world > 1:
-            dist.all_reduce(fused, op=dist.ReduceOp.SUM)
+        exchange()
 
     def barrier():
         if world > 1:
@@ -219,7 +235,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu",
+                          dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
     ms_per_step = elapsed / args.steps * 1e3
@@ -283,7 +300,8 @@ def main():
                                f"raster! + raster_pullback!",
                    "algo": {"raster": algo_f, "pullback": algo_b}, "pullback_reuses_forward_binning": share,
                    "poses_global": world, "point_order": args.order,
-                   "exchange": "all-reduce(sum) of [ds_dpoints|ds_dpoint_weight]" if world > 1 else "none"},
+                   "exchange": (f"all-reduce(sum) of [ds_dpoints|ds_dpoint_weight] ({backend})"
+                                if world > 1 else "none")},
         "roofline": roof,
     }
     if world == 1 and args.order == "random" and not args.no_secondary:
