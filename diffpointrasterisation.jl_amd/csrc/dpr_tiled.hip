@@ -36,24 +36,34 @@ namespace dpr {
 // ------------------------------------------------------------------ tile geometry
 template <int NO> struct TileDims;
 // 3-D tile shape and K4 block size (A/B measured on C3, profiles/r01_tile_shape_sweep.txt)
+#ifndef DPR_TX3
+#define DPR_TX3 64
+#endif
 #ifndef DPR_TY3
 #define DPR_TY3 16
 #endif
 #ifndef DPR_TZ3
-#define DPR_TZ3 16
+#define DPR_TZ3 8
 #endif
 #ifndef DPR_TILE_THREADS
 #define DPR_TILE_THREADS 512
 #endif
 template <> struct TileDims<3> {
-    static constexpr int T[3] = {32, DPR_TY3, DPR_TZ3};
+    static constexpr int T[3] = {DPR_TX3, DPR_TY3, DPR_TZ3};
 };
 template <> struct TileDims<2> {
     static constexpr int T[3] = {32, 32, 1};
 };
 constexpr int kMaxTiles = 32768;     // LDS cursor table: 4 B per tile, <= 128 KiB
 constexpr int kBinThreads = 1024;    // K1 / K3 block
-constexpr int kTileThreads = DPR_TILE_THREADS;  // K4 block
+#ifndef DPR_SPLAT_THREADS
+#define DPR_SPLAT_THREADS DPR_TILE_THREADS
+#endif
+#ifndef DPR_GATHER_THREADS
+#define DPR_GATHER_THREADS 256
+#endif
+constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
+constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
 constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
 
 template <int NO> struct TileGeom {
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
 
 // ------------------------------------------------------------------ forward K4
 template <typename T, int NI, int NO, bool HAS_PW>
-__global__ __launch_bounds__(kTileThreads) void k_tile_splat(
+__global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
     const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_order,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NV = tile_voxels<NO>();
     __shared__ double acc[NVH];
-    for (int i = threadIdx.x; i < NVH; i += kTileThreads) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
     const int tile = (int)tile_order[blockIdx.x];
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
@@ -344,9 +354,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     // lane-adjacent records hit the same voxel and same-address LDS atomics serialise).
     uint32_t r1 = tile_start[tile + 1];
     uint32_t r = tile_start[tile];
-    uint32_t step = kTileThreads;
+    uint32_t step = kSplatThreads;
     if (blocked) {
-        const uint32_t per = (r1 - r + kTileThreads - 1) / kTileThreads;
+        const uint32_t per = (r1 - r + kSplatThreads - 1) / kSplatThreads;
         r += threadIdx.x * per;
         r1 = (r + per < r1) ? r + per : r1;
         step = 1;
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     // owned voxels: out = background + acc   (plain stores, rows of TX contiguous values)
     const double bgv = bg ? (double)bg[b] : 0.0;
     T* o = out + b * gd.G;
-    for (int i = threadIdx.x; i < NV; i += kTileThreads) {
+    for (int i = threadIdx.x; i < NV; i += kSplatThreads) {
         int l[NO], rem = i;
         int off = 0, stride = 1;
         bool ok = true;
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_splat(
     }
     // upper halo -> compact per-tile buffer (always fully written, zeros included)
     T* hb = halo + (size_t)tile * halo_count<NO>();
-    for (int i = threadIdx.x; i < NVH; i += kTileThreads) {
+    for (int i = threadIdx.x; i < NVH; i += kSplatThreads) {
         int h[NO], rem = i;
         bool is_halo = false;
 #pragma unroll
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
 // original order with one random read per point.  !UNPERM: the owner thread stores straight
 // to ds_dpoints[idx] / ds_dpoint_weight[idx] (good when the input order is spatially coherent).
 template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM>
-__global__ __launch_bounds__(kTileThreads) void k_tile_gather(
+__global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, int64_t P,
     const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ tile_order, const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     double* __restrict__ partials) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NVAL = NO * NI + NO + 2;  // dR | dt | d out_weight | d background
-    constexpr int NW = kTileThreads / kWave;
+    constexpr int NW = kGatherThreads / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
     const int tile = (int)tile_order[blockIdx.x];
@@ -549,12 +559,12 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
     double bg_sum = 0.0;
     {
         // all loads are issued (clamped addresses, no branches) before the first LDS write
-        constexpr int IT = (NVH + kTileThreads - 1) / kTileThreads;
+        constexpr int IT = (NVH + kGatherThreads - 1) / kGatherThreads;
         T v[IT];
         bool own[IT];
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            const int i = threadIdx.x + k * kTileThreads;
+            const int i = threadIdx.x + k * kGatherThreads;
             int rem = i, off = 0, stride = 1;
             bool ok = i < NVH, owned = true;
 #pragma unroll
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
         }
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
-            const int i = threadIdx.x + k * kTileThreads;
+            const int i = threadIdx.x + k * kGatherThreads;
             if (i < NVH) tile_g[i] = v[k];
             if (own[k]) bg_sum += (double)v[k];
         }
@@ -589,7 +599,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_gather(
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
         const uint32_t rcur = r;
-        r += kTileThreads;
+        r += kGatherThreads;
         {
             const uint32_t rl = r < r1 ? r : r1 - 1;  // clamped prefetch
             nxt = rec[rl];
@@ -938,13 +948,13 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                                            (T*)nullptr, (T*)nullptr, 0))
             return rc;
         if (pw)
-            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, true>), dim3(tg.NT), dim3(kTileThreads), 0,
+            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, true>), dim3(tg.NT), dim3(kSplatThreads), 0,
                                st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
                                (const uint32_t*)(ws + pl.off_tile_start),
                                (const uint32_t*)(ws + pl.off_order), rot, trans, ow, bg, b, out,
                                halo, blocked);
         else
-            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, false>), dim3(tg.NT), dim3(kTileThreads),
+            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, false>), dim3(tg.NT), dim3(kSplatThreads),
                                0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
                                (const uint32_t*)(ws + pl.off_tile_start),
                                (const uint32_t*)(ws + pl.off_order), rot, trans, ow, bg, b, out,
@@ -1000,7 +1010,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             return rc;
 #define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                                                   \
     hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(tg.NT),             \
-                       dim3(kTileThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,       \
+                       dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,     \
                        (const uint32_t*)(ws + pl.off_idx),                                      \
                        (const uint32_t*)(ws + pl.off_tile_start),                               \
                        (const uint32_t*)(ws + pl.off_order), g, rot, trans, ow, b, d_pts, d_pw, \

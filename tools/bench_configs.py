@@ -1,0 +1,46 @@
+"""One-GPU timings of the other BASELINE.json configs (not bench lines; see profiles/).
+C2: 1M pts -> 128^3 f32, 1 pose.  C4 (per-GPU share, reduced): 10M pts -> 512^2 f32, 8 of the
+64 poses a GPU would own.  C5 (per-pose): 50M pts -> 512^3 f64, 1 of the 8 poses a GPU owns."""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dpr_amd
+from bench import morton_order
+from tests import data as D
+
+dev = torch.device("cuda:0")
+def t_ms(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in e:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in e]))
+
+def run(name, P, grid, B, dt, order, algo="auto"):
+    rng = np.random.default_rng(0)
+    npdt = np.float32 if dt == torch.float32 else np.float64
+    pts = (0.4 * rng.standard_normal(size=(P, 3), dtype=np.float32))
+    if order == "morton":
+        pts = pts[morton_order(pts)]
+    n_out = len(grid)
+    tp = torch.as_tensor(pts.astype(npdt), device=dev)
+    R = torch.as_tensor(D.random_rotations(rng, B)[:, :n_out].astype(npdt), device=dev)
+    t = torch.as_tensor((0.1 * rng.normal(size=(B, n_out))).astype(npdt), device=dev)
+    g = torch.randn((B,) + tuple(reversed(grid)), device=dev, dtype=dt).permute(*reversed(range(n_out + 1)))
+    out = dpr_amd.empty_grid(grid, B, dt, dev)
+    wsb = max(16, dpr_amd.workspace_bytes("pullback", grid, P, B, 3, dt, algo), dpr_amd.workspace_bytes("raster", grid, P, B, 3, dt, algo))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    f = t_ms(lambda: dpr_amd.raster_(out, tp, R, t, algo=algo, workspace=ws))
+    b = t_ms(lambda: dpr_amd.raster_pullback_(g, tp, R, t, algo=algo, workspace=ws))
+    pp = P * B
+    print(f"{name:34s} {order:6s} algo={algo:7s} fwd {f:9.3f} ms ({pp / f / 1e6:8.2f} G point-poses/s)  bwd {b:9.3f} ms ({pp / b / 1e6:8.2f} G point-poses/s)  workspace {wsb / 2**20:7.0f} MiB", flush=True)
+    del out, g, ws, tp
+    torch.cuda.empty_cache()
+
+for order in ("random", "morton"):
+    run("C2 1M -> 128^3 f32, B=1", 1_000_000, (128,) * 3, 1, torch.float32, order)
+    run("C3 10M -> 256^3 f32, B=1", 10_000_000, (256,) * 3, 1, torch.float32, order)
+    run("C4 10M -> 512^2 f32, B=8 (of 64/GPU)", 10_000_000, (512, 512), 8, torch.float32, order)
+    run("C4 same, algo=atomic", 10_000_000, (512, 512), 8, torch.float32, order, "atomic")
+    run("C5 50M -> 512^3 f64, B=1 (of 8/GPU)", 50_000_000, (512,) * 3, 1, torch.float64, order)
