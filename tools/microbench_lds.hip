@@ -13,6 +13,7 @@ constexpr int TILE = 4096;  // 16 KB of floats
 
 // MODE 0: ds_add_f32 random   1: ds_add_f32 conflict-free (lane-linear)   2: ds_add_f32 same addr
 // 3: ds_add_u32 random   4: ds_write_b32 random   5: ds_add_rtn_f32 random  6: ds_add_f64 random (half tile)
+// 8: ds_add_u64 random  9: ds_max_f32? (unused)
 // 7: ds_add_f32 "splat-like": 4 x-adjacent pairs around a random base  8: ds_pk_add? (skip)
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* outp, int iters) {
@@ -44,6 +45,9 @@ __global__ __launch_bounds__(256) void k(float* outp, int iters) {
             if (MODE == 4) tile[idx] = (float)it;
             if (MODE == 5) acc += atomicAdd(&tile[idx], 0.5f);
             if (MODE == 6) atomicAdd(&tile_d[idx >> 1], 0.5);
+            if (MODE == 8) atomicAdd(&((unsigned long long*)tile_d)[idx >> 1], 12345ull);
+            if (MODE == 9) atomicAdd(&((unsigned long long*)tile_d)[(threadIdx.x + 64 * s + it * 64) & (TILE / 2 - 1)], 12345ull);
+            if (MODE == 10) atomicAdd(&tile_d[(threadIdx.x + 64 * s + it * 64) & (TILE / 2 - 1)], 0.5);
         }
     }
     __syncthreads();
@@ -78,6 +82,9 @@ int main() {
         run<5>("ds_add_rtn_f32 random", sink, bpc);
         run<6>("ds_add_f64 random", sink, bpc);
         run<7>("ds_add_f32 splat-like", sink, bpc);
+        run<8>("ds_add_u64 random", sink, bpc);
+        run<9>("ds_add_u64 conflict-free", sink, bpc);
+        run<10>("ds_add_f64 conflict-free", sink, bpc);
     }
     return 0;
 }
