@@ -31,7 +31,8 @@ ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED, "chunked
 
 EXPORTS = [
     "dpr_version", "dpr_last_error", "dpr_stage_timing_begin", "dpr_stage_timing_end",
-    "dpr_resolve_algo",
+    "dpr_resolve_algo", "dpr_sort_points_workspace_bytes", "dpr_sort_points_f32",
+    "dpr_sort_points_f64",
     "dpr_workspace_bytes_f32", "dpr_workspace_bytes_f64",
     "dpr_raster_f32", "dpr_raster_f64", "dpr_raster_ex_f32", "dpr_raster_ex_f64",
     "dpr_raster_pullback_f32", "dpr_raster_pullback_f64",
@@ -82,6 +83,12 @@ def lib() -> ctypes.CDLL:
     L.dpr_stage_timing_end.argtypes = []
     L.dpr_resolve_algo.restype = i
     L.dpr_resolve_algo.argtypes = [i, i, i, vp, i64, i64]
+    L.dpr_sort_points_workspace_bytes.restype = sz
+    L.dpr_sort_points_workspace_bytes.argtypes = [i64]
+    for suf in ("f32", "f64"):
+        f = getattr(L, f"dpr_sort_points_{suf}")
+        f.restype = i
+        f.argtypes = [vp, i, i64, vp, vp, vp, vp, vp, vp, sz]
     for suf in ("f32", "f64"):
         f = getattr(L, f"dpr_workspace_bytes_{suf}")
         f.restype = sz

@@ -1,0 +1,160 @@
+// dpr_sort_points_*: pose-independent spatial pre-sort of the model-frame points
+// (Morton / Z-order).  Not part of the reference; SURVEY.md 8(f) rank 3.  Every algorithm of
+// this library is faster on spatially coherent input (profiles/r01_summary.md), and the sort
+// depends on the points only, so a caller amortises it over poses and iterations.
+//
+//   keys   30-bit (3-D) / 32-bit (2-D) Morton code of the point quantised on [-1, 1)^n
+//   sort   rocPRIM radix sort of (key, index) pairs
+//   gather points_sorted[i] = points[perm[i]]   (+ point weights)
+//
+// Gradients computed on the sorted cloud go back with ds_dpoints[perm[i]] = sorted_grad[i].
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/dpr.h"
+#include "dpr_tiled.h"
+
+namespace dpr {
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t spread2(uint32_t v) {  // 16 bits -> every second bit
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void k_morton_keys(int64_t P, const T* __restrict__ points,
+                                                     uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ idx) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    constexpr int BITS = NI == 3 ? 10 : 16;
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        T x = points[p * NI + j];
+        // [-1, 1) -> [0, 2^BITS); NaN and out-of-range points go to the ends
+        x = (x * T(0.5) + T(0.5)) * T(1u << BITS);
+        uint32_t q = !(x > T(0)) ? 0u : (x >= T((1u << BITS) - 1) ? (1u << BITS) - 1 : (uint32_t)x);
+        key |= (NI == 3 ? spread3(q) : spread2(q)) << j;
+    }
+    keys[p] = key;
+    idx[p] = (uint32_t)p;
+}
+
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void k_gather_points(int64_t P, const uint32_t* __restrict__ perm,
+                                                       const T* __restrict__ points,
+                                                       const T* __restrict__ pw,
+                                                       T* __restrict__ points_sorted,
+                                                       T* __restrict__ pw_sorted) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t p = perm[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) points_sorted[i * NI + j] = points[(size_t)p * NI + j];
+    if (pw_sorted) pw_sorted[i] = pw[p];
+}
+
+static size_t salign(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t radix_temp_bytes(int64_t P) {
+    size_t temp = 0;
+    uint32_t* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t)P, 0, 32,
+                                    (hipStream_t)0);
+    return temp;
+}
+
+size_t sort_workspace_bytes(int64_t P) {
+    if (P < 1) P = 1;
+    return salign((size_t)P * 4) * 3 + salign(radix_temp_bytes(P));  // keys in/out, idx in, temp
+}
+
+template <typename T>
+int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
+                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes) {
+    if (n_in != 2 && n_in != 3)
+        return fail(DPR_ERR_UNSUPPORTED_DIMS, "dpr_sort_points: n_in must be 2 or 3 (got %d)", n_in);
+    if (P < 0 || P >= ((int64_t)1 << 32))
+        return fail(DPR_ERR_INVALID_ARG, "dpr_sort_points: P out of range");
+    if (P == 0) return DPR_OK;
+    if (!points || !points_sorted || !perm)
+        return fail(DPR_ERR_INVALID_ARG, "dpr_sort_points: NULL points / points_sorted / perm");
+    if ((pw == nullptr) != (pw_sorted == nullptr))
+        return fail(DPR_ERR_INVALID_ARG,
+                    "dpr_sort_points: point_weight and point_weight_sorted go together");
+    if (points == points_sorted)
+        return fail(DPR_ERR_INVALID_ARG, "dpr_sort_points: in-place sorting is not supported");
+    const size_t need = sort_workspace_bytes(P);
+    if (!ws_ || ws_bytes < need)
+        return fail(DPR_ERR_WORKSPACE, "dpr_sort_points needs %zu workspace bytes, got %zu", need,
+                    ws_ ? ws_bytes : (size_t)0);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)ws_;
+    // workspace: keys_in | keys_out | idx_in | rocPRIM temporary storage
+    uint32_t* keys_in = (uint32_t*)ws;
+    uint32_t* keys_out = (uint32_t*)(ws + salign((size_t)P * 4));
+    uint32_t* idx_in = (uint32_t*)(ws + 2 * salign((size_t)P * 4));
+    void* temp = ws + 3 * salign((size_t)P * 4);
+    size_t temp_bytes = radix_temp_bytes(P);
+    const dim3 grid((unsigned)((P + 255) / 256));
+    if (n_in == 3)
+        hipLaunchKernelGGL((k_morton_keys<T, 3>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+    else
+        hipLaunchKernelGGL((k_morton_keys<T, 2>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm,
+                                             (size_t)P, 0, n_in == 3 ? 30 : 32, st);
+    if (e != hipSuccess)
+        return fail(DPR_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+    if (n_in == 3)
+        hipLaunchKernelGGL((k_gather_points<T, 3>), grid, dim3(256), 0, st, P, perm, points, pw,
+                           points_sorted, pw_sorted);
+    else
+        hipLaunchKernelGGL((k_gather_points<T, 2>), grid, dim3(256), 0, st, P, perm, points, pw,
+                           points_sorted, pw_sorted);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(DPR_ERR_HIP, "dpr_sort_points: %s", hipGetErrorString(e));
+    return DPR_OK;
+}
+
+template int sort_points_impl<float>(void*, int, int64_t, const float*, float*, uint32_t*,
+                                     const float*, float*, void*, size_t);
+template int sort_points_impl<double>(void*, int, int64_t, const double*, double*, uint32_t*,
+                                      const double*, double*, void*, size_t);
+
+}  // namespace dpr
+
+extern "C" {
+
+size_t dpr_sort_points_workspace_bytes(int64_t P) { return dpr::sort_workspace_bytes(P); }
+
+int dpr_sort_points_f32(void* stream, int n_in, int64_t P, const float* points,
+                        float* points_sorted, uint32_t* perm, const float* point_weight,
+                        float* point_weight_sorted, void* workspace, size_t workspace_bytes) {
+    return dpr::sort_points_impl<float>(stream, n_in, P, points, points_sorted, perm, point_weight,
+                                        point_weight_sorted, workspace, workspace_bytes);
+}
+
+int dpr_sort_points_f64(void* stream, int n_in, int64_t P, const double* points,
+                        double* points_sorted, uint32_t* perm, const double* point_weight,
+                        double* point_weight_sorted, void* workspace, size_t workspace_bytes) {
+    return dpr::sort_points_impl<double>(stream, n_in, P, points, points_sorted, perm,
+                                         point_weight, point_weight_sorted, workspace,
+                                         workspace_bytes);
+}
+}

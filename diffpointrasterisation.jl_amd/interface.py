@@ -347,3 +347,27 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
     if c["single"]:
         return PullbackResult(d_pts, rot_math[0], d_trans[0], d_bg[0], d_ow[0], d_pw)
     return PullbackResult(d_pts, rot_math, d_trans, d_bg, d_ow, d_pw)
+
+
+def sort_points(points: torch.Tensor, point_weight: Optional[torch.Tensor] = None):
+    """Pose-independent Morton pre-sort of the model-frame points (dpr_sort_points_*).
+    Returns (points_sorted, perm[, point_weight_sorted]) with points_sorted[i] =
+    points[perm[i]]; gradients computed on the sorted cloud go back with
+    `ds_dpoints.index_copy_(0, perm.long(), ds_dpoints_sorted)`."""
+    device = _device_of(points)
+    if points.ndim != 2 or points.dtype not in _SUFFIX:
+        raise DimensionMismatch("points must be a (P, N_in) float32/float64 tensor")
+    pts = points.contiguous()
+    P, n_in = pts.shape
+    out = torch.empty_like(pts)
+    perm = torch.empty(P, dtype=torch.int32, device=device)
+    pw = None if point_weight is None else _as(point_weight, pts.dtype, device, (P,), "point_weight")
+    pw_out = None if pw is None else torch.empty_like(pw)
+    L = _lib.lib()
+    need = L.dpr_sort_points_workspace_bytes(P)
+    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        fn = getattr(L, f"dpr_sort_points_{_SUFFIX[pts.dtype]}")
+        _lib.check(fn(_stream_ptr(device), n_in, P, _ptr(pts), _ptr(out), _ptr(perm), _ptr(pw),
+                      _ptr(pw_out), _ptr(ws), ws.numel()))
+    return (out, perm) if pw is None else (out, perm, pw_out)

@@ -168,6 +168,19 @@ int dpr_raster_pullback_ex_f64(void *stream, int algo, unsigned flags, int n_in,
                                double *ds_dbackground, double *ds_dout_weight,
                                double *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
 
+/* Pose-independent spatial pre-sort (Morton order) of the model-frame points -- not in the
+ * reference; every algorithm here is faster on coherent input and the sort only depends on
+ * the points.  points_sorted[i] = points[perm[i]] (and point weights likewise; pass NULL for
+ * both weight pointers when unused).  Gradients of the sorted cloud go back with
+ * ds_dpoints[perm[i]] = ds_dpoints_sorted[i].  n_in = 2 or 3; P < 2^32. */
+size_t dpr_sort_points_workspace_bytes(int64_t P);
+int dpr_sort_points_f32(void *stream, int n_in, int64_t P, const float *points,
+                        float *points_sorted, uint32_t *perm, const float *point_weight,
+                        float *point_weight_sorted, void *workspace, size_t workspace_bytes);
+int dpr_sort_points_f64(void *stream, int n_in, int64_t P, const double *points,
+                        double *points_sorted, uint32_t *perm, const double *point_weight,
+                        double *point_weight_sorted, void *workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

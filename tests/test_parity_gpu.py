@@ -452,3 +452,43 @@ def test_large_grid_fp64_properties(dev, algo):
     pb = dpr_amd.raster_pullback_(gc, pts, R, t, None, ow, algo=algo)
     assert float(pb.points.abs().max()) <= 1e-9 * n
     assert_close(pb.point_weight, np.full(P, 1.5), 1e-12)
+
+
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in", [2, 3])
+def test_sort_points_is_a_morton_permutation(oracle, dev, npdt, tdt, n_in):
+    """dpr_sort_points_*: a permutation, keys non-decreasing, weights follow, and the
+    rasterisation of the sorted cloud equals that of the original (order-independent up to
+    rounding); gradients map back through perm."""
+    rng = np.random.default_rng(9)
+    P = 50_000
+    pts = (0.45 * rng.normal(size=(P, n_in))).astype(npdt)
+    pts[:5] = [[np.nan] * n_in, [5.0] * n_in, [-5.0] * n_in, [0.999] * n_in, [-1.0] * n_in]
+    pw = rng.uniform(size=P).astype(npdt)
+    sp, perm, spw = dpr_amd.sort_points(T(pts, dev), T(pw, dev))
+    perm_h = perm.cpu().numpy().astype(np.int64)
+    assert sorted(perm_h.tolist()) == list(range(P))
+    np.testing.assert_array_equal(sp.cpu().numpy(), pts[perm_h])
+    np.testing.assert_array_equal(spw.cpu().numpy(), pw[perm_h])
+    bits = 10 if n_in == 3 else 16
+    x = (pts[perm_h].astype(npdt) * npdt(0.5) + npdt(0.5)) * npdt(1 << bits)
+    q = np.where(~(x > 0), 0, np.where(x >= (1 << bits) - 1, (1 << bits) - 1, np.nan_to_num(x).astype(np.int64))).astype(np.int64)
+    key = np.zeros(P, dtype=np.int64)
+    for bit in range(bits):
+        for k in range(n_in):
+            key |= ((q[:, k] >> bit) & 1) << (n_in * bit + k)
+    assert (np.diff(key) >= 0).all()
+    # same image, gradients map back through perm
+    fin = np.isfinite(pts).all(axis=1)
+    pts[~fin] = 7.0
+    d = D.make(n_points=10, n_in=n_in, n_out=2 if n_in == 2 else 3, batch=1, grid_n=24, seed=3, dtype=npdt)
+    sp, perm = dpr_amd.sort_points(T(pts, dev))
+    a = dpr_amd.raster(d.grid, T(pts, dev), T(d.rotations, dev), T(d.translations, dev))
+    b = dpr_amd.raster(d.grid, sp, T(d.rotations, dev), T(d.translations, dev))
+    assert_close(b, a.cpu().numpy(), tol(npdt, "out"), "sorted vs original image")
+    g = grid_to_dev(D.make(n_points=1, n_in=n_in, n_out=len(d.grid), batch=1, grid_n=24, seed=4, dtype=npdt).ds_dout, dev)
+    pa = dpr_amd.raster_pullback_(g, T(pts, dev), T(d.rotations, dev), T(d.translations, dev))
+    pb = dpr_amd.raster_pullback_(g, sp, T(d.rotations, dev), T(d.translations, dev))
+    back = torch.empty_like(pb.points)
+    back.index_copy_(0, perm.long(), pb.points)
+    assert_close(back, pa.points.cpu().numpy(), tol(npdt, "points"), "gradients through perm")
