@@ -165,6 +165,16 @@ __device__ __forceinline__ uint32_t slot_to_idx(double v) {
     return (uint32_t)__double_as_longlong(v);
 }
 
+// XCD-aware work mapping (speed only, never correctness): workgroups are dealt round-robin
+// over the 8 XCDs, so blocks b and b+8 share an L2.  Giving the blocks of one XCD a
+// CONTIGUOUS range of slices keeps neighbouring slices -- whose record runs share cache lines
+// at their ends, and whose un-permute reads hit the same 64-byte sectors -- in one L2.
+__device__ __forceinline__ unsigned xcd_slice(unsigned block, unsigned nblocks) {
+    const unsigned per = nblocks / 8;  // slices per XCD in the swizzled part
+    if (block >= per * 8) return block;  // remainder keeps its identity
+    return (block % 8) * per + block / 8;
+}
+
 // ------------------------------------------------------------------ K1: count
 template <typename T, int NI, int NO>
 __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom<NO> tg, int64_t P,
@@ -176,7 +186,8 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
     for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) hist[i] = 0;
     __syncthreads();
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
-    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
+    const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
     for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
         T pt[NI];
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
             atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
     }
     __syncthreads();
-    uint32_t* row = counts + (size_t)blockIdx.x * tg.NT;
+    uint32_t* row = counts + (size_t)slice * tg.NT;
     for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) row[i] = hist[i];
 }
 
@@ -284,11 +295,12 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     Rec4<T>* __restrict__ rec, uint32_t* __restrict__ rec_idx, uint32_t* __restrict__ slot_of,
     T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, int zero_dropped) {
     extern __shared__ uint32_t cursor[];
-    const uint32_t* row = prefix + (size_t)blockIdx.x * tg.NT;
+    const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
+    const uint32_t* row = prefix + (size_t)slice * tg.NT;
     for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) cursor[i] = tile_start[i] + row[i];
     __syncthreads();
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
-    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
     // Fixed memory-op pattern per iteration (one clamped prefetch, one record store, the
     // latter to the spare slot P when the point has no in-range voxel) so that the wait for
@@ -713,7 +725,7 @@ __global__ __launch_bounds__(256) void k_unpermute(int64_t P, const Rec4<T>* __r
                                                    const uint32_t* __restrict__ slot_of,
                                                    T* __restrict__ ds_dpoints,
                                                    T* __restrict__ ds_dpw) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = (int64_t)xcd_slice(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (p >= P) return;
     const Rec4<T> g = grad[slot_of[p]];
     if (FIRST_POSE) {
