@@ -204,13 +204,15 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
 
 // ------------------------------------------------------------------ K2: scans
 // counts[nblk][NT] -> in place exclusive prefix down each column; totals[NT].
-// Block = 64 tiles x 16 row groups.
+// Block = kScanTiles tiles x kScanGroups row groups (32 x 32: NT/32 blocks keep more CUs busy
+// than the 64 x 16 split; rows of 32 tiles are still 128-byte segments).
+constexpr int kScanTiles = 32, kScanGroups = 32;
 __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
                                                   uint32_t* __restrict__ totals) {
-    __shared__ uint32_t part[16][64];
-    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 64 + j;
-    const int rows = (nblk + 15) / 16;
+    __shared__ uint32_t part[kScanGroups][kScanTiles];
+    const int j = threadIdx.x % kScanTiles, g = threadIdx.x / kScanTiles;
+    const int tile = blockIdx.x * kScanTiles + j;
+    const int rows = (nblk + kScanGroups - 1) / kScanGroups;
     const int r0 = g * rows, r1 = (r0 + rows < nblk) ? r0 + rows : nblk;
     uint32_t s = 0;
     if (tile < NT)
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts,
     __syncthreads();
     uint32_t base = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < kScanGroups; ++k) {
         const uint32_t v = part[k][j];
         if (k < g) base += v;
         total += v;
@@ -905,7 +907,7 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     hipLaunchKernelGGL((k_count<T, NI, NO>), dim3(pl.nblk), dim3(kBinThreads), lds, st, gd, tg, P,
                        pl.chunk, points, rot, trans, b, counts);
     stage_mark(st);
-    hipLaunchKernelGGL(k_colscan, dim3((tg.NT + 63) / 64), dim3(1024), 0, st, counts, pl.nblk,
+    hipLaunchKernelGGL(k_colscan, dim3((tg.NT + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st, counts, pl.nblk,
                        tg.NT, totals);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, tile_start,
                        (uint32_t*)(ws + pl.off_order));
