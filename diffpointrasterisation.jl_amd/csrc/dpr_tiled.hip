@@ -348,6 +348,125 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     }
 }
 
+// ------------------------------------------------------------------ K3': write-combining scatter
+// Same placement as k_scatter, but the records of a sub-chunk of S points are first ordered
+// by tile in LDS, so that neighbouring lanes of the write-out store neighbouring slots:
+// one 64-lane store instruction then covers a few contiguous runs instead of 64 unrelated
+// 16-byte pieces (measured: 10 M scattered 16-byte stores cost ~75 us more than coalesced
+// ones, profiles/r01_experiments.md).
+//   LDS: cursor[NT] (dynamic) | lhist[NT] (dynamic) | recs[S] | dest[S]
+template <typename T, int NI, int NO, bool HAS_PW, int S>
+__global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
+    GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
+    const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
+    Rec4<T>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
+    T* __restrict__ ds_dpw, int zero_dropped) {
+    constexpr int PPT = S / kBinThreads;  // points per thread per sub-chunk
+    extern __shared__ uint32_t dyn[];
+    uint32_t* cursor = dyn;
+    uint32_t* lhist = dyn + tg.NT;
+    __shared__ Rec4<T> recs[S];
+    __shared__ uint32_t dest[S];
+    __shared__ uint32_t wsum[kBinThreads / kWave];
+    const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
+    const uint32_t* row = prefix + (size_t)slice * tg.NT;
+    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) {
+        cursor[i] = tile_start[i] + row[i];
+        lhist[i] = 0;
+    }
+    __syncthreads();
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
+    const int64_t lo = (int64_t)slice * chunk;
+    const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
+    // bins owned by this thread in the scan / cursor update
+    const int bpt = (tg.NT + kBinThreads - 1) / kBinThreads;
+    const int bin0 = threadIdx.x * bpt;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int64_t base = lo; base < hi; base += S) {
+        // a. load, classify, rank inside (sub-chunk, tile)
+        T pt[PPT][NI], w[PPT];
+        int tile[PPT];
+        uint32_t lrank[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+            const int64_t pl = p < hi ? p : hi - 1;
+            load_point<T, NI>(points, pl, pt[k]);
+            w[k] = HAS_PW ? pw[pl] : T(1);
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+            int ref0[NO];
+            T dlo[NO];
+            const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
+            tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+            lrank[k] = 0;
+            if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
+        }
+        __syncthreads();
+        // b. exclusive scan of lhist (in place); keep the owned counts for the cursor update
+        uint32_t cnt_sum = 0;
+        for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) cnt_sum += lhist[i];
+        uint32_t incl = cnt_sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - cnt_sum;
+        for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
+        uint32_t n_valid = 0;
+#pragma unroll
+        for (int wv = 0; wv < kBinThreads / kWave; ++wv) n_valid += wsum[wv];
+        for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) {
+            const uint32_t c = lhist[i];
+            lhist[i] = run;  // exclusive offset inside the sub-chunk
+            run += c;
+        }
+        __syncthreads();
+        // c. place into LDS in tile order; remember the global destination
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+            if (tile[k] >= 0) {
+                const uint32_t sidx = lhist[tile[k]] + lrank[k];
+                const uint32_t d = cursor[tile[k]] + lrank[k];
+                Rec4<T> r;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
+                r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+                recs[sidx] = r;
+                dest[sidx] = d;
+                if (slot_of) slot_of[p] = d;
+            } else if (p < hi) {
+                if (slot_of) slot_of[p] = (uint32_t)P;  // spare slot
+                if (zero_dropped) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
+                    ds_dpw[p] = T(0);
+                }
+            }
+        }
+        __syncthreads();
+        // d. write-out in LDS (= tile) order; e. advance cursors, clear the histogram
+        for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[dest[i]] = recs[i];
+        {
+            // counts of the owned bins = differences of the exclusive offsets
+            for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) {
+                const uint32_t nxt = (i + 1 < tg.NT) ? lhist[i + 1] : n_valid;
+                cursor[i] += nxt - lhist[i];
+            }
+        }
+        __syncthreads();
+        for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) lhist[i] = 0;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ forward K4
 template <typename T, int NI, int NO, bool HAS_PW>
 __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
@@ -882,6 +1001,21 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
                           const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
                           const T* rot, const T* trans, int64_t b, T* d_pts, T* d_pw,
                           int zero_dropped) {
+    // write-combining variant: needs 2 NT counters + the sub-chunk in LDS, and does not
+    // produce rec_idx (only the direct-store pullback mode with point weights reads that)
+    const int wc = env_int("DPR_SCATTER_WC", 1);
+    const bool needs_idx = HAS_PW && WANT_IDX && env_int("DPR_BWD_UNPERMUTE", 1) == 0;
+    if (wc && tg.NT <= 4096 && !needs_idx) {
+        constexpr int S = (sizeof(T) == 4) ? 4096 : 2048;
+        const size_t lds2 = (size_t)tg.NT * 8;
+        hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S>), dim3(pl.nblk), dim3(kBinThreads),
+                           lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, b,
+                           (const uint32_t*)(ws + pl.off_counts),
+                           (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),
+                           WANT_IDX ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr, d_pts,
+                           d_pw, zero_dropped);
+        return DPR_OK;
+    }
     const size_t lds = (size_t)tg.NT * 4;
     if (int rc = allow_big_lds(k_scatter<T, NI, NO, HAS_PW, WANT_IDX>, lds)) return rc;
     hipLaunchKernelGGL((k_scatter<T, NI, NO, HAS_PW, WANT_IDX>), dim3(pl.nblk), dim3(kBinThreads),
