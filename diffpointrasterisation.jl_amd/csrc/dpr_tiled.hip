@@ -1055,8 +1055,14 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
                                                                rot, trans, b, d_pts, d_pw,
                                                                zero_dropped);
     } else {
-        rc = launch_scatter<T, NI, NO, false, true>(st, gd, tg, pl, ws, P, points, pw, rot, trans,
-                                                    b, d_pts, d_pw, zero_dropped);
+        // without point weights the original index rides in the record for free; slot_of is
+        // only written when a pullback will consume the binning
+        rc = want_idx ? launch_scatter<T, NI, NO, false, true>(st, gd, tg, pl, ws, P, points, pw,
+                                                               rot, trans, b, d_pts, d_pw,
+                                                               zero_dropped)
+                      : launch_scatter<T, NI, NO, false, false>(st, gd, tg, pl, ws, P, points, pw,
+                                                                rot, trans, b, d_pts, d_pw,
+                                                                zero_dropped);
     }
     stage_mark(st);
     return rc;
