@@ -49,6 +49,8 @@ def synth_inputs(cfg, rank, device, order, dist_kind="gauss"):
     pts = (0.4 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
     if dist_kind == "uniform":  # diagnostic only (balanced tiles); not the headline workload
         pts = (1.1 * rng.random(size=(P, n_in), dtype=np.float32) - 0.55).astype(npdt)
+    if dist_kind == "tight":  # diagnostic only: a compact cluster, few heavily loaded tiles
+        pts = (0.1 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
     if order == "morton":
         pts = pts[morton_order(pts)]
     prng = np.random.default_rng(1 + rank)
@@ -144,7 +146,7 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled", "chunked"])
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="point order in memory: as generated, or pre-sorted (pose-independent)")
-    ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform"])
+    ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform", "tight"])
     ap.add_argument("--no-share-binning", action="store_true",
                     help="make the pullback redo the binning instead of reusing the forward's")
     ap.add_argument("--no-secondary", action="store_true",
@@ -295,7 +297,7 @@ def main():
         "value": round(value, 3), "unit": "M points/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
-        "config": {"workload": f"{args.config}: {P} 3-D points ({'0.4*N(0,I)' if args.dist == 'gauss' else 'uniform(-.55,.55)'}, {args.order} order) -> "
+        "config": {"workload": f"{args.config}: {P} 3-D points ({ {'gauss': '0.4*N(0,I)', 'uniform': 'uniform(-.55,.55)', 'tight': '0.1*N(0,I)'}[args.dist] }, {args.order} order) -> "
                                f"{'x'.join(map(str, grid))} {dt} grid, one pose per GPU, "
                                f"raster! + raster_pullback!",
                    "algo": {"raster": algo_f, "pullback": algo_b}, "pullback_reuses_forward_binning": share,

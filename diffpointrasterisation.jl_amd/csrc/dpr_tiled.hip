@@ -65,6 +65,7 @@ constexpr int kBinThreads = 1024;    // K1 / K3 block
 constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
 constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
 constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
+constexpr int kSplitBlocks = 8;      // k_halo_gather blocks per split tile
 
 template <int NO> struct TileGeom {
     int nt[NO];  // tiles per axis
@@ -236,19 +237,55 @@ __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts,
     }
 }
 
-// exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768)
-// Also emits tile_order[]: tile ids by decreasing record count (bucketed by log2), so the
-// heaviest tiles of the following one-block-per-tile kernels are dispatched first.
+// One unit of work of the tile kernels: a contiguous record range of one tile.  Tiles with
+// more than `cap` records are split into several items (parts) so that a clustered cloud
+// (few heavily loaded tiles) still fills the chip; the parts of a split tile leave their LDS
+// tiles in overflow slabs that k_halo_gather sums.
+struct alignas(16) WorkItem {
+    uint32_t tile, begin, end;
+    uint32_t part_nparts;  // part | nparts << 16
+};
+
+// exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768), and the
+// work list: items[] ordered by decreasing size (log2 buckets; the heaviest items are
+// dispatched first), n_items, and per tile the number of parts and its first overflow slab.
 __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ totals, int NT,
-                                                   uint32_t* __restrict__ tile_start,
-                                                   uint32_t* __restrict__ tile_order) {
-    __shared__ uint32_t wsum[16];
+                                                   uint32_t cap, uint32_t* __restrict__ tile_start,
+                                                   WorkItem* __restrict__ items,
+                                                   uint32_t* __restrict__ n_items,
+                                                   uint32_t* __restrict__ tile_parts,
+                                                   uint32_t* __restrict__ tile_slab,
+                                                   uint32_t* __restrict__ split_list,
+                                                   uint32_t* __restrict__ n_split) {
+    __shared__ uint32_t wsum[16], wslab[16];
+    __shared__ uint32_t s_nsplit;
+    if (threadIdx.x == 0) s_nsplit = 0;
     __shared__ uint32_t bcount[33], bstart[33];
     if (threadIdx.x < 33) bcount[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < NT; i += 1024) {
+    const int per = (NT + 1023) / 1024;
+    const int i0 = threadIdx.x * per;
+    uint32_t s = 0, slabs = 0;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
         const uint32_t c = totals[i];
-        atomicAdd(&bcount[c ? 32 - __clz(c) : 0], 1u);
+        s += c;
+        const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
+        const uint32_t sz = (c + k - 1) / k;  // records per part
+        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
+        if (k > 1) slabs += k;
+    }
+    uint32_t incl = s, incl_slab = slabs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64), v2 = __shfl_up(incl_slab, o, 64);
+        if ((threadIdx.x & 63) >= o) {
+            incl += v;
+            incl_slab += v2;
+        }
+    }
+    if ((threadIdx.x & 63) == 63) {
+        wsum[threadIdx.x >> 6] = incl;
+        wslab[threadIdx.x >> 6] = incl_slab;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -257,32 +294,41 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
             bstart[k] = start;
             start += bcount[k];
         }
+        *n_items = start;
+    }
+    uint32_t wbase = 0, sbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
+        wbase += wsum[w];
+        sbase += wslab[w];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NT; i += 1024) {
-        const uint32_t c = totals[i];
-        tile_order[atomicAdd(&bstart[c ? 32 - __clz(c) : 0], 1u)] = (uint32_t)i;
-    }
-    const int per = (NT + 1023) / 1024;
-    const int i0 = threadIdx.x * per;
-    uint32_t s = 0;
-    for (int i = i0; i < i0 + per && i < NT; ++i) s += totals[i];
-    uint32_t incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o, 64);
-        if ((threadIdx.x & 63) >= o) incl += v;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += wsum[w];
-    uint32_t run = wbase + incl - s;
+    uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
     for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = totals[i];
         tile_start[i] = run;
-        run += totals[i];
+        const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
+        const uint32_t sz = (c + k - 1) / k;
+        const int bucket = sz ? 32 - __clz(sz) : 0;
+        tile_parts[i] = k;
+        tile_slab[i] = slab_run;
+        for (uint32_t part = 0; part < k; ++part) {
+            WorkItem it;
+            it.tile = (uint32_t)i;
+            it.begin = run + part * sz;
+            it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
+            if (it.begin > run + c) it.begin = run + c;
+            it.part_nparts = part | (k << 16);
+            items[atomicAdd(&bstart[bucket], 1u)] = it;
+        }
+        if (k > 1) {
+            slab_run += k;
+            split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
+        }
+        run += c;
     }
     if (threadIdx.x == 1023) tile_start[NT] = wbase + incl;
+    __syncthreads();
+    if (threadIdx.x == 0) *n_split = s_nsplit;
 }
 
 // ------------------------------------------------------------------ K3: scatter
@@ -471,22 +517,25 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
 template <typename T, int NI, int NO, bool HAS_PW>
 __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
-    const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_order,
-    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
-    const T* __restrict__ bg, int64_t b, T* __restrict__ out, T* __restrict__ halo, int blocked) {
+    const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
+    const uint32_t* __restrict__ tile_slab, const T* __restrict__ rot,
+    const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b,
+    T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NV = tile_voxels<NO>();
     __shared__ double acc[NVH];
+    if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
+    const WorkItem item = items[blockIdx.x];
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
-    const int tile = (int)tile_order[blockIdx.x];
+    const int tile = (int)item.tile;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     // Record assignment: strided (lane-adjacent records, coalesced) or blocked (each thread
     // owns a contiguous run, so lanes are far apart in the list: with spatially sorted input
     // lane-adjacent records hit the same voxel and same-address LDS atomics serialise).
-    uint32_t r1 = tile_start[tile + 1];
-    uint32_t r = tile_start[tile];
+    uint32_t r1 = item.end;
+    uint32_t r = item.begin;
     uint32_t step = kSplatThreads;
     if (blocked) {
         const uint32_t per = (r1 - r + kSplatThreads - 1) / kSplatThreads;
@@ -538,6 +587,13 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         }
     }
     __syncthreads();
+    if ((item.part_nparts >> 16) > 1) {
+        // part of a split tile: the whole LDS tile goes to this part's overflow slab;
+        // k_halo_gather sums the parts
+        T* slab = ovf + (size_t)(tile_slab[tile] + (item.part_nparts & 0xffffu)) * NVH;
+        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)acc[i];
+        return;
+    }
     // owned voxels: out = background + acc   (plain stores, rows of TX contiguous values)
     const double bgv = bg ? (double)bg[b] : 0.0;
     T* o = out + b * gd.G;
@@ -612,17 +668,59 @@ template <int NO> __device__ __forceinline__ void low_face_coords(int i, int (&l
 
 // One block per tile; threads walk the tile's low-face voxels and add what the lower
 // neighbours accumulated for them.  Gather form: each voxel has exactly one writer.
+// Split tiles (tile_parts > 1): their parts left whole LDS tiles in overflow slabs; the block
+// then walks ALL owned voxels (out = background + sum of parts) and neighbours read a split
+// tile's halo as the sum over its slabs.
 template <typename T, int NO>
 __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<NO> tg,
-                                                     const T* __restrict__ halo, int64_t b,
+                                                     const T* __restrict__ halo,
+                                                     const T* __restrict__ ovf,
+                                                     const uint32_t* __restrict__ tile_parts,
+                                                     const uint32_t* __restrict__ tile_slab,
+                                                     const uint32_t* __restrict__ split_list,
+                                                     const uint32_t* __restrict__ n_split,
+                                                     const T* __restrict__ bg, int64_t b,
                                                      T* __restrict__ out) {
-    const int tile = blockIdx.x;
+    constexpr int NV = tile_voxels<NO>();
+    constexpr int NVH = tile_voxels_halo<NO>();
+    constexpr int CH = kSplitBlocks;  // blocks sharing the owned voxels of one split tile
+    // blocks [0, NT): the low faces of an unsplit tile; blocks NT + s*CH + c: every CH-th
+    // 256-voxel chunk of the s-th split tile (all of its owned voxels)
+    int tile, i_begin, i_end;
+    bool split;
+    const bool any_split = *n_split != 0;  // uniform; the common case has no split tile
+    if ((int)blockIdx.x < tg.NT) {
+        tile = blockIdx.x;
+        split = false;
+        if (any_split && tile_parts[tile] > 1) return;  // handled by its chunk blocks
+        i_begin = 0;
+        i_end = low_face_count<NO>();
+    } else {
+        const int sidx = ((int)blockIdx.x - tg.NT) / CH, c = ((int)blockIdx.x - tg.NT) % CH;
+        if (!any_split || sidx >= (int)*n_split) return;
+        tile = (int)split_list[sidx];
+        split = true;
+        i_begin = c * 256;
+        i_end = NV;
+    }
+    const int i_step = split ? 256 * CH : 256;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     T* o = out + b * gd.G;
-    for (int i = threadIdx.x; i < low_face_count<NO>(); i += 256) {
+    const uint32_t my_parts = split ? tile_parts[tile] : 1u;
+    const double bgv = bg ? (double)bg[b] : 0.0;
+    for (int i = i_begin + threadIdx.x; i < i_end; i += i_step) {
         int l[NO];
-        low_face_coords<NO>(i, l);
+        if (split) {
+            int rem = i;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                l[d] = rem % TileDims<NO>::T[d];
+                rem /= TileDims<NO>::T[d];
+            }
+        } else {
+            low_face_coords<NO>(i, l);
+        }
         int off = 0, stride = 1;
         bool ok = true, low = false;
 #pragma unroll
@@ -633,24 +731,40 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
             off += gcoord * stride;
             stride *= gd.n[d];
         }
-        if (!ok || !low) continue;
+        if (!ok || (!low && !split)) continue;
         double add = 0.0;
+        if (low) {
 #pragma unroll
-        for (int m = 1; m < (1 << NO); ++m) {
-            bool valid = true;
-            int h[NO];
-            int src = 0, tstride = 1;
+            for (int m = 1; m < (1 << NO); ++m) {
+                bool valid = true;
+                int h[NO];
+                int src = 0, tstride = 1;
 #pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                const bool in_m = (m >> d) & 1;
-                valid = valid && (!in_m || (l[d] == 0 && tc[d] > 0));
-                h[d] = in_m ? TileDims<NO>::T[d] : l[d];
-                src += (tc[d] - (in_m ? 1 : 0)) * tstride;
-                tstride *= tg.nt[d];
+                for (int d = 0; d < NO; ++d) {
+                    const bool in_m = (m >> d) & 1;
+                    valid = valid && (!in_m || (l[d] == 0 && tc[d] > 0));
+                    h[d] = in_m ? TileDims<NO>::T[d] : l[d];
+                    src += (tc[d] - (in_m ? 1 : 0)) * tstride;
+                    tstride *= tg.nt[d];
+                }
+                if (!valid) continue;
+                const uint32_t sp = any_split ? tile_parts[src] : 1u;
+                if (sp > 1) {
+                    const T* slab = ovf + (size_t)tile_slab[src] * NVH + lds_index<NO>(h);
+                    for (uint32_t q = 0; q < sp; ++q) add += (double)slab[(size_t)q * NVH];
+                } else {
+                    add += (double)halo[(size_t)src * halo_count<NO>() + halo_index<NO>(h)];
+                }
             }
-            if (valid) add += (double)halo[(size_t)src * halo_count<NO>() + halo_index<NO>(h)];
         }
-        o[off] = (T)((double)o[off] + add);
+        if (split) {
+            const T* slab = ovf + (size_t)tile_slab[tile] * NVH + lds_index<NO>(l);
+            double own = bgv;
+            for (uint32_t q = 0; q < my_parts; ++q) own += (double)slab[(size_t)q * NVH];
+            o[off] = (T)(own + add);
+        } else {
+            o[off] = (T)((double)o[off] + add);
+        }
     }
 }
 
@@ -662,21 +776,23 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
 template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM>
 __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, int64_t P,
-    const uint32_t* __restrict__ rec_idx, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ tile_order, const T* __restrict__ g, const T* __restrict__ rot, const T* __restrict__ trans,
-    const T* __restrict__ ow, int64_t b, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
-    double* __restrict__ partials) {
+    const uint32_t* __restrict__ rec_idx, const WorkItem* __restrict__ items,
+    const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
+    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b,
+    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NVAL = NO * NI + NO + 2;  // dR | dt | d out_weight | d background
     constexpr int NW = kGatherThreads / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
-    const int tile = (int)tile_order[blockIdx.x];
+    if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
+    const WorkItem item = items[blockIdx.x];
+    const int tile = (int)item.tile;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const T* gb = g + b * gd.G;
-    const uint32_t r1 = tile_start[tile + 1];
-    uint32_t r = tile_start[tile] + threadIdx.x;
+    const uint32_t r1 = item.end;
+    uint32_t r = item.begin + threadIdx.x;
     Rec4<T> nxt;
     uint32_t nxt_idx = 0;
     if (r < r1) {
@@ -718,7 +834,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         for (int k = 0; k < IT; ++k) {
             const int i = threadIdx.x + k * kGatherThreads;
             if (i < NVH) tile_g[i] = v[k];
-            if (own[k]) bg_sum += (double)v[k];
+            if (own[k] && (item.part_nparts & 0xffffu) == 0) bg_sum += (double)v[k];
         }
     }
     __syncthreads();
@@ -834,7 +950,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * tg.NT + tile] = s;
+        partials[(size_t)threadIdx.x * max_items + blockIdx.x] = s;
     }
 }
 
@@ -863,15 +979,18 @@ __global__ __launch_bounds__(256) void k_unpermute(int64_t P, const Rec4<T>* __r
 // ------------------------------------------------------------------ pullback K5
 // partials[NVAL][NT] (f64) -> the per-pose outputs of pose b.  One block per scalar.
 template <typename T, int NI, int NO>
-__global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__ partials, int NT,
-                                                      int64_t b, T* __restrict__ ds_drotation,
+__global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__ partials,
+                                                      const uint32_t* __restrict__ n_items,
+                                                      int max_items, int64_t b,
+                                                      T* __restrict__ ds_drotation,
                                                       T* __restrict__ ds_dtranslation,
                                                       T* __restrict__ ds_dbackground,
                                                       T* __restrict__ ds_dout_weight) {
     __shared__ double wsum[16];
     const int k = blockIdx.x;
     double s = 0.0;
-    for (int t = threadIdx.x; t < NT; t += 1024) s += partials[(size_t)k * NT + t];
+    const int n = (int)*n_items;
+    for (int t = threadIdx.x; t < n; t += 1024) s += partials[(size_t)k * max_items + t];
     s = wave_sum<double>(s);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -901,11 +1020,15 @@ static int env_int(const char* name, int dflt) {
 
 // Workspace layout (identical for raster and pullback so that a pullback can reuse the
 // binning a raster call left behind, DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING):
-//   counts table | totals | tile_start | tile_order | records | indices | slot_of | aux (halo / partials)
+//   counts table | totals | tile_start | work items, n_items, tile_parts, tile_slab | records | indices | slot_of | aux (halo / partials)
 struct Plan {
     int nblk;
     int64_t chunk;
-    size_t off_counts, off_totals, off_tile_start, off_order, off_rec, off_idx, off_slot, off_aux, total;
+    uint32_t cap;    // records per work item above which a tile is split
+    int max_items;   // NT + worst-case number of extra parts
+    int max_slabs;   // overflow slabs (parts of split tiles)
+    size_t off_counts, off_totals, off_tile_start, off_items, off_nitems, off_tparts, off_tslab,
+        off_split, off_rec, off_idx, off_slot, off_aux, total;
 };
 
 static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
@@ -927,8 +1050,24 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     o += align_up((size_t)NT * 4);
     pl.off_tile_start = o;
     o += align_up((size_t)(NT + 1) * 4);
-    pl.off_order = o;
+    // split threshold: ~P/256 records (even a fully clustered cloud then yields >= 256 items,
+    // one per CU, while the headline Gaussian cloud has no tile above it), at least 4096; a
+    // split tile's parts hold more than cap/2 records each
+    int64_t cap = P / 256;
+    if (cap < 4096) cap = 4096;
+    pl.cap = (uint32_t)cap;
+    pl.max_slabs = (int)(2 * ((P + cap - 1) / cap) + 1);
+    pl.max_items = NT + pl.max_slabs;
+    pl.off_items = o;
+    o += align_up((size_t)pl.max_items * sizeof(WorkItem));
+    pl.off_nitems = o;
+    o += align_up(4);
+    pl.off_tparts = o;
     o += align_up((size_t)NT * 4);
+    pl.off_tslab = o;
+    o += align_up((size_t)NT * 4);
+    pl.off_split = o;  // [0] = n_split, [1..] = split tile ids (at most max_slabs / 2)
+    o += align_up((size_t)(pl.max_slabs / 2 + 2) * 4);
     pl.off_rec = o;
     o += align_up((size_t)(P + 1) * 4 * elem);  // + spare slot for rejected points
     pl.off_idx = o;
@@ -936,8 +1075,11 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
     pl.off_aux = o;
-    const size_t halo = (size_t)NT * ((n_out == 3) ? halo_count<3>() : halo_count<2>()) * elem;
-    const size_t partials = (size_t)NT * 16 * 8;
+    // aux: forward = halo buffer | overflow slabs ; pullback = per-item partials
+    const size_t nvh = (n_out == 3) ? tile_voxels_halo<3>() : tile_voxels_halo<2>();
+    const size_t halo = align_up((size_t)NT * ((n_out == 3) ? halo_count<3>() : halo_count<2>()) * elem) +
+                        align_up((size_t)pl.max_slabs * nvh * elem);
+    const size_t partials = (size_t)pl.max_items * 16 * 8;
     o += align_up(halo > partials ? halo : partials);
     pl.total = o;
     return pl;
@@ -1043,8 +1185,10 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     stage_mark(st);
     hipLaunchKernelGGL(k_colscan, dim3((tg.NT + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st, counts, pl.nblk,
                        tg.NT, totals);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, tile_start,
-                       (uint32_t*)(ws + pl.off_order));
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, pl.cap, tile_start,
+                       (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
+                       (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
+                       (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split));
     stage_mark(st);
     int rc;
     if (pw) {
@@ -1096,26 +1240,30 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     T* halo = (T*)(ws + pl.off_aux);
+    T* ovf = (T*)(ws + pl.off_aux + align_up((size_t)tg.NT * halo_count<NO>() * sizeof(T)));
     const int blocked = env_int("DPR_SPLAT_BLOCKED", 1);
     for (int64_t b = 0; b < B; ++b) {
         if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, keep,
                                            (T*)nullptr, (T*)nullptr, 0))
             return rc;
-        if (pw)
-            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, true>), dim3(tg.NT), dim3(kSplatThreads), 0,
-                               st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
-                               (const uint32_t*)(ws + pl.off_tile_start),
-                               (const uint32_t*)(ws + pl.off_order), rot, trans, ow, bg, b, out,
-                               halo, blocked);
-        else
-            hipLaunchKernelGGL((k_tile_splat<T, NI, NO, false>), dim3(tg.NT), dim3(kSplatThreads),
-                               0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),
-                               (const uint32_t*)(ws + pl.off_tile_start),
-                               (const uint32_t*)(ws + pl.off_order), rot, trans, ow, bg, b, out,
-                               halo, blocked);
+#define DPR_LAUNCH_SPLAT(HAS_PW)                                                                 \
+    hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW>), dim3(pl.max_items),                   \
+                       dim3(kSplatThreads), 0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),   \
+                       (const WorkItem*)(ws + pl.off_items),                                    \
+                       (const uint32_t*)(ws + pl.off_nitems),                                   \
+                       (const uint32_t*)(ws + pl.off_tslab), rot, trans, ow, bg, b, out, halo,  \
+                       ovf, blocked)
+        if (pw) DPR_LAUNCH_SPLAT(true);
+        else DPR_LAUNCH_SPLAT(false);
+#undef DPR_LAUNCH_SPLAT
         stage_mark(st);
-        hipLaunchKernelGGL((k_halo_gather<T, NO>), dim3(tg.NT), dim3(256), 0, st, gd, tg,
-                           (const T*)halo, b, out);
+        hipLaunchKernelGGL((k_halo_gather<T, NO>),
+                           dim3(tg.NT + (pl.max_slabs / 2) * kSplitBlocks),
+                           dim3(256), 0, st, gd, tg, (const T*)halo, (const T*)ovf,
+                           (const uint32_t*)(ws + pl.off_tparts),
+                           (const uint32_t*)(ws + pl.off_tslab),
+                           (const uint32_t*)(ws + pl.off_split) + 1,
+                           (const uint32_t*)(ws + pl.off_split), bg, b, out);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());
@@ -1163,12 +1311,11 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                                                   true, d_pts, d_pw, (b == 0 && !unperm) ? 1 : 0))
             return rc;
 #define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                                                   \
-    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(tg.NT),             \
+    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(pl.max_items),             \
                        dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,     \
-                       (const uint32_t*)(ws + pl.off_idx),                                      \
-                       (const uint32_t*)(ws + pl.off_tile_start),                               \
-                       (const uint32_t*)(ws + pl.off_order), g, rot, trans, ow, b, d_pts, d_pw, \
-                       partials)
+                       (const uint32_t*)(ws + pl.off_idx), (const WorkItem*)(ws + pl.off_items), \
+                       (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,  \
+                       b, d_pts, d_pw, partials)
         if (unperm) {
             if (pw) DPR_LAUNCH_GATHER(true, true, true);
             else DPR_LAUNCH_GATHER(false, true, true);
@@ -1197,7 +1344,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
 #undef DPR_LAUNCH_GATHER
         stage_mark(st);
         hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(NVAL), dim3(1024), 0, st,
-                           (const double*)partials, tg.NT, b, d_rot, d_trans, d_bg, d_ow);
+                           (const double*)partials, (const uint32_t*)(ws + pl.off_nitems),
+                           pl.max_items, b, d_rot, d_trans, d_bg, d_ow);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());

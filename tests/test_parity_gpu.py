@@ -297,6 +297,32 @@ def test_chunked_on_spatially_sorted_points(oracle, dev, npdt, tdt, n_in, n_out,
     _compare(*_run_both(oracle, dev, d, npdt, "chunked"), npdt)
 
 
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 70), (3, 2, 90), (2, 2, 64)])
+def test_heavy_tiles_are_split(oracle, dev, npdt, tdt, n_in, n_out, grid_n):
+    """A tightly clustered cloud puts far more than the split threshold (4096 records) into a
+    handful of tiles: the tile kernels then run several work items per tile and the parts are
+    combined from overflow slabs.  Forward, pullback and the binning-reuse
+    pairing against the oracle."""
+    d = D.make(n_points=40_000, n_in=n_in, n_out=n_out, batch=2, grid_n=grid_n, seed=27, dtype=npdt)
+    d.points = (d.points * npdt(0.12)).astype(npdt)  # ~ +-0.15: a few tiles hold everything
+    d.points[::50] *= npdt(8.0)                      # plus some stragglers elsewhere
+    _compare(*_run_both(oracle, dev, d, npdt, "tiled"), npdt)
+    ws = torch.empty(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 1, n_in, tdt, "tiled"),
+                     dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, 1, tdt, dev)
+    args = (T(d.points, dev), T(d.rotations[:1], dev), T(d.translations[:1], dev),
+            T(d.backgrounds[:1], dev), T(d.weights[:1], dev), T(d.point_weights, dev))
+    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=True)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout[..., :1], dev), *args, algo="tiled",
+                                  workspace=ws, reuse_binning=True)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations[:1], d.translations[:1],
+                            d.backgrounds[:1], d.weights[:1], d.point_weights, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout[..., :1], d.points, d.rotations[:1],
+                                    d.translations[:1], d.weights[:1], d.point_weights, dtype=npdt)
+    _compare(ref_out, ref_pb, out, pb, npdt)
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
