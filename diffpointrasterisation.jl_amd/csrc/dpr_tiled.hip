@@ -1,28 +1,34 @@
 // DPR_ALGO_TILED: per-pose binning of the points into voxel tiles, then one workgroup per
-// tile that keeps the tile in LDS.  No global float atomics anywhere on this path.
+// work item (a tile, or a part of a heavily loaded tile) that keeps the tile in LDS.
+// No global float atomics anywhere on this path.  DESIGN.md 4.2 has the table of stages.
 //
 // Per pose b (sequential launches on the caller's stream, workspace reused):
-//   K1 k_count    each block histograms its slice of the points by PRIMARY tile (the tile
-//                 holding max(ref,0)) in LDS and stores one row of the counts table
-//   K2 k_colscan  column-wise exclusive prefix of the table (per tile over blocks) + totals
-//      k_tilescan exclusive scan of the tile totals -> tile_start[]
-//   K3 k_scatter  each block re-reads its slice and writes one record {p, point_weight}
-//                 (+ original index for the pullback) per in-range point at its final
-//                 position (LDS cursors seeded from the table: no global atomics, exact
-//                 capacity P, placement deterministic per block)
-//   forward  K4 k_tile_splat   LDS tile (+1 upper halo) of f64 accumulators, ds_add_f64;
-//                              owned voxels leave with plain coalesced stores fused with the
-//                              background; the halo goes to a compact per-tile halo buffer
-//            K5 k_halo_gather  every low-face voxel adds the (<= 2^N-1) neighbour halos
-//   pullback K4 k_tile_gather  ds_dout tile (+halo) staged in LDS, per-point gathers from
-//                              LDS, ds_dpoints/ds_dpoint_weight written by the single owner
-//                              of each point, per-tile partial sums of the per-pose scalars
-//            K5 k_pose_reduce  sums the per-tile partials (f64) into ds_drotation etc.
+//   count    k_count        each block histograms its slice of the points by PRIMARY tile (the
+//                           tile holding max(ref,0)) in LDS -> one row of the counts table
+//   scan     k_colscan      column-wise exclusive prefix of the table + tile totals
+//            k_tilescan     tile offsets; work list (heavy tiles split, heaviest first)
+//   scatter  k_scatter_wc   LDS cursors seeded from the table -> exact, atomic-free placement
+//            (k_scatter)    of one 16/32-byte record per in-range point; sub-chunks are ordered
+//                           by tile in LDS first so stores cover contiguous runs
+//   forward  k_tile_splat   LDS tile (+1 upper halo) of f64 accumulators, ds_add_f64; owned
+//                           voxels leave with plain stores fused with the background, the halo
+//                           goes to a compact buffer (parts of split tiles: overflow slabs)
+//            k_halo_gather  low-face voxels add the (<= 2^N-1) neighbour halos; split tiles are
+//                           assembled from their slabs
+//   pullback k_tile_gather  ds_dout tile (+halo) staged in LDS, per-point gathers from LDS, the
+//                           gradient overwrites the record in place; per-item partial sums
+//            k_unpermute    gradient records back to the original point order
+//            k_pose_reduce  per-item partials (f64) -> ds_drotation, ds_dtranslation, ...
 //
 // Why f64 accumulators for fp32 data: on gfx950 ds_add_f32 retires ~1 lane per 3 cycles
 // (193 cycles per wave-instruction, measured), while ds_add_f64 takes ~26 cycles per
-// wave-instruction (profiles/r01_microbench.txt).  It also makes fp32 results practically
-// independent of the accumulation order.
+// wave-instruction (profiles/r01_microbench_lds_atomics.txt).  It also makes fp32 results
+// practically independent of the accumulation order.
+//
+// Experiment knobs (environment, compiled-in defaults are the measured best):
+//   DPR_SCATTER_WC=0     plain scatter instead of the write-combining one
+//   DPR_SPLAT_BLOCKED=0  lane-adjacent (strided) instead of blocked record assignment
+//   DPR_BWD_UNPERMUTE=0  owner threads store ds_dpoints directly instead of un-permuting
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
