@@ -518,3 +518,52 @@ def test_sort_points_is_a_morton_permutation(oracle, dev, npdt, tdt, n_in):
     back = torch.empty_like(pb.points)
     back.index_copy_(0, perm.long(), pb.points)
     assert_close(back, pa.points.cpu().numpy(), tol(npdt, "points"), "gradients through perm")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_runs_on_the_callers_stream_and_in_hip_graphs(oracle, dev, algo):
+    """The library only enqueues on the stream it is given (no sync, no allocation, no global
+    state): (i) results on a side stream match, (ii) forward + pullback can be captured into
+    a HIP graph and replayed on new input contents."""
+    d = D.make(n_points=20_000, n_in=3, n_out=3, batch=1, grid_n=48, seed=33, dtype=np.float32)
+    pts = T(d.points, dev)
+    R, t = T(d.rotations, dev), T(d.translations, dev)
+    g = grid_to_dev(d.ds_dout, dev)
+    out = dpr_amd.empty_grid(d.grid, 1, torch.float32, dev)
+    ws = torch.empty(max(16, dpr_amd.workspace_bytes("pullback", d.grid, d.n_points, 1, 3,
+                                                     torch.float32, algo)),
+                     dtype=torch.uint8, device=dev)
+    d_pts = torch.empty(d.n_points, 3, device=dev)
+    d_pw = torch.empty(d.n_points, device=dev)
+
+    def run():
+        dpr_amd.raster_(out, pts, R, t, algo=algo, workspace=ws)
+        return dpr_amd.raster_pullback_(g, pts, R, t, algo=algo, workspace=ws, ds_dpoints=d_pts,
+                                        ds_dpoint_weight=d_pw)
+
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, dtype=np.float32)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations,
+                                    dtype=np.float32)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        pb = run()
+    side.synchronize()
+    _compare(ref_out, ref_pb, out, pb, np.float32)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        run()  # warm-up outside capture
+    side.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        pb = run()
+    # new contents in the same buffers, then replay
+    pts2 = d.points[::-1].copy() * np.float32(0.9)
+    pts.copy_(T(pts2, dev))
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    ref_out2 = oracle.raster(d.grid, pts2, d.rotations, d.translations, dtype=np.float32)
+    ref_pb2 = oracle.raster_pullback(d.ds_dout, pts2, d.rotations, d.translations,
+                                     dtype=np.float32)
+    _compare(ref_out2, ref_pb2, out, pb, np.float32)
