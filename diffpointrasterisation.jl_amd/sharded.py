@@ -78,3 +78,50 @@ def raster_pullback_sharded_(ds_dout_local, points, rotation_local, translation_
         dist.all_reduce(fused_buffer, op=dist.ReduceOp.SUM, group=group)
     return PullbackResult(d_pts, res.rotation, res.translation, res.background, res.out_weight,
                           d_pw)
+
+
+# ---------------------------------------------------------------------------------------
+# Point sharding: the alternative for single-pose (or few-pose) problems, where pose sharding
+# has nothing to split.  Rank r owns a contiguous block of the POINTS; every
+# rank holds all poses.  Forward: each rank splats its points into a full grid (background
+# only on rank 0) and ONE all-reduce(sum) of the grid assembles `out` (67 MB at C3).
+# Pullback: ds_dout is replicated, point gradients stay local to the owning rank (no
+# communication), the per-pose sums (rotation, translation, out_weight: N_out*(N_in+1)+1
+# scalars per pose) are all-reduced; the background gradient is the same on every rank.
+def raster_point_sharded(grid_size, points_local, rotation, translation, background=None,
+                         out_weight=None, point_weight_local=None, *, group=None,
+                         local_raster: Callable = raster, **kw):
+    """`points_local` / `point_weight_local` are this rank's block of the cloud
+    (`shard_range(P, rank, world)`); the pose arguments are global.  Returns the full `out`
+    (identical on every rank)."""
+    dist = _dist()
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bg = background if rank == 0 else None  # the background must be counted once
+    out = local_raster(grid_size, points_local, rotation, translation, bg, out_weight,
+                       point_weight_local, **kw)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        flat = out.permute(*reversed(range(out.ndim)))  # the contiguous buffer behind the view
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def raster_pullback_point_sharded_(ds_dout, points_local, rotation, translation, background=None,
+                                   out_weight=None, point_weight_local=None, *, group=None,
+                                   local_pullback: Callable = raster_pullback_,
+                                   **kw) -> PullbackResult:
+    """Pullback for this rank's block of the points.  `points` / `point_weight` of the result
+    are LOCAL (gradients of the local block); rotation / translation / out_weight are summed
+    over ranks; background is already global."""
+    dist = _dist()
+    res = local_pullback(ds_dout, points_local, rotation, translation, background, out_weight,
+                         point_weight_local, **kw)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        rot, tr, ow = res.rotation, res.translation, res.out_weight
+        fused = torch.cat([rot.reshape(-1), tr.reshape(-1), ow.reshape(-1)])
+        dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=group)
+        n1, n2 = rot.numel(), tr.numel()
+        rot = fused[:n1].reshape(rot.shape)
+        tr = fused[n1:n1 + n2].reshape(tr.shape)
+        ow = fused[n1 + n2:].reshape(ow.shape)
+        res = PullbackResult(res.points, rot, tr, res.background, ow, res.point_weight)
+    return res
