@@ -63,7 +63,7 @@ template <> struct TileDims<2> {
 constexpr int kMaxTiles = 32768;     // LDS cursor table: 4 B per tile, <= 128 KiB
 constexpr int kBinThreads = 1024;    // K1 / K3 block
 #ifndef DPR_SPLAT_THREADS
-#define DPR_SPLAT_THREADS DPR_TILE_THREADS
+#define DPR_SPLAT_THREADS 1024
 #endif
 #ifndef DPR_GATHER_THREADS
 #define DPR_GATHER_THREADS 256
@@ -136,6 +136,16 @@ template <int NO> __device__ __forceinline__ int lds_index(const int (&l)[NO]) {
         stride *= TileDims<NO>::T[d] + 1;
     }
     return idx;
+}
+
+// offset of neighbour s (bit d = +1 along axis d) inside the (T+1)^N LDS tile
+template <int NO> __host__ __device__ constexpr int nbr_lds_offset(int s) {
+    int off = 0, stride = 1;
+    for (int d = 0; d < NO; ++d) {
+        if ((s >> d) & 1) off += stride;
+        stride *= TileDims<NO>::T[d] + 1;
+    }
+    return off;
 }
 
 // Compact halo layout of one tile.  h has at least one coordinate equal to T[d].
@@ -551,45 +561,82 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     } else {
         r += threadIdx.x;
     }
-    Rec4<T> nxt;
-    if (r < r1) nxt = rec[r];
+    // kPF records per thread are kept in flight: with one load per iteration the heaviest
+    // item's per-thread chain (records / threads iterations x memory latency) sets the
+    // kernel time, whatever the LDS atomic rate.
+#ifndef DPR_PF
+#define DPR_PF 2
+#endif
+    constexpr int kPF = DPR_PF;
+    Rec4<T> nxt[kPF];
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) {
+        const uint32_t ru = r + u * step;
+        nxt[u] = rec[ru < r1 ? ru : (r1 > item.begin ? r1 - 1 : item.begin)];
+    }
     __syncthreads();
     while (r < r1) {
-        const Rec4<T> rc = nxt;
-        r += step;
-        nxt = rec[r < r1 ? r : r1 - 1];  // clamped prefetch (branch-free loop body)
-        T pt[NI];
+        Rec4<T> cur[kPF];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
-        const T w = HAS_PW ? ps.ow * rc.v[3] : ps.ow * T(1);  // src/raster.jl:52
-        int ref0[NO];
-        T dlo[NO];
-        ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
-        // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
-        // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
-        // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
-        int lb[NO];
-        bool low_ok[NO];
+        for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
+        const uint32_t r_cur = r;
+        r += kPF * step;
 #pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            lb[d] = ref0[d] - x0[d];
-            // records of this tile have lb in [-1, T-1]; the clamp only matters if the caller
-            // breaks the REUSE_BINNING contract (stale workspace) and keeps LDS indices legal
-            lb[d] = lb[d] < -1 ? -1 : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
-            low_ok[d] = lb[d] >= 0;
+        for (int u = 0; u < kPF; ++u) {
+            const uint32_t ru = r + u * step;
+            nxt[u] = rec[ru < r1 ? ru : r1 - 1];  // clamped prefetch (branch-free loop body)
         }
 #pragma unroll
-        for (int s = 0; s < (1 << NO); ++s) {
-            int l[NO];
-            bool ok = true;
+        for (int u = 0; u < kPF; ++u) {
+            const Rec4<T> rc = cur[u];
+            const bool active = r_cur + u * step < r1;
+            T pt[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
+            const T w = HAS_PW ? ps.ow * rc.v[3] : ps.ow * T(1);  // src/raster.jl:52
+            int ref0[NO];
+            T dlo[NO];
+            ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
+            // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
+            // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
+            // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
+            int lb[NO];
+            bool low_ok[NO];
 #pragma unroll
             for (int d = 0; d < NO; ++d) {
-                const int sd = (s >> d) & 1;
-                ok = ok && (sd || low_ok[d]);
-                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+                lb[d] = ref0[d] - x0[d];
+                // records of this tile have lb in [-1, T-1]; the clamp only matters if the
+                // caller breaks the REUSE_BINNING contract (stale workspace): LDS indices
+                // stay legal
+                lb[d] = lb[d] < -1 ? -1
+                                   : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
+                low_ok[d] = lb[d] >= 0;
             }
-            const T v = voxel_weight<T, NO>(dlo, s, w);
-            atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
+            bool interior = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+            if (active && interior) {
+                // common case: one base address, the 2^N neighbours are compile-time offsets
+                // (they fold into the ds_add offset field)
+                double* base = &acc[lds_index<NO>(lb)];
+#pragma unroll
+                for (int s = 0; s < (1 << NO); ++s)
+                    atomicAdd(base + nbr_lds_offset<NO>(s), (double)voxel_weight<T, NO>(dlo, s, w));
+            } else if (active) {  // a lower neighbour at -1: only at the low faces of the grid
+#pragma unroll
+                for (int s = 0; s < (1 << NO); ++s) {
+                    int l[NO];
+                    bool ok = true;
+#pragma unroll
+                    for (int d = 0; d < NO; ++d) {
+                        const int sd = (s >> d) & 1;
+                        ok = ok && (sd || low_ok[d]);
+                        l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+                    }
+                    const T v = voxel_weight<T, NO>(dlo, s, w);
+                    atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
+                }
+            }
         }
     }
     __syncthreads();
@@ -881,18 +928,28 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
             low_ok[d] = lb[d] >= 0;
         }
         T gv[1 << NO];
+        bool interior = true;
 #pragma unroll
-        for (int s = 0; s < (1 << NO); ++s) {
-            int l[NO];
-            bool ok = true;
+        for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+        if (interior) {
+            // common case: one base address, neighbours at compile-time offsets
+            const T* base = &tile_g[lds_index<NO>(lb)];
 #pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                const int sd = (s >> d) & 1;
-                ok = ok && (sd || low_ok[d]);
-                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+            for (int s = 0; s < (1 << NO); ++s) gv[s] = base[nbr_lds_offset<NO>(s)];
+        } else {
+#pragma unroll
+            for (int s = 0; s < (1 << NO); ++s) {
+                int l[NO];
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < NO; ++d) {
+                    const int sd = (s >> d) & 1;
+                    ok = ok && (sd || low_ok[d]);
+                    l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+                }
+                const T gi = tile_g[lds_index<NO>(l)];
+                gv[s] = ok ? gi : T(0);
             }
-            const T gi = tile_g[lds_index<NO>(l)];
-            gv[s] = ok ? gi : T(0);
         }
         T scaled[NO], dow_part = T(0), dpw_part = T(0);
         {
@@ -1059,8 +1116,14 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     // split threshold: ~P/256 records (even a fully clustered cloud then yields >= 256 items,
     // one per CU, while the headline Gaussian cloud has no tile above it), at least 4096; a
     // split tile's parts hold more than cap/2 records each
-    int64_t cap = P / 256;
+    int64_t cap = P / env_int("DPR_CAP3D_DIV", 256);
     if (cap < 4096) cap = 4096;
+    if (n_out == 2) {
+        // 2-D grids have few tiles (256 at 512^2) with cheap LDS tiles (8.7 KB): split
+        // earlier so that a dense projection still gives the chip ~2048 items
+        cap = env_int("DPR_CAP2D_DIV", 2048) > 0 ? P / env_int("DPR_CAP2D_DIV", 2048) : cap;
+        if (cap < 2048) cap = 2048;
+    }
     pl.cap = (uint32_t)cap;
     pl.max_slabs = (int)(2 * ((P + cap - 1) / cap) + 1);
     pl.max_items = NT + pl.max_slabs;
