@@ -567,3 +567,33 @@ def test_runs_on_the_callers_stream_and_in_hip_graphs(oracle, dev, algo):
     ref_pb2 = oracle.raster_pullback(d.ds_dout, pts2, d.rotations, d.translations,
                                      dtype=np.float32)
     _compare(ref_out2, ref_pb2, out, pb, np.float32)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_against_oracle(oracle, dev, seed):
+    """Seeded fuzz over shapes the fixed tests do not hit: random point counts (incl. sizes
+    around the block / chunk / sub-chunk boundaries), anisotropic grids with tile remainders,
+    batch sizes, optional arguments, dtypes and algorithms; partly out-of-range clouds."""
+    rng = np.random.default_rng(1000 + seed)
+    n_in, n_out = SHAPES[rng.integers(len(SHAPES))]
+    npdt, tdt = DTYPES[rng.integers(2)]
+    algo = ALGOS[rng.integers(len(ALGOS))]
+    P = int(rng.choice([1, 63, 64, 65, 255, 257, 1023, 1025, 4095, 4097, 8193, 20481, 50_000]))
+    B = int(rng.integers(1, 5))
+    grid = tuple(int(g) for g in rng.integers(3, 150 if n_out == 2 else 90, size=n_out))
+    spread = float(rng.choice([0.05, 0.4, 0.9]))
+    pts = (spread * rng.normal(size=(P, n_in))).astype(npdt)
+    R = D.random_rotations(rng, B, n_in)[:, :n_out, :].astype(npdt)
+    t = (0.2 * rng.normal(size=(B, n_out))).astype(npdt)
+    use = rng.integers(0, 2, size=3).astype(bool)
+    bg = rng.normal(size=B).astype(npdt) if use[0] else None
+    ow = (rng.uniform(0.5, 3, size=B)).astype(npdt) if use[1] else None
+    pw = rng.uniform(0.1, 2, size=P).astype(npdt) if use[2] else None
+    g = np.asfortranarray(rng.normal(size=grid + (B,)).astype(npdt))
+    ref_out = oracle.raster(grid, pts, R, t, bg, ow, pw, dtype=npdt)
+    ref_pb = oracle.raster_pullback(g, pts, R, t, ow, pw, dtype=npdt)
+    out = dpr_amd.raster(grid, T(pts, dev), T(R, dev), T(t, dev), T(bg, dev), T(ow, dev),
+                         T(pw, dev), algo=algo)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), T(pts, dev), T(R, dev), T(t, dev),
+                                  T(bg, dev), T(ow, dev), T(pw, dev), algo=algo)
+    _compare(ref_out, ref_pb, out, pb, npdt)
