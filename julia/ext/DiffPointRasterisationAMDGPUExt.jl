@@ -23,11 +23,17 @@ suffix(::Type{Float64}) = :f64
 
 # FillArrays defaults (src/interface.jl:368-394) travel as NULL pointers
 devptr(::FillArrays.AbstractFill, ::Type{T}) where {T} = Ptr{T}(C_NULL)
-devptr(a::ROCArray{T}, ::Type{T}) where {T} = Ptr{T}(UInt(pointer(a)))
-# pose vectors may arrive as host SVector{1} (single-pose wrap, src/interface.jl:113-116)
-todev(a::ROCArray, ::Type{T}) where {T} = eltype(a) === T ? a : T.(a)
-todev(a::FillArrays.AbstractFill, ::Type) = a
-todev(a::AbstractVector, ::Type{T}) where {T} = ROCArray(T.(reinterpret(reshape, eltype(eltype(a)) <: Number ? eltype(eltype(a)) : eltype(a), collect(a))))
+devptr(a::ROCArray, ::Type{T}) where {T} = Ptr{T}(UInt(pointer(a)))
+
+# Device buffer whose memory is the elements of `a` converted to T, in `a`'s own order
+# (Vector{SMatrix} is already "B x column-major N_out x N_in").  Pose vectors may arrive as
+# host SVector{1} wrappers (single-pose path, src/interface.jl:113-116): those are uploaded.
+devbuf(a::ROCArray{<:Number}, ::Type{T}) where {T} = eltype(a) === T ? a : T.(a)
+devbuf(a::ROCArray{<:StaticArray}, ::Type{T}) where {T} =
+    eltype(eltype(a)) === T ? a : map(x -> T.(x), a)
+devbuf(a::FillArrays.AbstractFill, ::Type) = a
+devbuf(a::AbstractVector{<:StaticArray}, ::Type{T}) where {T} = ROCArray(map(x -> T.(x), collect(a)))
+devbuf(a::AbstractVector{<:Number}, ::Type{T}) where {T} = ROCArray(T.(collect(a)))
 
 function check(status::Cint)
     status == 0 && return nothing
@@ -37,7 +43,6 @@ function check(status::Cint)
 end
 
 function workspace(op::Integer, ::Type{T}, n_in, n_out, grid, P, B) where {T}
-    fn = T === Float32 ? :dpr_workspace_bytes_f32 : :dpr_workspace_bytes_f64
     g = collect(Int64, grid)
     nbytes = T === Float32 ?
         ccall((:dpr_workspace_bytes_f32, libdpr), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Int64}, Int64, Int64), op, 0, n_in, n_out, g, P, B) :
@@ -60,8 +65,8 @@ function DiffPointRasterisation.raster!(
     @argcheck B == length(rotation) == length(translation) == length(background) == length(out_weight) DimensionMismatch
     P = length(points)
     @argcheck length(point_weight) == P
-    rot, tr = todev(rotation, T), todev(translation, T)
-    bg, ow, pw = todev(background, T), todev(out_weight, T), todev(point_weight, T)
+    rot, tr = devbuf(rotation, T), devbuf(translation, T)
+    bg, ow, pw = devbuf(background, T), devbuf(out_weight, T), devbuf(point_weight, T)
     grid = collect(Int64, size(out)[1:N_out])
     ws = workspace(0, T, N_in, N_out, grid, P, B)
     stream = AMDGPU.stream()
@@ -69,14 +74,14 @@ function DiffPointRasterisation.raster!(
         st = if T === Float32
             ccall((:dpr_raster_f32, libdpr), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
-                stream.stream, N_in, N_out, grid, P, B, devptr(out, T), Ptr{T}(UInt(pointer(points))),
-                Ptr{T}(UInt(pointer(rot))), Ptr{T}(UInt(pointer(tr))), devptr(bg, T), devptr(ow, T), devptr(pw, T),
+                stream.stream, N_in, N_out, grid, P, B, devptr(out, T), devptr(points, T),
+                devptr(rot, T), devptr(tr, T), devptr(bg, T), devptr(ow, T), devptr(pw, T),
                 Ptr{Cvoid}(UInt(pointer(ws))), length(ws))
         else
             ccall((:dpr_raster_f64, libdpr), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
-                stream.stream, N_in, N_out, grid, P, B, devptr(out, T), Ptr{T}(UInt(pointer(points))),
-                Ptr{T}(UInt(pointer(rot))), Ptr{T}(UInt(pointer(tr))), devptr(bg, T), devptr(ow, T), devptr(pw, T),
+                stream.stream, N_in, N_out, grid, P, B, devptr(out, T), devptr(points, T),
+                devptr(rot, T), devptr(tr, T), devptr(bg, T), devptr(ow, T), devptr(pw, T),
                 Ptr{Cvoid}(UInt(pointer(ws))), length(ws))
         end
         check(st)
@@ -107,18 +112,16 @@ function DiffPointRasterisation.raster_pullback!(
     P = length(points)
     @argcheck length(ds_dpoint_weight) == P
     B = length(batch_axis)
-    rot, tr = todev(rotation, T), todev(translation, T)
-    ow, pw = todev(out_weight, T), todev(point_weight, T)
+    rot, tr = devbuf(rotation, T), devbuf(translation, T)
+    ow, pw = devbuf(out_weight, T), devbuf(point_weight, T)
     grid = collect(Int64, size(ds_dout)[1:N_out])
     ws = workspace(1, T, N_in, N_out, grid, P, B)
-    fn = T === Float32 ? :dpr_raster_pullback_f32 : :dpr_raster_pullback_f64
     GC.@preserve ds_dout points rot tr ow pw ws begin
         args = (AMDGPU.stream().stream, N_in, N_out, grid, P, B, devptr(ds_dout, T),
-            Ptr{T}(UInt(pointer(points))), Ptr{T}(UInt(pointer(rot))), Ptr{T}(UInt(pointer(tr))),
+            devptr(points, T), devptr(rot, T), devptr(tr, T),
             devptr(ow, T), devptr(pw, T), devptr(ds_dpoints, T), devptr(ds_drotation, T),
             devptr(ds_dtranslation, T), devptr(ds_dbackground, T), devptr(ds_dout_weight, T),
             devptr(ds_dpoint_weight, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws))
-        argt = (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, ntuple(_ -> Ptr{T}, 12)..., Ptr{Cvoid}, Csize_t)
         st = T === Float32 ?
             ccall((:dpr_raster_pullback_f32, libdpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t), args...) :
             ccall((:dpr_raster_pullback_f64, libdpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t), args...)
