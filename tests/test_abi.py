@@ -98,3 +98,61 @@ def test_shard_range_is_a_partition():
                 assert b == c
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_auto_algorithm_and_workspace_queries_need_no_device():
+    """dpr_resolve_algo / dpr_workspace_bytes_* are pure host arithmetic."""
+    import torch
+
+    assert dpr_amd.resolve_algo("raster", (256, 256, 256), 10_000_000, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256, 256, 256), 10_000_000, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (8, 8, 8), 1000, 1, 3) == "atomic"
+    # more tiles than the tiled path supports -> direct kernels
+    assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "atomic"
+    assert dpr_amd.workspace_bytes("raster", (8, 8), 100, 1, 2, torch.float64, "atomic") == 0
+    small = dpr_amd.workspace_bytes("raster", (256,) * 3, 1_000_000, 1, 3, torch.float32, "tiled")
+    big = dpr_amd.workspace_bytes("raster", (256,) * 3, 10_000_000, 1, 3, torch.float32, "tiled")
+    assert 0 < small < big < 10_000_000 * 64
+    assert dpr_amd.workspace_bytes("pullback", (256,) * 3, 10_000_000, 1, 3, torch.float32, "tiled") == big
+    f64 = dpr_amd.workspace_bytes("raster", (256,) * 3, 10_000_000, 1, 3, torch.float64, "tiled")
+    assert f64 > big
+    assert dpr_amd.workspace_bytes("raster", (256,) * 3, 10_000_000, 4, 3, torch.float32, "chunked") > 0
+    with pytest.raises(dpr_amd.DprError):
+        dpr_amd.workspace_bytes("raster", (8, 8, 8, 8), 10, 1, 3, torch.float32, "tiled")
+
+
+@pytest.mark.parametrize("suf,ctype", [("f32", ctypes.c_float), ("f64", ctypes.c_double)])
+def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
+    """A too-small workspace, or binning flags on the wrong algorithm / batch size, are
+    rejected on the host (dummy non-NULL pointers are never dereferenced)."""
+    L = dpr_amd.lib()
+    grid = np.array([64, 64, 64], dtype=np.int64)
+    gp = grid.ctypes.data_as(ctypes.c_void_p)
+    dummy = (ctypes.c_double * 64)()
+    d = ctypes.cast(dummy, ctypes.c_void_p)
+    fn = getattr(L, f"dpr_raster_ex_{suf}")
+    # tiled needs a workspace
+    rc = fn(None, dpr_amd._lib.ALGO_TILED, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_WORKSPACE and "workspace" in dpr_amd._lib.last_error()
+    rc = fn(None, dpr_amd._lib.ALGO_TILED, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, d, 64)
+    assert rc == dpr_amd._lib.ERR_WORKSPACE
+    # keep / reuse flags: tiled or chunked only, one pose only
+    rc = fn(None, dpr_amd._lib.ALGO_ATOMIC, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 1, d, d,
+            d, d, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_UNSUPPORTED_ALGO
+    rc = fn(None, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 2, d, d,
+            d, d, None, None, None, d, 1 << 30)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "B == 1" in dpr_amd._lib.last_error()
+    pb = getattr(L, f"dpr_raster_pullback_ex_{suf}")
+    rc = pb(None, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_REUSE_BINNING, 3, 3, gp, 1000, 2,
+            *([d] * 4), None, None, *([d] * 6), d, 1 << 30)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG
+    # unknown algorithm id
+    rc = fn(None, 77, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_UNSUPPORTED_ALGO
+    # the sort utility validates too
+    srt = getattr(L, f"dpr_sort_points_{suf}")
+    assert srt(None, 4, 10, d, d, d, None, None, d, 1 << 20) == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
+    assert srt(None, 3, 10, d, d, d, d, None, d, 1 << 20) == dpr_amd._lib.ERR_INVALID_ARG
+    d2 = ctypes.cast((ctypes.c_double * 64)(), ctypes.c_void_p)
+    assert srt(None, 3, 10, d, d2, d, None, None, d, 8) == dpr_amd._lib.ERR_WORKSPACE
