@@ -37,6 +37,8 @@ EXPORTS = [
     "dpr_raster_f32", "dpr_raster_f64", "dpr_raster_ex_f32", "dpr_raster_ex_f64",
     "dpr_raster_pullback_f32", "dpr_raster_pullback_f64",
     "dpr_raster_pullback_ex_f32", "dpr_raster_pullback_ex_f64",
+    "dpr_raster_residual_pullback_f32", "dpr_raster_residual_pullback_f64",
+    "dpr_raster_residual_pullback_ex_f32", "dpr_raster_residual_pullback_ex_f64",
 ]
 
 _lib = None
@@ -107,6 +109,14 @@ def lib() -> ctypes.CDLL:
         f = getattr(L, f"dpr_raster_pullback_ex_{suf}")
         f.restype = i
         f.argtypes = [vp, i, ctypes.c_uint, i, i, vp, i64, i64] + [vp] * 12 + [vp, sz]
+        # ..., out, target, residual_scale, points, rot, trans, ow, pw, loss, 6 outputs, ws, ws_bytes
+        f = getattr(L, f"dpr_raster_residual_pullback_{suf}")
+        f.restype = i
+        f.argtypes = [vp, i, i, vp, i64, i64, vp, vp, ctypes.c_double] + [vp] * 12 + [vp, sz]
+        f = getattr(L, f"dpr_raster_residual_pullback_ex_{suf}")
+        f.restype = i
+        f.argtypes = ([vp, i, ctypes.c_uint, i, i, vp, i64, i64, vp, vp, ctypes.c_double]
+                      + [vp] * 12 + [vp, sz])
     _lib = L
     return L
 

@@ -149,8 +149,9 @@ template <typename T, int NI, int NO>
 static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t P, int64_t B,
                            const T* g, const T* points, const T* rot, const T* trans, const T* ow,
                            const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
-                           T* d_pw) {
+                           T* d_pw, Residual<T> rs) {
     const GridDesc<NO> gd = make_grid<NO>(grid, G);
+    if (rs.target && rs.loss) DPR_HIP(hipMemsetAsync(rs.loss, 0, sizeof(T) * (size_t)B, st));
     DPR_HIP(hipMemsetAsync(d_rot, 0, sizeof(T) * (size_t)(B * NO * NI), st));
     DPR_HIP(hipMemsetAsync(d_trans, 0, sizeof(T) * (size_t)(B * NO), st));
     DPR_HIP(hipMemsetAsync(d_ow, 0, sizeof(T) * (size_t)B, st));
@@ -161,7 +162,10 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
         if (want * nb > 8192) want = (8192 + nb - 1) / nb;
         if (want < 1) want = 1;
         dim3 gg((unsigned)want, (unsigned)nb);
-        hipLaunchKernelGGL(k_grid_sum<T>, gg, dim3(kBlock), 0, st, g + b0 * G, G, d_bg + b0);
+        Residual<T> rb = rs;
+        if (rb.target) rb.target += b0 * G;
+        if (rb.loss) rb.loss += b0;
+        hipLaunchKernelGGL(k_grid_sum<T>, gg, dim3(kBlock), 0, st, g + b0 * G, G, d_bg + b0, rb);
     }
     stage_mark(st);
     if (P > 0) {
@@ -183,7 +187,7 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
         dim3 gg((unsigned)pblocks, (unsigned)slices);
         hipLaunchKernelGGL((k_bwd_gather<T, NI, NO>), gg, dim3(kBlock), 0, st, gd, P, B, g, points,
                            rot, trans, ow, pw, d_pts, d_rot, d_trans, d_ow, d_pw, poses_per_slice,
-                           accumulate);
+                           accumulate, rs);
     }
     stage_mark(st);
     DPR_HIP(hipGetLastError());
@@ -194,7 +198,8 @@ template <typename T>
 static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid,
                          int64_t P, int64_t B, const T* g, const T* points, const T* rot,
                          const T* trans, const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans,
-                         T* d_bg, T* d_ow, T* d_pw, void* ws, size_t ws_bytes) {
+                         T* d_bg, T* d_ow, T* d_pw, void* ws, size_t ws_bytes,
+                         Residual<T> rs = Residual<T>{nullptr, T(0), nullptr}) {
     int64_t G = 0;
     if (int rc = check_common(n_in, n_out, grid, P, B, &G)) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -209,7 +214,7 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
         }
         return DPR_OK;
     }
-    if (!g) return fail(DPR_ERR_INVALID_ARG, "ds_dout is NULL");
+    if (!g) return fail(DPR_ERR_INVALID_ARG, rs.target ? "out is NULL" : "ds_dout is NULL");
     if (!rot || !trans) return fail(DPR_ERR_INVALID_ARG, "rotation/translation is NULL");
     if (!d_rot || !d_trans || !d_bg || !d_ow)
         return fail(DPR_ERR_INVALID_ARG, "a per-pose output pointer is NULL");
@@ -219,11 +224,14 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     if (n_in == NI && n_out == NO) {                                                             \
         if (algo == DPR_ALGO_ATOMIC && flags == 0)                                               \
             return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw,   \
-                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw);          \
+                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, rs);      \
         if (algo == DPR_ALGO_TILED)                                                              \
             return pullback_tiled<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans, ow, pw,    \
                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
-                                             ws_bytes);                                          \
+                                             ws_bytes, rs);                                      \
+        if (algo == DPR_ALGO_CHUNKED && rs.target)                                               \
+            return fail(DPR_ERR_UNSUPPORTED_ALGO,                                                \
+                        "the residual pullback has no DPR_ALGO_CHUNKED variant");                \
         if (algo == DPR_ALGO_CHUNKED)                                                            \
             return pullback_chunked<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans,   \
                                                ow, pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw,  \
@@ -344,5 +352,38 @@ size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int6
 DPR_DEFINE(f32, float)
 DPR_DEFINE(f64, double)
 #undef DPR_DEFINE
+
+#define DPR_DEFINE_RESIDUAL(SUF, T)                                                               \
+    int dpr_raster_residual_pullback_ex_##SUF(                                                    \
+        void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid,         \
+        int64_t P, int64_t B, const T* out, const T* target, double residual_scale,               \
+        const T* points, const T* rotation, const T* translation, const T* out_weight,            \
+        const T* point_weight, T* loss, T* ds_dpoints, T* ds_drotation, T* ds_dtranslation,       \
+        T* ds_dbackground, T* ds_dout_weight, T* ds_dpoint_weight, void* workspace,               \
+        size_t workspace_bytes) {                                                                 \
+        if (!target && B > 0)                                                                     \
+            return dpr::fail(DPR_ERR_INVALID_ARG, "residual pullback: target is NULL");           \
+        return dpr::pullback_impl<T>(stream, algo, flags, n_in, n_out, grid, P, B, out, points,   \
+                                     rotation, translation, out_weight, point_weight, ds_dpoints, \
+                                     ds_drotation, ds_dtranslation, ds_dbackground,               \
+                                     ds_dout_weight, ds_dpoint_weight, workspace,                 \
+                                     workspace_bytes,                                             \
+                                     dpr::Residual<T>{target, (T)residual_scale, loss});          \
+    }                                                                                             \
+    int dpr_raster_residual_pullback_##SUF(                                                       \
+        void* stream, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B,             \
+        const T* out, const T* target, double residual_scale, const T* points,                    \
+        const T* rotation, const T* translation, const T* out_weight, const T* point_weight,      \
+        T* loss, T* ds_dpoints, T* ds_drotation, T* ds_dtranslation, T* ds_dbackground,           \
+        T* ds_dout_weight, T* ds_dpoint_weight, void* workspace, size_t workspace_bytes) {        \
+        return dpr_raster_residual_pullback_ex_##SUF(                                             \
+            stream, DPR_ALGO_AUTO, 0u, n_in, n_out, grid, P, B, out, target, residual_scale,      \
+            points, rotation, translation, out_weight, point_weight, loss, ds_dpoints,            \
+            ds_drotation, ds_dtranslation, ds_dbackground, ds_dout_weight, ds_dpoint_weight,      \
+            workspace, workspace_bytes);                                                          \
+    }
+DPR_DEFINE_RESIDUAL(f32, float)
+DPR_DEFINE_RESIDUAL(f64, double)
+#undef DPR_DEFINE_RESIDUAL
 
 }  // extern "C"

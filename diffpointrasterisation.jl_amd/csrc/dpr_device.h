@@ -142,6 +142,23 @@ __device__ __forceinline__ void point_backward(const int (&ref0)[NO], const T (&
     for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));
 }
 
+// Fused residual sensitivity (dpr_raster_residual_pullback_*): when `target` is set the
+// grid argument of a pullback kernel is the forward result `out` and the sensitivity is formed
+// on the fly, ds_dout = scale * (out - target)  (README.md:151 computes exactly this grid on
+// the host with scale = -2; examples/logo.jl:40-44 is the scale = +2 case), so ds_dout is
+// never written to or re-read from HBM.  loss[b] = sum((out - target)^2) over pose b.
+template <typename T> struct Residual {
+    const T* target;  // nullptr: the grid argument already is ds_dout
+    T scale;
+    T* loss;          // B values or nullptr
+};
+
+template <typename T>
+__device__ __forceinline__ T sens(const Residual<T>& rs, const T* __restrict__ g, int64_t i) {
+    const T x = g[i];
+    return rs.target ? rs.scale * (x - rs.target[i]) : x;
+}
+
 // wave-level sum (all 64 lanes must call)
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

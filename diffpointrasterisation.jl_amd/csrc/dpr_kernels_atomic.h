@@ -58,22 +58,36 @@ __global__ __launch_bounds__(kBlock) void k_fwd_atomic(GridDesc<NO> gd, int64_t 
 // ext/DiffPointRasterisationCUDAExt.jl:265-267).  ds_dbackground pre-zeroed.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_grid_sum(const T* __restrict__ g, int64_t G,
-                                                     T* __restrict__ ds_dbackground) {
-    __shared__ T part[kBlock / kWave];
+                                                     T* __restrict__ ds_dbackground,
+                                                     Residual<T> rs) {
+    __shared__ T part[2][kBlock / kWave];
     const int64_t b = blockIdx.y;
-    const T* gb = g + b * G;
-    T acc = T(0);
+    const int64_t o = b * G;
+    T acc = T(0), sq = T(0);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < G;
-         i += (int64_t)gridDim.x * kBlock)
-        acc += gb[i];
+         i += (int64_t)gridDim.x * kBlock) {
+        const T x = g[o + i];
+        if (rs.target) {
+            const T d = x - rs.target[o + i];
+            acc += rs.scale * d;
+            sq += d * d;
+        } else {
+            acc += x;
+        }
+    }
     acc = wave_sum<T>(acc);
-    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = acc;
+    sq = wave_sum<T>(sq);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        part[0][threadIdx.x / kWave] = acc;
+        part[1][threadIdx.x / kWave] = sq;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        T s = part[0];
+    if (threadIdx.x < 2) {
+        T s = part[threadIdx.x][0];
 #pragma unroll
-        for (int w = 1; w < kBlock / kWave; ++w) s += part[w];
-        atomic_add<T>(ds_dbackground + b, s);
+        for (int w = 1; w < kBlock / kWave; ++w) s += part[threadIdx.x][w];
+        if (threadIdx.x == 0) atomic_add<T>(ds_dbackground + b, s);
+        else if (rs.target && rs.loss) atomic_add<T>(rs.loss + b, s);
     }
 }
 
@@ -87,7 +101,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gather(
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
     const T* __restrict__ pw, T* __restrict__ ds_dpoints, T* __restrict__ ds_drotation,
     T* __restrict__ ds_dtranslation, T* __restrict__ ds_dout_weight,
-    T* __restrict__ ds_dpoint_weight, int poses_per_slice, int accumulate_points) {
+    T* __restrict__ ds_dpoint_weight, int poses_per_slice, int accumulate_points,
+    Residual<T> rs) {
     constexpr int NV = NO * NI + NO + 1;  // dR | dt | d out_weight
     constexpr int NW = kBlock / kWave;
     __shared__ T red[NW][NV];
@@ -117,11 +132,11 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gather(
         int ref0[NO];
         T dlo[NO];
         if (live && ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
-            const T* gb = g + b * gd.G;
+            const int64_t gb = b * gd.G;
             T scaled[NO], dow_part, dpw_part;
             point_backward<T, NI, NO>(ref0, dlo, gd, ps.ow, pwi,
-                                      [&](int off) { return gb[off]; }, scaled, dow_part,
-                                      dpw_part);
+                                      [&](int off) { return sens<T>(rs, g, gb + off); }, scaled,
+                                      dow_part, dpw_part);
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
 #pragma unroll

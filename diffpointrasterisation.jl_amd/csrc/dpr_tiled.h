@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dpr_device.h"
+
 namespace dpr {
 
 int fail(int code, const char* fmt, ...);
@@ -24,7 +26,7 @@ template <typename T, int NI, int NO>
 int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B,
                    const T* g, const T* points, const T* rot, const T* trans, const T* ow,
                    const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw,
-                   void* ws, size_t ws_bytes);
+                   void* ws, size_t ws_bytes, Residual<T> rs);
 
 // DPR_ALGO_CHUNKED (dpr_chunked.hip)
 bool chunked_supported(int n_out, const int64_t* grid);

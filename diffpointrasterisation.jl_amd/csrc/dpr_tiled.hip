@@ -832,9 +832,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     const uint32_t* __restrict__ rec_idx, const WorkItem* __restrict__ items,
     const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b,
-    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials) {
+    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials,
+    Residual<T> rs) {
     constexpr int NVH = tile_voxels_halo<NO>();
-    constexpr int NVAL = NO * NI + NO + 2;  // dR | dt | d out_weight | d background
+    constexpr int NVAL = NO * NI + NO + 3;  // dR | dt | d out_weight | d background | loss
     constexpr int NW = kGatherThreads / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
@@ -844,6 +845,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const T* gb = g + b * gd.G;
+    const T* tb = rs.target ? rs.target + b * gd.G : nullptr;
     const uint32_t r1 = item.end;
     uint32_t r = item.begin + threadIdx.x;
     Rec4<T> nxt;
@@ -857,13 +859,14 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         z.v[0] = z.v[1] = z.v[2] = z.v[3] = T(0);
         rec[P] = z;  // spare slot: the gradient of every rejected point
     }
-    // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground
-    double bg_sum = 0.0;
+    // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground (residual
+    // mode: ds_dout = scale * (out - target) formed here, squared residuals summed for loss)
+    double bg_sum = 0.0, sq_sum = 0.0;
     {
         // all loads are issued (clamped addresses, no branches) before the first LDS write
         constexpr int IT = (NVH + kGatherThreads - 1) / kGatherThreads;
-        T v[IT];
-        bool own[IT];
+        T v[IT], tv[IT];
+        bool own[IT], inside[IT];
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
             const int i = threadIdx.x + k * kGatherThreads;
@@ -880,8 +883,18 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
                 stride *= gd.n[d];
             }
             const T x = gb[ok ? off : 0];
+            tv[k] = tb ? tb[ok ? off : 0] : T(0);
             v[k] = ok ? x : T(0);
             own[k] = owned && ok;
+            inside[k] = ok;
+        }
+        if (tb) {
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const T d = v[k] - tv[k];
+                if (own[k] && (item.part_nparts & 0xffffu) == 0) sq_sum += (double)d * (double)d;
+                v[k] = inside[k] ? rs.scale * d : T(0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
@@ -894,9 +907,9 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     // per-thread sums of the per-pose scalars: T within the thread (few records each),
     // f64 across threads / tiles
-    T vals[NVAL - 1];
+    T vals[NVAL - 2];
 #pragma unroll
-    for (int k = 0; k < NVAL - 1; ++k) vals[k] = T(0);
+    for (int k = 0; k < NVAL - 2; ++k) vals[k] = T(0);
     while (r < r1) {
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
@@ -1004,12 +1017,13 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < NVAL; ++k) {
-        const double v = (k < NVAL - 1) ? (double)vals[k < NVAL - 1 ? k : 0] : bg_sum;
+        const double v = (k < NVAL - 2) ? (double)vals[k < NVAL - 2 ? k : 0]
+                                        : (k == NVAL - 2 ? bg_sum : sq_sum);
         const double s = wave_sum<double>(v);
         if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NVAL) {
+    if (threadIdx.x < (rs.target ? NVAL : NVAL - 1)) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
@@ -1048,7 +1062,8 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
                                                       T* __restrict__ ds_drotation,
                                                       T* __restrict__ ds_dtranslation,
                                                       T* __restrict__ ds_dbackground,
-                                                      T* __restrict__ ds_dout_weight) {
+                                                      T* __restrict__ ds_dout_weight,
+                                                      T* __restrict__ loss) {
     __shared__ double wsum[16];
     const int k = blockIdx.x;
     double s = 0.0;
@@ -1067,8 +1082,10 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
             ds_dtranslation[b * NO + (k - NO * NI)] = (T)tot;
         else if (k == NO * NI + NO)
             ds_dout_weight[b] = (T)tot;
-        else
+        else if (k == NO * NI + NO + 1)
             ds_dbackground[b] = (T)tot;
+        else if (loss)
+            loss[b] = (T)tot;
     }
 }
 
@@ -1343,7 +1360,7 @@ template <typename T, int NI, int NO>
 int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
                    int64_t B, const T* g, const T* points, const T* rot, const T* trans,
                    const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
-                   T* d_pw, void* ws_, size_t ws_bytes) {
+                   T* d_pw, void* ws_, size_t ws_bytes, Residual<T> rs) {
     TileGeom<NO> tg;
     if (!make_geom<NO>(grid, &tg))
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
@@ -1362,7 +1379,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     double* partials = (double*)(ws + pl.off_aux);
-    constexpr int NVAL = NO * NI + NO + 2;
+    constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
     const bool unperm = env_int("DPR_BWD_UNPERMUTE", 1) != 0;
     for (int64_t b = 0; b < B; ++b) {
         if (reuse) {
@@ -1384,7 +1401,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                        dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,     \
                        (const uint32_t*)(ws + pl.off_idx), (const WorkItem*)(ws + pl.off_items), \
                        (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,  \
-                       b, d_pts, d_pw, partials)
+                       b, d_pts, d_pw, partials, rs)
         if (unperm) {
             if (pw) DPR_LAUNCH_GATHER(true, true, true);
             else DPR_LAUNCH_GATHER(false, true, true);
@@ -1412,9 +1429,10 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         }
 #undef DPR_LAUNCH_GATHER
         stage_mark(st);
-        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(NVAL), dim3(1024), 0, st,
-                           (const double*)partials, (const uint32_t*)(ws + pl.off_nitems),
-                           pl.max_items, b, d_rot, d_trans, d_bg, d_ow);
+        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(rs.target ? NVAL + 1 : NVAL),
+                           dim3(1024), 0, st, (const double*)partials,
+                           (const uint32_t*)(ws + pl.off_nitems), pl.max_items, b, d_rot,
+                           d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());
@@ -1428,7 +1446,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     template int pullback_tiled<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t,        \
                                            int64_t, int64_t, const T*, const T*, const T*,        \
                                            const T*, const T*, const T*, T*, T*, T*, T*, T*, T*,  \
-                                           void*, size_t);
+                                           void*, size_t, Residual<T>);
 DPR_INST(float, 2, 2)
 DPR_INST(float, 3, 3)
 DPR_INST(float, 3, 2)

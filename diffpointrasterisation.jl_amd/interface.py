@@ -283,6 +283,36 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
     Returned layouts: points (P, N_in); rotation (B, N_out, N_in) -- a transposed view of
     the column-major (N_out, N_in, B) buffer; translation (B, N_out); background,
     out_weight (B,); point_weight (P,)."""
+    return _pullback(ds_dout, None, points, rotation, translation, background, out_weight,
+                     point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
+                     ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning)
+
+
+def raster_residual_pullback_(out, target, points, rotation, translation, background=None,
+                              out_weight=None, point_weight=None, *, scale: float = 2.0,
+                              loss=None, ds_dpoints=None, ds_drotation=None,
+                              ds_dtranslation=None, ds_dbackground=None, ds_dout_weight=None,
+                              ds_dpoint_weight=None, algo: str = "auto", workspace=None,
+                              reuse_binning: bool = False):
+    """Pullback of a squared-error loss without materialising its sensitivity
+    (dpr_raster_residual_pullback_*).  Equivalent to
+
+        ds_dout = scale * (out - target)          # README.md:151 (there: scale = -2)
+        raster_pullback_(ds_dout, points, ...)     # src/interface.jl:196-308
+        loss    = ((out - target) ** 2).sum over each pose's grid
+
+    with `out` the result of `raster` for the same arguments; ds_dout is formed inside the
+    kernels, so the grid is read once (out, target) instead of written and re-read.  Returns
+    (PullbackResult, loss) with loss of shape (B,) (0-d for a single pose)."""
+    return _pullback(out, (target, float(scale), loss), points, rotation, translation, background,
+                     out_weight, point_weight, ds_dpoints, ds_drotation, ds_dtranslation,
+                     ds_dbackground, ds_dout_weight, ds_dpoint_weight, algo, workspace,
+                     reuse_binning)
+
+
+def _pullback(ds_dout, residual, points, rotation, translation, background, out_weight,
+              point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
+              ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning):
     import numpy as np
 
     c = _canonicalise(points, rotation, translation, background, out_weight, point_weight,
@@ -300,6 +330,17 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
         g = to_grid_layout(g)
     grid = tuple(g.shape[:n_out])
     grid_arr = np.asarray(grid, dtype=np.int64)
+    tgt = None
+    if residual is not None:
+        target, res_scale, loss = residual
+        if not isinstance(target, torch.Tensor) or target.device != dev:
+            raise RuntimeError("target must be a tensor on the same HIP device as points")
+        if tuple(target.shape) != tuple(ds_dout.shape):
+            raise DimensionMismatch(
+                f"target shape {tuple(target.shape)} != out shape {tuple(ds_dout.shape)}")
+        tgt = target.to(dtype)
+        if not _is_grid_layout(tgt):
+            tgt = to_grid_layout(tgt)
 
     def out_buf(given, shape, name):
         if given is None:
@@ -328,25 +369,37 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
     d_ow = out_buf(None if ds_dout_weight is None else ds_dout_weight.reshape(B), (B,),
                    "ds_dout_weight")
     d_pw = out_buf(ds_dpoint_weight, (P,), "ds_dpoint_weight")
+    d_loss = None
+    if residual is not None:
+        d_loss = out_buf(None if loss is None else loss.reshape(B), (B,), "loss")
 
     suf = _SUFFIX[dtype]
     algo_c = _lib.ALGOS[algo]
     with torch.cuda.device(dev):
         ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
                                   workspace)
-        fn = getattr(_lib.lib(), f"dpr_raster_pullback_ex_{suf}")
         flags = _lib.FLAG_REUSE_BINNING if reuse_binning else 0
         if reuse_binning and workspace is None:
             raise ValueError("reuse_binning needs the workspace of the preceding raster_ call")
-        _lib.check(fn(_stream_ptr(dev), algo_c, flags, n_in, n_out,
-                      grid_arr.ctypes.data_as(ctypes.c_void_p), P, B, _ptr(g), _ptr(c["points"]),
-                      _ptr(c["rot"]), _ptr(c["trans"]), _ptr(c["ow"]), _ptr(c["pw"]),
-                      _ptr(d_pts), _ptr(d_rot), _ptr(d_trans), _ptr(d_bg), _ptr(d_ow),
-                      _ptr(d_pw), _ptr(ws), ws_bytes))
+        head = (_stream_ptr(dev), algo_c, flags, n_in, n_out,
+                grid_arr.ctypes.data_as(ctypes.c_void_p), P, B)
+        pose = (_ptr(c["points"]), _ptr(c["rot"]), _ptr(c["trans"]), _ptr(c["ow"]), _ptr(c["pw"]))
+        outs = (_ptr(d_pts), _ptr(d_rot), _ptr(d_trans), _ptr(d_bg), _ptr(d_ow), _ptr(d_pw),
+                _ptr(ws), ws_bytes)
+        if residual is None:
+            fn = getattr(_lib.lib(), f"dpr_raster_pullback_ex_{suf}")
+            _lib.check(fn(*head, _ptr(g), *pose, *outs))
+        else:
+            fn = getattr(_lib.lib(), f"dpr_raster_residual_pullback_ex_{suf}")
+            _lib.check(fn(*head, _ptr(g), _ptr(tgt), res_scale, *pose, _ptr(d_loss), *outs))
     rot_math = d_rot.transpose(1, 2)
     if c["single"]:
-        return PullbackResult(d_pts, rot_math[0], d_trans[0], d_bg[0], d_ow[0], d_pw)
-    return PullbackResult(d_pts, rot_math, d_trans, d_bg, d_ow, d_pw)
+        res = PullbackResult(d_pts, rot_math[0], d_trans[0], d_bg[0], d_ow[0], d_pw)
+    else:
+        res = PullbackResult(d_pts, rot_math, d_trans, d_bg, d_ow, d_pw)
+    if residual is None:
+        return res
+    return res, (d_loss[0] if c["single"] else d_loss)
 
 
 def sort_points(points: torch.Tensor, point_weight: Optional[torch.Tensor] = None):

@@ -168,6 +168,56 @@ int dpr_raster_pullback_ex_f64(void *stream, int algo, unsigned flags, int n_in,
                                double *ds_dbackground, double *ds_dout_weight,
                                double *ds_dpoint_weight, void *workspace, size_t workspace_bytes);
 
+/* Residual pullback: the caller one step out of raster_pullback!.
+ * `out` is the result of dpr_raster_* for the same points / poses / weights, `target` a grid
+ * of the same layout.  Computes, without materialising the sensitivity,
+ *     ds_dout = residual_scale * (out - target)        README.md:151 (scale -2 there; +2 is
+ *                                                      the gradient of examples/logo.jl:40-44)
+ *     <all six outputs of dpr_raster_pullback_*>(ds_dout, ...)
+ *     loss[b] = sum over pose b's grid of (out - target)^2      (loss may be NULL)
+ * The sensitivity is formed in the kernels that consume it: the grid is read twice (out,
+ * target) instead of read twice, written once and read again.  Flags / workspace as for
+ * dpr_raster_pullback_ex_*; DPR_ALGO_CHUNKED is not available (DPR_ERR_UNSUPPORTED_ALGO). */
+int dpr_raster_residual_pullback_f32(void *stream, int n_in, int n_out, const int64_t *grid,
+                                     int64_t P, int64_t B, const float *out, const float *target,
+                                     double residual_scale, const float *points,
+                                     const float *rotation, const float *translation,
+                                     const float *out_weight, const float *point_weight,
+                                     float *loss, float *ds_dpoints, float *ds_drotation,
+                                     float *ds_dtranslation, float *ds_dbackground,
+                                     float *ds_dout_weight, float *ds_dpoint_weight,
+                                     void *workspace, size_t workspace_bytes);
+int dpr_raster_residual_pullback_f64(void *stream, int n_in, int n_out, const int64_t *grid,
+                                     int64_t P, int64_t B, const double *out,
+                                     const double *target, double residual_scale,
+                                     const double *points, const double *rotation,
+                                     const double *translation, const double *out_weight,
+                                     const double *point_weight, double *loss, double *ds_dpoints,
+                                     double *ds_drotation, double *ds_dtranslation,
+                                     double *ds_dbackground, double *ds_dout_weight,
+                                     double *ds_dpoint_weight, void *workspace,
+                                     size_t workspace_bytes);
+int dpr_raster_residual_pullback_ex_f32(void *stream, int algo, unsigned flags, int n_in,
+                                        int n_out, const int64_t *grid, int64_t P, int64_t B,
+                                        const float *out, const float *target,
+                                        double residual_scale, const float *points,
+                                        const float *rotation, const float *translation,
+                                        const float *out_weight, const float *point_weight,
+                                        float *loss, float *ds_dpoints, float *ds_drotation,
+                                        float *ds_dtranslation, float *ds_dbackground,
+                                        float *ds_dout_weight, float *ds_dpoint_weight,
+                                        void *workspace, size_t workspace_bytes);
+int dpr_raster_residual_pullback_ex_f64(void *stream, int algo, unsigned flags, int n_in,
+                                        int n_out, const int64_t *grid, int64_t P, int64_t B,
+                                        const double *out, const double *target,
+                                        double residual_scale, const double *points,
+                                        const double *rotation, const double *translation,
+                                        const double *out_weight, const double *point_weight,
+                                        double *loss, double *ds_dpoints, double *ds_drotation,
+                                        double *ds_dtranslation, double *ds_dbackground,
+                                        double *ds_dout_weight, double *ds_dpoint_weight,
+                                        void *workspace, size_t workspace_bytes);
+
 /* Pose-independent spatial pre-sort (Morton order) of the model-frame points -- not in the
  * reference; every algorithm here is faster on coherent input and the sort only depends on
  * the points.  points_sorted[i] = points[perm[i]] (and point weights likewise; pass NULL for

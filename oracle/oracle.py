@@ -145,3 +145,22 @@ def raster_pullback(ds_dout, points, rotation, translation, out_weight=None, poi
     if rc != 0:
         raise RuntimeError(f"oracle raster_pullback failed rc={rc}")
     return PullbackResult(d_points, np.transpose(d_rot_cm, (0, 2, 1)).copy(), d_trans, d_bg, d_ow, d_pw)
+
+
+def residual_pullback(out, target, points, rotation, translation, out_weight=None,
+                      point_weight=None, scale: float = 2.0, dtype=np.float64, **kw):
+    """The reference's explicit-interface recipe one step out of `raster_pullback!`
+    (/root/reference/README.md:151-165): form the sensitivity of a squared-error loss on the
+    host, `ds_dout = scale .* (out .- target)` (README.md:151 is the scale = -2 case,
+    examples/logo.jl:40-44 the loss whose gradient is scale = +2), then call the pullback.
+    Returns (PullbackResult, loss[B]) with loss[b] = sum((out - target)[..., b] ** 2)."""
+    dtype = np.dtype(dtype)
+    out = np.asarray(out, dtype=dtype)
+    target = np.asarray(target, dtype=dtype)
+    assert out.shape == target.shape
+    resid = out - target
+    ds_dout = (dtype.type(scale) * resid).astype(dtype)
+    res = raster_pullback(ds_dout, points, rotation, translation, out_weight, point_weight,
+                          dtype=dtype, **kw)
+    loss = (resid.astype(np.float64) ** 2).reshape(-1, out.shape[-1]).sum(axis=0)
+    return res, loss

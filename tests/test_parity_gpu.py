@@ -323,6 +323,100 @@ def test_heavy_tiles_are_split(oracle, dev, npdt, tdt, n_in, n_out, grid_n):
     _compare(ref_out, ref_pb, out, pb, npdt)
 
 
+# ------------------------------------------------------------------ residual pullback
+def test_readme_gradient_example_fused(dev, golden):
+    """README.md:151-183 with the sensitivity formed inside the pullback kernels: scale = -2
+    reproduces the README's `ds_dout = 2 .* (target .- raster(...))` literally."""
+    g = golden["readme_gradient"]
+    pts = T(np.array(g["points"]), dev)
+    R = T(np.array(g["rotation"]), dev)
+    t = T(np.array(g["translation"]), dev)
+    target = T(np.array(g["target_image"]), dev)
+    for algo in ("atomic", "tiled"):
+        out = dpr_amd.raster((5, 5), pts, R, t, algo=algo)
+        pb, loss = dpr_amd.raster_residual_pullback_(out, target, pts, R, t, scale=-2.0, algo=algo)
+        full = -np.array(g["ds_dpoints_zygote_full_precision_negated"])
+        np.testing.assert_allclose(pb.points.cpu().numpy(), full, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(pb.rotation.cpu().numpy(), np.array(g["ds_drotation"]),
+                                   rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(pb.translation.cpu().numpy(), np.array(g["ds_dtranslation"]),
+                                   rtol=0, atol=2e-5)
+        assert loss.ndim == 0
+        np.testing.assert_allclose(float(loss), float(((out - target) ** 2).sum()), rtol=1e-12)
+
+
+@pytest.mark.parametrize("algo", ["atomic", "tiled"])
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out", SHAPES)
+def test_residual_pullback_equals_oracle_recipe(oracle, dev, algo, npdt, tdt, n_in, n_out):
+    """dpr_raster_residual_pullback_* against the oracle's host recipe (ds_dout = scale *
+    (out - target), then raster_pullback; README.md:151-165) and against the un-fused device
+    path, batched, with every optional argument and points outside the grid."""
+    d = D.make(n_points=20_000, n_in=n_in, n_out=n_out, batch=3, grid_n=36, seed=33, dtype=npdt)
+    d.points[::9] *= 3.0
+    rng = np.random.default_rng(34)
+    target = np.asfortranarray(rng.normal(size=d.grid + (d.batch,)).astype(npdt))
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(d.point_weights, dev))
+    out = dpr_amd.raster(d.grid, *args, algo=algo)
+    tgt = grid_to_dev(target, dev)
+    loss_buf = torch.empty(d.batch, dtype=tdt, device=dev)
+    pb, loss = dpr_amd.raster_residual_pullback_(out, tgt, *args, scale=2.0, loss=loss_buf, algo=algo)
+    assert loss.data_ptr() == loss_buf.data_ptr()
+    # (1) oracle recipe on the DEVICE's `out` (isolates the pullback from forward rounding)
+    ref_pb, ref_loss = oracle.residual_pullback(out.cpu().numpy(), target, d.points, d.rotations,
+                                                d.translations, d.weights, d.point_weights,
+                                                scale=2.0, dtype=npdt)
+    assert_close(pb.points, ref_pb.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.point_weight, ref_pb.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    assert_close(pb.rotation, ref_pb.rotation, tol(npdt, "pose"), "ds_drotation")
+    assert_close(pb.translation, ref_pb.translation, tol(npdt, "pose"), "ds_dtranslation")
+    assert_close(pb.background, ref_pb.background, tol(npdt, "pose"), "ds_dbackground")
+    assert_close(pb.out_weight, ref_pb.out_weight, tol(npdt, "pose"), "ds_dout_weight")
+    assert_close(loss, ref_loss.astype(npdt), tol(npdt, "out"), "loss")
+    # (2) the un-fused device path on the same sensitivity: the tiled kernels see bit-identical
+    # values, so the per-point results agree bitwise (the per-pose sums depend on the record
+    # order inside a tile, which the binning's atomics do not fix)
+    unfused = dpr_amd.raster_pullback_(2.0 * (out - tgt), *args, algo=algo)
+    if algo == "tiled":
+        assert torch.equal(pb.points, unfused.points)
+        assert torch.equal(pb.point_weight, unfused.point_weight)
+        assert_close(pb.rotation, unfused.rotation.cpu().numpy(), tol(npdt, "pose"), "rot")
+        assert_close(pb.background, unfused.background.cpu().numpy(), tol(npdt, "pose"), "bg")
+    else:  # global atomics: same values, unordered sums
+        assert_close(pb.points, unfused.points.cpu().numpy(), tol(npdt, "points"), "pts")
+        assert_close(pb.rotation, unfused.rotation.cpu().numpy(), tol(npdt, "pose"), "rot")
+
+
+def test_residual_pullback_reuses_forward_binning_and_rejects_chunked(oracle, dev):
+    """The training-step pairing: raster_(keep_binning) -> residual pullback (reuse_binning),
+    one pose, clustered cloud so that split tiles are covered too."""
+    npdt, tdt = np.float32, torch.float32
+    d = D.make(n_points=60_000, n_in=3, n_out=3, batch=1, grid_n=70, seed=35, dtype=npdt)
+    d.points[: 40_000] *= npdt(0.1)
+    rng = np.random.default_rng(36)
+    target = np.asfortranarray(rng.normal(size=d.grid + (1,)).astype(npdt))
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), None)
+    ws = torch.empty(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 1, 3, tdt, "tiled"),
+                     dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, 1, tdt, dev)
+    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=True)
+    tgt = grid_to_dev(target, dev)
+    pb, loss = dpr_amd.raster_residual_pullback_(out, tgt, *args, algo="tiled", workspace=ws,
+                                                 reuse_binning=True)
+    ref_pb, ref_loss = oracle.residual_pullback(out.cpu().numpy(), target, d.points, d.rotations,
+                                                d.translations, d.weights, None, dtype=npdt)
+    assert_close(pb.points, ref_pb.points, 1e-4, "ds_dpoints")
+    assert_close(pb.rotation, ref_pb.rotation, 1e-3, "ds_drotation")
+    assert_close(pb.background, ref_pb.background, 1e-3, "ds_dbackground")
+    assert_close(loss, ref_loss.astype(npdt), 5e-5, "loss")
+    with pytest.raises(dpr_amd.DprError):
+        dpr_amd.raster_residual_pullback_(out, tgt, *args, algo="chunked")
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster_residual_pullback_(out, tgt[1:], *args)
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
