@@ -9,7 +9,9 @@ A "step" is one raster! + one raster_pullback! of this rank's pose over the full
 cloud, inputs already resident in HBM.  At N > 1 the global problem is a batch of N poses
 sharded one per rank (weak scaling) and each step ends with the all-reduce(sum) of the
 fused [ds_dpoints | ds_dpoint_weight] buffer -- the only exchange the batched pullback has
-(/root/reference/src/raster_pullback.jl:141,146).
+(/root/reference/src/raster_pullback.jl:141,146).  By default that all-reduce runs on RCCL's
+stream while the next step's kernels run (double-buffered; all of them complete inside the
+timed region); `--no-overlap-exchange` serialises it.
 
 Besides the contract's JSON line fields this prints `roofline` (dominant kernel, HIP-event
 timed on the stream the kernels run on) and, on rank 0 at N = 1, `cpu_baseline` (the CPU
@@ -147,6 +149,8 @@ def main():
     ap.add_argument("--order", default="random", choices=["random", "morton"],
                     help="point order in memory: as generated, or pre-sorted (pose-independent)")
     ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform", "tight"])
+    ap.add_argument("--no-overlap-exchange", action="store_true",
+                    help="N > 1: finish each step's all-reduce before the next step starts")
     ap.add_argument("--no-share-binning", action="store_true",
                     help="make the pullback redo the binning instead of reusing the forward's")
     ap.add_argument("--no-secondary", action="store_true",
@@ -209,21 +213,47 @@ def main():
                                  ds_dpoints=d_pts, ds_dpoint_weight=d_pw, algo=algo_b,
                                  workspace=ws, reuse_binning=reuse)
 
-    def exchange():
+    # Exchange of the point gradients (N > 1).  Default: the all-reduce of step k runs on RCCL's
+    # own stream while step k+1 computes into the other half of a double buffer (a rank that
+    # works through its poses one after the other overlaps exactly like this); every
+    # all-reduce is finished before the timed region's closing barrier.  --no-overlap-exchange
+    # waits for it inside the step.
+    overlap = world > 1 and backend == "nccl" and not args.no_overlap_exchange
+    fused_alt = torch.empty_like(fused) if overlap else None
+    pending = [None, None]
+    step_no = [0]
+
+    def exchange(buf):
         if world > 1:
             if backend == "nccl":
-                dist.all_reduce(fused, op=dist.ReduceOp.SUM)
-            else:
-                host = fused.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                fused.copy_(host)
+                return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=overlap)
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        return None
 
     def step():
+        k = step_no[0] & 1 if overlap else 0
+        step_no[0] += 1
+        buf = fused_alt if k else fused
+        if pending[k] is not None:
+            pending[k].wait()  # the launch stream waits until this buffer's all-reduce is done
+            pending[k] = None
         fwd()
-        bwd()
-        exchange()
+        dpr_amd.raster_pullback_(inp["ds_dout"], inp["points"], inp["R"], inp["t"],
+                                 ds_dpoints=buf[: P * n_in].view(P, n_in),
+                                 ds_dpoint_weight=buf[P * n_in:], algo=algo_b, workspace=ws,
+                                 reuse_binning=share)
+        pending[k] = exchange(buf)
+
+    def drain():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -303,6 +333,8 @@ def main():
                    "algo": {"raster": algo_f, "pullback": algo_b}, "pullback_reuses_forward_binning": share,
                    "poses_global": world, "point_order": args.order,
                    "exchange": (f"all-reduce(sum) of [ds_dpoints|ds_dpoint_weight] ({backend})"
+                                + (", overlapped with the next step's kernels (double buffer)"
+                                   if overlap else ", inside the step")
                                 if world > 1 else "none")},
         "roofline": roof,
     }
