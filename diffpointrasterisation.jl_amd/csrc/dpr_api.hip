@@ -109,6 +109,17 @@ static int raster_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t
     return DPR_OK;
 }
 
+// The kernels move records as 16/32-byte vectors and scalars as T: a misaligned pointer
+// would fault on the device, so it is refused here.
+template <typename T>
+static int check_alignment(const void* ws, const void* a, const void* b) {
+    if (ws && ((uintptr_t)ws & 255))
+        return fail(DPR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (((uintptr_t)a | (uintptr_t)b) & (sizeof(T) - 1))
+        return fail(DPR_ERR_INVALID_ARG, "a data pointer is not aligned to its element type");
+    return DPR_OK;
+}
+
 template <typename T>
 static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid, int64_t P,
                        int64_t B, T* out, const T* points, const T* rot, const T* trans,
@@ -121,6 +132,7 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
     if (P > 0 && !points) return fail(DPR_ERR_INVALID_ARG, "points is NULL with P > 0");
     if ((P + kBlock - 1) / kBlock > 0x7fffffffLL)
         return fail(DPR_ERR_INVALID_ARG, "P too large");
+    if (int rc = check_alignment<T>(ws, out, points)) return rc;
     hipStream_t st = (hipStream_t)stream;
     algo = resolve_algo(algo, DPR_OP_RASTER, n_out, grid, P, B, G);
     stage_mark(st);
@@ -218,6 +230,8 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     if (!rot || !trans) return fail(DPR_ERR_INVALID_ARG, "rotation/translation is NULL");
     if (!d_rot || !d_trans || !d_bg || !d_ow)
         return fail(DPR_ERR_INVALID_ARG, "a per-pose output pointer is NULL");
+    if (int rc = check_alignment<T>(ws, g, points)) return rc;
+    if (int rc = check_alignment<T>(nullptr, d_pts, rs.target)) return rc;
     algo = resolve_algo(algo, DPR_OP_PULLBACK, n_out, grid, P, B, G);
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                         \

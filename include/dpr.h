@@ -111,7 +111,9 @@ int dpr_stage_timing_begin(void **events, int capacity);
 int dpr_stage_timing_end(void);
 
 /* Bytes of caller-provided device workspace needed by `op` with `algo`
- * (may be 0).  Returns (size_t)-1 on invalid arguments. */
+ * (may be 0).  Returns (size_t)-1 on invalid arguments.  The workspace pointer must be
+ * 256-byte aligned (DPR_ERR_WORKSPACE otherwise; hipMalloc / AMDGPU.jl / torch allocations
+ * are); data pointers must be aligned to their element type. */
 size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B);
 size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t *grid,

@@ -128,9 +128,25 @@ def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
     L = dpr_amd.lib()
     grid = np.array([64, 64, 64], dtype=np.int64)
     gp = grid.ctypes.data_as(ctypes.c_void_p)
-    dummy = (ctypes.c_double * 64)()
-    d = ctypes.cast(dummy, ctypes.c_void_p)
+    dummy = (ctypes.c_char * 1024)()
+    d = ctypes.c_void_p((ctypes.addressof(dummy) + 255) & ~255)  # 256-byte aligned
     fn = getattr(L, f"dpr_raster_ex_{suf}")
+    # misaligned workspace / data pointers would fault on the device: refused
+    odd = ctypes.c_void_p(d.value + 4)
+    rc = fn(None, dpr_amd._lib.ALGO_TILED, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, odd,
+            1 << 30)
+    assert rc == dpr_amd._lib.ERR_WORKSPACE and "aligned" in dpr_amd._lib.last_error()
+    rc = fn(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, ctypes.c_void_p(d.value + 2), d,
+            d, d, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "aligned" in dpr_amd._lib.last_error()
+    # the residual pullback needs a target and has no chunked variant
+    rp = getattr(L, f"dpr_raster_residual_pullback_ex_{suf}")
+    rc = rp(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, d, None, 2.0, d, d, d, None, None,
+            None, *([d] * 6), None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "target" in dpr_amd._lib.last_error()
+    rc = rp(None, dpr_amd._lib.ALGO_CHUNKED, 0, 3, 3, gp, 1000, 1, d, d, 2.0, d, d, d, None, None,
+            None, *([d] * 6), d, 1 << 30)
+    assert rc == dpr_amd._lib.ERR_UNSUPPORTED_ALGO
     # tiled needs a workspace
     rc = fn(None, dpr_amd._lib.ALGO_TILED, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_WORKSPACE and "workspace" in dpr_amd._lib.last_error()
@@ -154,5 +170,6 @@ def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
     srt = getattr(L, f"dpr_sort_points_{suf}")
     assert srt(None, 4, 10, d, d, d, None, None, d, 1 << 20) == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
     assert srt(None, 3, 10, d, d, d, d, None, d, 1 << 20) == dpr_amd._lib.ERR_INVALID_ARG
-    d2 = ctypes.cast((ctypes.c_double * 64)(), ctypes.c_void_p)
+    dummy2 = (ctypes.c_char * 1024)()
+    d2 = ctypes.c_void_p((ctypes.addressof(dummy2) + 255) & ~255)
     assert srt(None, 3, 10, d, d2, d, None, None, d, 8) == dpr_amd._lib.ERR_WORKSPACE
