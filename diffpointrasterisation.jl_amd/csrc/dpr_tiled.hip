@@ -2,7 +2,9 @@
 // work item (a tile, or a part of a heavily loaded tile) that keeps the tile in LDS.
 // No global float atomics anywhere on this path.  DESIGN.md 4.2 has the table of stages.
 //
-// Per pose b (sequential launches on the caller's stream, workspace reused):
+// Per pose b -- or per POSE GROUP of up to 16 poses when the grid has few tiles (bins are then
+// (pose, tile) pairs; see pose_group()) -- sequential launches on the caller's stream,
+// workspace reused:
 //   count    k_count        each block histograms its slice of the points by PRIMARY tile (the
 //                           tile holding max(ref,0)) in LDS -> one row of the counts table
 //   scan     k_colscan      column-wise exclusive prefix of the table + tile totals
@@ -29,6 +31,7 @@
 //   DPR_SCATTER_WC=0     plain scatter instead of the write-combining one
 //   DPR_SPLAT_BLOCKED=0  lane-adjacent (strided) instead of blocked record assignment
 //   DPR_BWD_UNPERMUTE=0  owner threads store ds_dpoints directly instead of un-permuting
+//   DPR_POSE_GROUP=n     at most n poses per group (1 = per-pose pipeline)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -193,30 +196,57 @@ __device__ __forceinline__ unsigned xcd_slice(unsigned block, unsigned nblocks) 
 }
 
 // ------------------------------------------------------------------ K1: count
-template <typename T, int NI, int NO>
+template <typename T, int NI, int NO, bool GROUP>
 __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom<NO> tg, int64_t P,
                                                        int64_t chunk, const T* __restrict__ points,
                                                        const T* __restrict__ rot,
-                                                       const T* __restrict__ trans, int64_t b,
-                                                       uint32_t* __restrict__ counts) {
+                                                       const T* __restrict__ trans, int64_t b0,
+                                                       int nb, uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t hist[];
-    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) hist[i] = 0;
+    const int NTe = tg.NT * nb;  // bins = (pose of the group, tile)
+    for (int i = threadIdx.x; i < NTe; i += kBinThreads) hist[i] = 0;
     __syncthreads();
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
     const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
-    for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
-        T pt[NI];
-        load_point<T, NI>(points, p, pt);
-        int ref0[NO];
-        T dlo[NO];
-        if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo))
-            atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
+    if (!GROUP) {
+        const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0);
+        for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
+            T pt[NI];
+            load_point<T, NI>(points, p, pt);
+            int ref0[NO];
+            T dlo[NO];
+            if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo))
+                atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
+        }
+    } else {
+        // a pose group: each point is read once and classified for every pose of the group
+        // (pose parameters are wave-uniform scalar loads, amortised over kPB points)
+        constexpr int kPB = 4;
+        for (int64_t base = lo; base < hi; base += (int64_t)kPB * kBinThreads) {
+            T pt[kPB][NI];
+            bool live[kPB];
+#pragma unroll
+            for (int k = 0; k < kPB; ++k) {
+                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                live[k] = p < hi;
+                load_point<T, NI>(points, live[k] ? p : hi - 1, pt[k]);
+            }
+            for (int j = 0; j < nb; ++j) {
+                const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + j);
+#pragma unroll
+                for (int k = 0; k < kPB; ++k) {
+                    int ref0[NO];
+                    T dlo[NO];
+                    if (ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && live[k])
+                        atomicAdd(&hist[j * tg.NT + primary_tile<NO>(ref0, tg)], 1u);
+                }
+            }
+        }
     }
     __syncthreads();
-    uint32_t* row = counts + (size_t)slice * tg.NT;
-    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) row[i] = hist[i];
+    uint32_t* row = counts + (size_t)slice * NTe;
+    for (int i = threadIdx.x; i < NTe; i += kBinThreads) row[i] = hist[i];
 }
 
 // ------------------------------------------------------------------ K2: scans
@@ -416,40 +446,40 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
 // one 64-lane store instruction then covers a few contiguous runs instead of 64 unrelated
 // 16-byte pieces (measured: 10 M scattered 16-byte stores cost ~75 us more than coalesced
 // ones, profiles/r01_experiments.md).
-//   LDS: cursor[NT] (dynamic) | lhist[NT] (dynamic) | recs[S] | dest[S]
-template <typename T, int NI, int NO, bool HAS_PW, int S>
+//   LDS: cursor[NT * nb] (dynamic) | lhist[NT] (dynamic) | recs[S] | dest[S]
+template <typename T, int NI, int NO, bool HAS_PW, int S, bool GROUP>
 __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
-    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
-    const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
+    int nb, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
     Rec4<T>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
     T* __restrict__ ds_dpw, int zero_dropped) {
     constexpr int PPT = S / kBinThreads;  // points per thread per sub-chunk
+    // Pose group (nb > 1): the S points of a sub-chunk stay in registers while the poses of the
+    // group are binned one after the other, each into its own NT bins -- the runs that are
+    // written out stay as long as in the single-pose case, the points are read once per group.
+    if (!GROUP) nb = 1;  // compile-time trip count: the single-pose kernel keeps its registers
+    const int NT = tg.NT, NTe = NT * nb;
+    const uint32_t Pe = (uint32_t)(P * nb);  // spare slot (rejected point-poses)
     extern __shared__ uint32_t dyn[];
-    uint32_t* cursor = dyn;
-    uint32_t* lhist = dyn + tg.NT;
+    uint32_t* cursor = dyn;        // [NTe]
+    uint32_t* lhist = dyn + NTe;   // [NT]
     __shared__ Rec4<T> recs[S];
     __shared__ uint32_t dest[S];
     __shared__ uint32_t wsum[kBinThreads / kWave];
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
-    const uint32_t* row = prefix + (size_t)slice * tg.NT;
-    for (int i = threadIdx.x; i < tg.NT; i += kBinThreads) {
-        cursor[i] = tile_start[i] + row[i];
-        lhist[i] = 0;
-    }
+    const uint32_t* row = prefix + (size_t)slice * NTe;
+    for (int i = threadIdx.x; i < NTe; i += kBinThreads) cursor[i] = tile_start[i] + row[i];
+    for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
     __syncthreads();
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
     const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
     // bins owned by this thread in the scan / cursor update
-    const int bpt = (tg.NT + kBinThreads - 1) / kBinThreads;
+    const int bpt = (NT + kBinThreads - 1) / kBinThreads;
     const int bin0 = threadIdx.x * bpt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     for (int64_t base = lo; base < hi; base += S) {
-        // a. load, classify, rank inside (sub-chunk, tile)
         T pt[PPT][NI], w[PPT];
-        int tile[PPT];
-        uint32_t lrank[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
@@ -457,75 +487,81 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             load_point<T, NI>(points, pl, pt[k]);
             w[k] = HAS_PW ? pw[pl] : T(1);
         }
+        for (int jp = 0; jp < (GROUP ? nb : 1); ++jp) {
+            const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
+            uint32_t* cur = cursor + jp * NT;
+            uint32_t* slot_j = slot_of ? slot_of + (size_t)jp * P : nullptr;
+            // a. classify, rank inside (sub-chunk, tile)
+            int tile[PPT];
+            uint32_t lrank[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
-            int ref0[NO];
-            T dlo[NO];
-            const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
-            tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
-            lrank[k] = 0;
-            if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
-        }
-        __syncthreads();
-        // b. exclusive scan of lhist (in place); keep the owned counts for the cursor update
-        uint32_t cnt_sum = 0;
-        for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) cnt_sum += lhist[i];
-        uint32_t incl = cnt_sum;
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                int ref0[NO];
+                T dlo[NO];
+                const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
+                tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+                lrank[k] = 0;
+                if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
+            }
+            __syncthreads();
+            // b. exclusive scan of lhist (in place)
+            uint32_t cnt_sum = 0;
+            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) cnt_sum += lhist[i];
+            uint32_t incl = cnt_sum;
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += v;
-        }
-        if (lane == kWave - 1) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - cnt_sum;
-        for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
-        uint32_t n_valid = 0;
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o, kWave);
+                if (lane >= o) incl += v;
+            }
+            if (lane == kWave - 1) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - cnt_sum;
+            for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
+            uint32_t n_valid = 0;
 #pragma unroll
-        for (int wv = 0; wv < kBinThreads / kWave; ++wv) n_valid += wsum[wv];
-        for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) {
-            const uint32_t c = lhist[i];
-            lhist[i] = run;  // exclusive offset inside the sub-chunk
-            run += c;
-        }
-        __syncthreads();
-        // c. place into LDS in tile order; remember the global destination
+            for (int wv = 0; wv < kBinThreads / kWave; ++wv) n_valid += wsum[wv];
+            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) {
+                const uint32_t c = lhist[i];
+                lhist[i] = run;  // exclusive offset inside the sub-chunk
+                run += c;
+            }
+            __syncthreads();
+            // c. place into LDS in tile order; remember the global destination
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
-            if (tile[k] >= 0) {
-                const uint32_t sidx = lhist[tile[k]] + lrank[k];
-                const uint32_t d = cursor[tile[k]] + lrank[k];
-                Rec4<T> r;
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                if (tile[k] >= 0) {
+                    const uint32_t sidx = lhist[tile[k]] + lrank[k];
+                    const uint32_t d = cur[tile[k]] + lrank[k];
+                    Rec4<T> r;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
-                r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
-                recs[sidx] = r;
-                dest[sidx] = d;
-                if (slot_of) slot_of[p] = d;
-            } else if (p < hi) {
-                if (slot_of) slot_of[p] = (uint32_t)P;  // spare slot
-                if (zero_dropped) {
+                    for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
+                    r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+                    recs[sidx] = r;
+                    dest[sidx] = d;
+                    if (slot_j) slot_j[p] = d;
+                } else if (p < hi) {
+                    if (slot_j) slot_j[p] = Pe;  // spare slot
+                    if (zero_dropped) {
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-                    ds_dpw[p] = T(0);
+                        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
+                        ds_dpw[p] = T(0);
+                    }
                 }
             }
-        }
-        __syncthreads();
-        // d. write-out in LDS (= tile) order; e. advance cursors, clear the histogram
-        for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[dest[i]] = recs[i];
-        {
+            __syncthreads();
+            // d. write-out in LDS (= tile) order; e. advance cursors, clear the histogram
+            for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[dest[i]] = recs[i];
             // counts of the owned bins = differences of the exclusive offsets
-            for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) {
-                const uint32_t nxt = (i + 1 < tg.NT) ? lhist[i + 1] : n_valid;
-                cursor[i] += nxt - lhist[i];
+            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) {
+                const uint32_t nxt = (i + 1 < NT) ? lhist[i + 1] : n_valid;
+                cur[i] += nxt - lhist[i];
             }
+            __syncthreads();
+            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) lhist[i] = 0;
+            __syncthreads();
         }
-        __syncthreads();
-        for (int i = bin0; i < bin0 + bpt && i < tg.NT; ++i) lhist[i] = 0;
-        __syncthreads();
     }
 }
 
@@ -535,7 +571,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
     const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
     const uint32_t* __restrict__ tile_slab, const T* __restrict__ rot,
-    const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b,
+    const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
     T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NV = tile_voxels<NO>();
@@ -543,7 +579,9 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
     const WorkItem item = items[blockIdx.x];
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
-    const int tile = (int)item.tile;
+    // item.tile = (pose within the group) * NT + tile
+    const int tile = (int)(item.tile % (uint32_t)tg.NT);
+    const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
@@ -643,7 +681,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     if ((item.part_nparts >> 16) > 1) {
         // part of a split tile: the whole LDS tile goes to this part's overflow slab;
         // k_halo_gather sums the parts
-        T* slab = ovf + (size_t)(tile_slab[tile] + (item.part_nparts & 0xffffu)) * NVH;
+        T* slab = ovf + (size_t)(tile_slab[item.tile] + (item.part_nparts & 0xffffu)) * NVH;
         for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)acc[i];
         return;
     }
@@ -666,7 +704,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         if (ok) o[off] = (T)(bgv + acc[lds_index<NO>(l)]);
     }
     // upper halo -> compact per-tile buffer (always fully written, zeros included)
-    T* hb = halo + (size_t)tile * halo_count<NO>();
+    T* hb = halo + (size_t)item.tile * halo_count<NO>();
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) {
         int h[NO], rem = i;
         bool is_halo = false;
@@ -732,35 +770,39 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
                                                      const uint32_t* __restrict__ tile_slab,
                                                      const uint32_t* __restrict__ split_list,
                                                      const uint32_t* __restrict__ n_split,
-                                                     const T* __restrict__ bg, int64_t b,
-                                                     T* __restrict__ out) {
+                                                     const T* __restrict__ bg, int64_t b0,
+                                                     int nb, T* __restrict__ out) {
     constexpr int NV = tile_voxels<NO>();
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int CH = kSplitBlocks;  // blocks sharing the owned voxels of one split tile
-    // blocks [0, NT): the low faces of an unsplit tile; blocks NT + s*CH + c: every CH-th
-    // 256-voxel chunk of the s-th split tile (all of its owned voxels)
-    int tile, i_begin, i_end;
+    // blocks [0, NT*nb): the low faces of an unsplit (pose, tile); blocks NT*nb + s*CH + c: every
+    // CH-th 256-voxel chunk of the s-th split tile (all of its owned voxels)
+    const int NTe = tg.NT * nb;
+    int ptile, i_begin, i_end;
     bool split;
     const bool any_split = *n_split != 0;  // uniform; the common case has no split tile
-    if ((int)blockIdx.x < tg.NT) {
-        tile = blockIdx.x;
+    if ((int)blockIdx.x < NTe) {
+        ptile = blockIdx.x;
         split = false;
-        if (any_split && tile_parts[tile] > 1) return;  // handled by its chunk blocks
+        if (any_split && tile_parts[ptile] > 1) return;  // handled by its chunk blocks
         i_begin = 0;
         i_end = low_face_count<NO>();
     } else {
-        const int sidx = ((int)blockIdx.x - tg.NT) / CH, c = ((int)blockIdx.x - tg.NT) % CH;
+        const int sidx = ((int)blockIdx.x - NTe) / CH, c = ((int)blockIdx.x - NTe) % CH;
         if (!any_split || sidx >= (int)*n_split) return;
-        tile = (int)split_list[sidx];
+        ptile = (int)split_list[sidx];
         split = true;
         i_begin = c * 256;
         i_end = NV;
     }
+    const int tile = ptile % tg.NT;
+    const int pbase = ptile - tile;  // first bin of this pose
+    const int64_t b = b0 + ptile / tg.NT;
     const int i_step = split ? 256 * CH : 256;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     T* o = out + b * gd.G;
-    const uint32_t my_parts = split ? tile_parts[tile] : 1u;
+    const uint32_t my_parts = split ? tile_parts[ptile] : 1u;
     const double bgv = bg ? (double)bg[b] : 0.0;
     for (int i = i_begin + threadIdx.x; i < i_end; i += i_step) {
         int l[NO];
@@ -801,6 +843,7 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
                     tstride *= tg.nt[d];
                 }
                 if (!valid) continue;
+                src += pbase;
                 const uint32_t sp = any_split ? tile_parts[src] : 1u;
                 if (sp > 1) {
                     const T* slab = ovf + (size_t)tile_slab[src] * NVH + lds_index<NO>(h);
@@ -811,7 +854,7 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
             }
         }
         if (split) {
-            const T* slab = ovf + (size_t)tile_slab[tile] * NVH + lds_index<NO>(l);
+            const T* slab = ovf + (size_t)tile_slab[ptile] * NVH + lds_index<NO>(l);
             double own = bgv;
             for (uint32_t q = 0; q < my_parts; ++q) own += (double)slab[(size_t)q * NVH];
             o[off] = (T)(own + add);
@@ -831,7 +874,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, int64_t P,
     const uint32_t* __restrict__ rec_idx, const WorkItem* __restrict__ items,
     const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
-    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b,
+    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b0,
     T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials,
     Residual<T> rs) {
     constexpr int NVH = tile_voxels_halo<NO>();
@@ -841,7 +884,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     __shared__ double red[NW][NVAL];
     if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
     const WorkItem item = items[blockIdx.x];
-    const int tile = (int)item.tile;
+    const int tile = (int)(item.tile % (uint32_t)tg.NT);
+    const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     const T* gb = g + b * gd.G;
@@ -1032,16 +1076,23 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
 }
 
 // ------------------------------------------------------------------ pullback un-permute
-// thread per ORIGINAL point: gradient record of its slot -> ds_dpoints / ds_dpoint_weight
-// (coalesced stores; accumulating over poses when !FIRST_POSE).
+// thread per ORIGINAL point: gradient record(s) of its slot(s) -> ds_dpoints /
+// ds_dpoint_weight (coalesced stores; accumulating over poses when !FIRST_POSE).  A pose
+// group contributes nb records per point, summed here in registers.
 template <typename T, int NI, bool FIRST_POSE>
-__global__ __launch_bounds__(256) void k_unpermute(int64_t P, const Rec4<T>* __restrict__ grad,
+__global__ __launch_bounds__(256) void k_unpermute(int64_t P, int nb,
+                                                   const Rec4<T>* __restrict__ grad,
                                                    const uint32_t* __restrict__ slot_of,
                                                    T* __restrict__ ds_dpoints,
                                                    T* __restrict__ ds_dpw) {
     const int64_t p = (int64_t)xcd_slice(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (p >= P) return;
-    const Rec4<T> g = grad[slot_of[p]];
+    Rec4<T> g = grad[slot_of[p]];
+    for (int j = 1; j < nb; ++j) {
+        const Rec4<T> gj = grad[slot_of[(size_t)j * P + p]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.v[k] += gj.v[k];
+    }
     if (FIRST_POSE) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = g.v[j];
@@ -1054,11 +1105,13 @@ __global__ __launch_bounds__(256) void k_unpermute(int64_t P, const Rec4<T>* __r
 }
 
 // ------------------------------------------------------------------ pullback K5
-// partials[NVAL][NT] (f64) -> the per-pose outputs of pose b.  One block per scalar.
+// partials[NVAL][items] (f64) -> the per-pose outputs.  One block per (scalar, pose of the
+// group); an item belongs to pose item.tile / NT.
 template <typename T, int NI, int NO>
 __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__ partials,
+                                                      const WorkItem* __restrict__ items,
                                                       const uint32_t* __restrict__ n_items,
-                                                      int max_items, int64_t b,
+                                                      int max_items, int NT, int64_t b0,
                                                       T* __restrict__ ds_drotation,
                                                       T* __restrict__ ds_dtranslation,
                                                       T* __restrict__ ds_dbackground,
@@ -1066,9 +1119,16 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
                                                       T* __restrict__ loss) {
     __shared__ double wsum[16];
     const int k = blockIdx.x;
+    const uint32_t j = blockIdx.y;
+    const int64_t b = b0 + j;
     double s = 0.0;
     const int n = (int)*n_items;
-    for (int t = threadIdx.x; t < n; t += 1024) s += partials[(size_t)k * max_items + t];
+    if (gridDim.y == 1) {
+        for (int t = threadIdx.x; t < n; t += 1024) s += partials[(size_t)k * max_items + t];
+    } else {
+        for (int t = threadIdx.x; t < n; t += 1024)
+            if (items[t].tile / (uint32_t)NT == j) s += partials[(size_t)k * max_items + t];
+    }
     s = wave_sum<double>(s);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -1102,6 +1162,7 @@ static int env_int(const char* name, int dflt) {
 // binning a raster call left behind, DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING):
 //   counts table | totals | tile_start | work items, n_items, tile_parts, tile_slab | records | indices | slot_of | aux (halo / partials)
 struct Plan {
+    int bg;          // poses binned together (pose group, a power of two; 1 = per-pose pipeline)
     int nblk;
     int64_t chunk;
     uint32_t cap;    // records per work item above which a tile is split
@@ -1111,15 +1172,34 @@ struct Plan {
         off_split, off_rec, off_idx, off_slot, off_aux, total;
 };
 
-static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
+// Pose groups: with few tiles per pose (2-D projections, small 3-D grids) the bins become
+// (pose, tile) pairs of up to kMaxGroup poses, as long as they fit the write-combining
+// scatter's 4096 LDS cursors: the points are read once per group instead of once per pose and
+// the fixed per-launch costs (scans, halo pass, reductions, launch gaps) are shared.  Measured
+// (tools/pose_group_probe.py): 10 M points -> 512^2, 485 -> 383 us per pose (fwd + bwd);
+// 1 M points -> 128^3, 149 -> 65 us per pose.
+constexpr int kMaxGroup = 16;
+static int pose_group(int NT, int64_t P, int64_t B) {
+    const int limit = env_int("DPR_POSE_GROUP", kMaxGroup);
+    int bg = 1;
+    while (bg * 2 <= limit && bg * 2 <= kMaxGroup && bg * 2 <= B && NT * bg * 2 <= 4096 &&
+           P * bg * 2 <= ((int64_t)1 << 27))  // records of a group: <= 2 GiB (fp32)
+        bg *= 2;
+    return bg;
+}
+
+static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B) {
     Plan pl;
-    int64_t nblk = (P + 8191) / 8192;
+    pl.bg = pose_group(NT1, P1, B);
+    const int NT = NT1 * pl.bg;          // bins
+    const int64_t P = P1 * pl.bg;        // records
+    int64_t nblk = (P1 + 8191) / 8192;
     if (nblk < 1) nblk = 1;
     if (nblk > kMaxBinBlocks) nblk = kMaxBinBlocks;
-    int64_t chunk = (P + nblk - 1) / nblk;
+    int64_t chunk = (P1 + nblk - 1) / nblk;
     chunk = (chunk + kBinThreads - 1) / kBinThreads * kBinThreads;
     if (chunk < kBinThreads) chunk = kBinThreads;
-    nblk = (P + chunk - 1) / chunk;
+    nblk = (P1 + chunk - 1) / chunk;
     if (nblk < 1) nblk = 1;
     pl.nblk = (int)nblk;
     pl.chunk = chunk;
@@ -1157,7 +1237,7 @@ static Plan make_plan(size_t elem, int n_out, int NT, int64_t P) {
     pl.off_rec = o;
     o += align_up((size_t)(P + 1) * 4 * elem);  // + spare slot for rejected points
     pl.off_idx = o;
-    o += align_up((size_t)(P + 1) * 4);
+    o += align_up((size_t)(P1 + 1) * 4);
     pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
     pl.off_aux = o;
@@ -1194,7 +1274,6 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
 
 size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
                              int64_t P, int64_t B) {
-    (void)B;
     (void)op;
     (void)n_in;
     int NT;
@@ -1207,7 +1286,7 @@ size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int
         if (!make_geom<2>(grid, &tg)) return (size_t)-1;
         NT = tg.NT;
     }
-    return make_plan(elem, n_out, NT, P).total;
+    return make_plan(elem, n_out, NT, P, B).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -1227,21 +1306,26 @@ template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
 template <typename T, int NI, int NO, bool HAS_PW, bool WANT_IDX>
 static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                           const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
-                          const T* rot, const T* trans, int64_t b, T* d_pts, T* d_pw,
+                          const T* rot, const T* trans, int64_t b, int nb, T* d_pts, T* d_pw,
                           int zero_dropped) {
     // write-combining variant: needs 2 NT counters + the sub-chunk in LDS, and does not
     // produce rec_idx (only the direct-store pullback mode with point weights reads that)
-    const int wc = env_int("DPR_SCATTER_WC", 1);
-    const bool needs_idx = HAS_PW && WANT_IDX && env_int("DPR_BWD_UNPERMUTE", 1) == 0;
-    if (wc && tg.NT <= 4096 && !needs_idx) {
+    const int wc = env_int("DPR_SCATTER_WC", 1) || nb > 1;
+    const bool needs_idx =
+        HAS_PW && WANT_IDX && env_int("DPR_BWD_UNPERMUTE", 1) == 0 && nb == 1;
+    if (wc && tg.NT * nb <= 4096 && !needs_idx) {
         constexpr int S = (sizeof(T) == 4) ? 4096 : 2048;
-        const size_t lds2 = (size_t)tg.NT * 8;
-        hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S>), dim3(pl.nblk), dim3(kBinThreads),
-                           lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, b,
-                           (const uint32_t*)(ws + pl.off_counts),
-                           (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),
-                           WANT_IDX ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr, d_pts,
-                           d_pw, zero_dropped);
+        const size_t lds2 = (size_t)tg.NT * (nb + 1) * 4;
+#define DPR_LAUNCH_WC(GROUP)                                                                      \
+    hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S, GROUP>), dim3(pl.nblk),               \
+                       dim3(kBinThreads), lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, \
+                       b, nb, (const uint32_t*)(ws + pl.off_counts),                             \
+                       (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),   \
+                       WANT_IDX ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr, d_pts,     \
+                       d_pw, zero_dropped)
+        if (nb > 1) DPR_LAUNCH_WC(true);
+        else DPR_LAUNCH_WC(false);
+#undef DPR_LAUNCH_WC
         return DPR_OK;
     }
     const size_t lds = (size_t)tg.NT * 4;
@@ -1255,23 +1339,30 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
     return DPR_OK;
 }
 
-// K1-K3 for pose b.  want_idx: a pullback will consume the binning.
+// K1-K3 for the poses [b, b + nb).  want_idx: a pullback will consume the binning.
 template <typename T, int NI, int NO>
 static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                       const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
-                      const T* rot, const T* trans, int64_t b, bool want_idx, T* d_pts, T* d_pw,
-                      int zero_dropped) {
+                      const T* rot, const T* trans, int64_t b, int nb, bool want_idx, T* d_pts,
+                      T* d_pw, int zero_dropped) {
     uint32_t* counts = (uint32_t*)(ws + pl.off_counts);
     uint32_t* totals = (uint32_t*)(ws + pl.off_totals);
     uint32_t* tile_start = (uint32_t*)(ws + pl.off_tile_start);
-    const size_t lds = (size_t)tg.NT * 4;
-    if (int rc = allow_big_lds(k_count<T, NI, NO>, lds)) return rc;
-    hipLaunchKernelGGL((k_count<T, NI, NO>), dim3(pl.nblk), dim3(kBinThreads), lds, st, gd, tg, P,
-                       pl.chunk, points, rot, trans, b, counts);
+    const int NTe = tg.NT * nb;
+    const size_t lds = (size_t)NTe * 4;
+    if (nb > 1) {
+        if (int rc = allow_big_lds(k_count<T, NI, NO, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_count<T, NI, NO, true>), dim3(pl.nblk), dim3(kBinThreads), lds, st,
+                           gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts);
+    } else {
+        if (int rc = allow_big_lds(k_count<T, NI, NO, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_count<T, NI, NO, false>), dim3(pl.nblk), dim3(kBinThreads), lds, st,
+                           gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts);
+    }
     stage_mark(st);
-    hipLaunchKernelGGL(k_colscan, dim3((tg.NT + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st, counts, pl.nblk,
-                       tg.NT, totals);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, tg.NT, pl.cap, tile_start,
+    hipLaunchKernelGGL(k_colscan, dim3((NTe + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st,
+                       counts, pl.nblk, NTe, totals);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, NTe, pl.cap, tile_start,
                        (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
                        (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
                        (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split));
@@ -1279,20 +1370,20 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     int rc;
     if (pw) {
         rc = want_idx ? launch_scatter<T, NI, NO, true, true>(st, gd, tg, pl, ws, P, points, pw,
-                                                              rot, trans, b, d_pts, d_pw,
-                                                              zero_dropped)
+                                                              rot, trans, b, nb, d_pts,
+                                                              d_pw, zero_dropped)
                       : launch_scatter<T, NI, NO, true, false>(st, gd, tg, pl, ws, P, points, pw,
-                                                               rot, trans, b, d_pts, d_pw,
-                                                               zero_dropped);
+                                                               rot, trans, b, nb, d_pts,
+                                                               d_pw, zero_dropped);
     } else {
         // without point weights the original index rides in the record for free; slot_of is
         // only written when a pullback will consume the binning
         rc = want_idx ? launch_scatter<T, NI, NO, false, true>(st, gd, tg, pl, ws, P, points, pw,
-                                                               rot, trans, b, d_pts, d_pw,
-                                                               zero_dropped)
+                                                               rot, trans, b, nb, d_pts,
+                                                               d_pw, zero_dropped)
                       : launch_scatter<T, NI, NO, false, false>(st, gd, tg, pl, ws, P, points, pw,
-                                                                rot, trans, b, d_pts, d_pw,
-                                                                zero_dropped);
+                                                                rot, trans, b, nb, d_pts,
+                                                                d_pw, zero_dropped);
     }
     stage_mark(st);
     return rc;
@@ -1319,18 +1410,20 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     if (keep && B != 1)
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
                     (long long)B);
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P);
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     T* halo = (T*)(ws + pl.off_aux);
-    T* ovf = (T*)(ws + pl.off_aux + align_up((size_t)tg.NT * halo_count<NO>() * sizeof(T)));
+    T* ovf = (T*)(ws + pl.off_aux +
+                  align_up((size_t)tg.NT * pl.bg * halo_count<NO>() * sizeof(T)));
     const int blocked = env_int("DPR_SPLAT_BLOCKED", 1);
-    for (int64_t b = 0; b < B; ++b) {
-        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b, keep,
-                                           (T*)nullptr, (T*)nullptr, 0))
+    for (int64_t b = 0, nb = 1; b < B; b += nb) {
+        for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
+        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
+                                           (int)nb, keep, (T*)nullptr, (T*)nullptr, 0))
             return rc;
 #define DPR_LAUNCH_SPLAT(HAS_PW)                                                                 \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW>), dim3(pl.max_items),                   \
@@ -1344,12 +1437,12 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
 #undef DPR_LAUNCH_SPLAT
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>),
-                           dim3(tg.NT + (pl.max_slabs / 2) * kSplitBlocks),
+                           dim3(tg.NT * (int)nb + (pl.max_slabs / 2) * kSplitBlocks),
                            dim3(256), 0, st, gd, tg, (const T*)halo, (const T*)ovf,
                            (const uint32_t*)(ws + pl.off_tparts),
                            (const uint32_t*)(ws + pl.off_tslab),
                            (const uint32_t*)(ws + pl.off_split) + 1,
-                           (const uint32_t*)(ws + pl.off_split), bg, b, out);
+                           (const uint32_t*)(ws + pl.off_split), bg, b, (int)nb, out);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());
@@ -1371,7 +1464,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     if (reuse && B != 1)
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
                     (long long)B);
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P);
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -1380,8 +1473,12 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     double* partials = (double*)(ws + pl.off_aux);
     constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
-    const bool unperm = env_int("DPR_BWD_UNPERMUTE", 1) != 0;
-    for (int64_t b = 0; b < B; ++b) {
+    const bool unperm1 = env_int("DPR_BWD_UNPERMUTE", 1) != 0;
+    for (int64_t b = 0, nb = 1; b < B; b += nb) {
+        for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
+        // a pose group always goes through the gradient records (several (pose, tile) blocks
+        // own the same point, so they cannot store to ds_dpoints directly)
+        const bool unperm = unperm1 || nb > 1;
         if (reuse) {
             // The binning of the preceding raster call (same points / pose / grid) is in the
             // workspace.  Direct-store mode: points without an in-range voxel are in no tile,
@@ -1394,11 +1491,12 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             stage_mark(st);
             stage_mark(st);
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
-                                                  true, d_pts, d_pw, (b == 0 && !unperm) ? 1 : 0))
+                                                  (int)nb, true, d_pts, d_pw,
+                                                  (b == 0 && !unperm) ? 1 : 0))
             return rc;
 #define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                                                   \
     hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(pl.max_items),             \
-                       dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P,     \
+                       dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P * nb, \
                        (const uint32_t*)(ws + pl.off_idx), (const WorkItem*)(ws + pl.off_items), \
                        (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,  \
                        b, d_pts, d_pw, partials, rs)
@@ -1410,11 +1508,11 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                 const dim3 ug((unsigned)((P + 255) / 256));
                 if (b == 0)
                     hipLaunchKernelGGL((k_unpermute<T, NI, true>), ug, dim3(256), 0, st, P,
-                                       (const Rec4<T>*)(ws + pl.off_rec),
+                                       (int)nb, (const Rec4<T>*)(ws + pl.off_rec),
                                        (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
                 else
                     hipLaunchKernelGGL((k_unpermute<T, NI, false>), ug, dim3(256), 0, st, P,
-                                       (const Rec4<T>*)(ws + pl.off_rec),
+                                       (int)nb, (const Rec4<T>*)(ws + pl.off_rec),
                                        (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
             }
         } else {
@@ -1429,9 +1527,10 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         }
 #undef DPR_LAUNCH_GATHER
         stage_mark(st);
-        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>), dim3(rs.target ? NVAL + 1 : NVAL),
-                           dim3(1024), 0, st, (const double*)partials,
-                           (const uint32_t*)(ws + pl.off_nitems), pl.max_items, b, d_rot,
+        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>),
+                           dim3(rs.target ? NVAL + 1 : NVAL, (unsigned)nb), dim3(1024), 0, st,
+                           (const double*)partials, (const WorkItem*)(ws + pl.off_items),
+                           (const uint32_t*)(ws + pl.off_nitems), pl.max_items, tg.NT, b, d_rot,
                            d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr);
         stage_mark(st);
     }

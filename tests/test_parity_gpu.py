@@ -417,6 +417,34 @@ def test_residual_pullback_reuses_forward_binning_and_rejects_chunked(oracle, de
         dpr_amd.raster_residual_pullback_(out, tgt[1:], *args)
 
 
+# ------------------------------------------------------------------ pose groups
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out,grid_n,batch", [(3, 2, 96, 21), (3, 3, 40, 19), (2, 2, 64, 7)])
+@pytest.mark.parametrize("with_pw", [False, True])
+def test_pose_groups_equal_oracle(oracle, dev, npdt, tdt, n_in, n_out, grid_n, batch, with_pw):
+    """Grids with few tiles bin up to 16 poses together ((pose, tile) bins):
+    odd batch sizes decompose into groups of 16 / 4 / 2 / 1 poses.  Forward, pullback and the
+    residual pullback against the oracle; a clustered cloud makes some (pose, tile) bins split."""
+    d = D.make(n_points=30_000, n_in=n_in, n_out=n_out, batch=batch, grid_n=grid_n, seed=41, dtype=npdt)
+    d.points[:20_000] *= npdt(0.3)
+    d.points[::11] *= npdt(5.0)
+    if not with_pw:
+        d.point_weights = None
+    _compare(*_run_both(oracle, dev, d, npdt, "tiled"), npdt)
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(d.point_weights, dev))
+    out = dpr_amd.raster(d.grid, *args, algo="tiled")
+    target = np.asfortranarray(np.random.default_rng(42).normal(size=d.grid + (batch,)).astype(npdt))
+    pb, loss = dpr_amd.raster_residual_pullback_(out, grid_to_dev(target, dev), *args, algo="tiled")
+    ref_pb, ref_loss = oracle.residual_pullback(out.cpu().numpy(), target, d.points, d.rotations,
+                                                d.translations, d.weights, d.point_weights,
+                                                dtype=npdt)
+    assert_close(pb.points, ref_pb.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.rotation, ref_pb.rotation, tol(npdt, "pose"), "ds_drotation")
+    assert_close(pb.background, ref_pb.background, tol(npdt, "pose"), "ds_dbackground")
+    assert_close(loss, ref_loss.astype(npdt), tol(npdt, "out"), "loss")
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
