@@ -1261,14 +1261,27 @@ bool tiled_supported(int n_out, const int64_t* grid) {
 }
 
 bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G) {
-    if (!tiled_supported(n_out, grid)) return false;
-    if (P >= (int64_t)1 << 32) return false;
-    // Measured crossover (profiles/r01_algo_sweep.txt, 128^3 / 256^3 / 512^2 grids, random and
-    // Morton order): the tiled pipeline's fixed cost (6-7 launches per pose) is repaid from
-    // ~2-3e5 points on, forward and backward alike; below that the direct kernels win.
     (void)G;
-    (void)B;
-    (void)op;
+    if (P >= (int64_t)1 << 32) return false;
+    int NT;
+    if (n_out == 3) {
+        TileGeom<3> tg;
+        if (!make_geom<3>(grid, &tg)) return false;
+        NT = tg.NT;
+    } else {
+        TileGeom<2> tg;
+        if (!make_geom<2>(grid, &tg)) return false;
+        NT = tg.NT;
+    }
+    // Measured crossovers (profiles/r01_algo_sweep.txt: one pose; r01_algo_sweep_batched.txt:
+    // 4-64 poses; 64^3 ... 256^3 and 128^2 / 512^2 grids).  One pose: the tiled pipeline's fixed
+    // cost (6-7 launches) is repaid from ~2-3e5 points on, forward and backward alike.  Batched
+    // poses on a grid that forms pose groups: the fixed cost is shared, the forward pays from
+    // ~6e4 points; the direct pullback kernel, which keeps a point in registers across the poses
+    // of a slice, stays ahead up to ~3e5 points (~6e5 when the grid is too large for groups).
+    const bool grouped = B >= 4 && pose_group(NT, P, B) >= 4;
+    if (op == DPR_OP_RASTER) return P >= (grouped ? 60000 : 250000);
+    if (B >= 4) return P >= (grouped ? 300000 : 600000);
     return P >= 250000;
 }
 
