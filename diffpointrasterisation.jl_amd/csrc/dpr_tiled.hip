@@ -474,18 +474,35 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     __syncthreads();
     const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
-    // bins owned by this thread in the scan / cursor update
+    // bins owned by this thread in the scan / cursor update (NT <= 4096: at most 4)
+    constexpr int kMaxBpt = 4096 / kBinThreads;
     const int bpt = (NT + kBinThreads - 1) / kBinThreads;
     const int bin0 = threadIdx.x * bpt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lo >= hi) return;
+    T nxt_pt[PPT][NI], nxt_w[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = lo + threadIdx.x + (int64_t)k * kBinThreads;
+        const int64_t pl = p < hi ? p : hi - 1;
+        load_point<T, NI>(points, pl, nxt_pt[k]);
+        nxt_w[k] = HAS_PW ? pw[pl] : T(1);
+    }
     for (int64_t base = lo; base < hi; base += S) {
         T pt[PPT][NI], w[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) pt[k][j] = nxt_pt[k][j];
+            w[k] = nxt_w[k];
+        }
+        // the next sub-chunk's points are requested now and arrive during the LDS phases
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base + S + threadIdx.x + (int64_t)k * kBinThreads;
             const int64_t pl = p < hi ? p : hi - 1;
-            load_point<T, NI>(points, pl, pt[k]);
-            w[k] = HAS_PW ? pw[pl] : T(1);
+            load_point<T, NI>(points, pl, nxt_pt[k]);
+            nxt_w[k] = HAS_PW ? pw[pl] : T(1);
         }
         for (int jp = 0; jp < (GROUP ? nb : 1); ++jp) {
             const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
@@ -507,7 +524,13 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             __syncthreads();
             // b. exclusive scan of lhist (in place)
             uint32_t cnt_sum = 0;
-            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) cnt_sum += lhist[i];
+            uint32_t cnt[kMaxBpt];
+#pragma unroll
+            for (int q = 0; q < kMaxBpt; ++q) {
+                const int i = bin0 + q;
+                cnt[q] = (q < bpt && i < NT) ? lhist[i] : 0u;
+                cnt_sum += cnt[q];
+            }
             uint32_t incl = cnt_sum;
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
@@ -521,10 +544,11 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             uint32_t n_valid = 0;
 #pragma unroll
             for (int wv = 0; wv < kBinThreads / kWave; ++wv) n_valid += wsum[wv];
-            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) {
-                const uint32_t c = lhist[i];
-                lhist[i] = run;  // exclusive offset inside the sub-chunk
-                run += c;
+#pragma unroll
+            for (int q = 0; q < kMaxBpt; ++q) {
+                const int i = bin0 + q;
+                if (q < bpt && i < NT) lhist[i] = run;  // exclusive offset inside the sub-chunk
+                run += cnt[q];
             }
             __syncthreads();
             // c. place into LDS in tile order; remember the global destination
@@ -553,13 +577,16 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             __syncthreads();
             // d. write-out in LDS (= tile) order; e. advance cursors, clear the histogram
             for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[dest[i]] = recs[i];
-            // counts of the owned bins = differences of the exclusive offsets
-            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) {
-                const uint32_t nxt = (i + 1 < NT) ? lhist[i + 1] : n_valid;
-                cur[i] += nxt - lhist[i];
+            // advance the cursors by the owned bins' counts (kept in registers since the scan)
+            // and clear the histogram; the next round's atomics start after the barrier
+#pragma unroll
+            for (int q = 0; q < kMaxBpt; ++q) {
+                const int i = bin0 + q;
+                if (q < bpt && i < NT) {
+                    cur[i] += cnt[q];
+                    lhist[i] = 0;
+                }
             }
-            __syncthreads();
-            for (int i = bin0; i < bin0 + bpt && i < NT; ++i) lhist[i] = 0;
             __syncthreads();
         }
     }
