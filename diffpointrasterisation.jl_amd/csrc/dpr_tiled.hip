@@ -195,6 +195,15 @@ __device__ __forceinline__ unsigned xcd_slice(unsigned block, unsigned nblocks) 
     return (block % 8) * per + block / 8;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store of the wave (s_waitcnt vmcnt(0)); in loops whose barriers
+// only separate LDS phases that wait would put the latency of prefetched loads and of
+// fire-and-forget scattered stores on the critical path of every phase.  Global data written
+// before this barrier must not be read by other threads of the block after it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------ K1: count
 template <typename T, int NI, int NO, bool GROUP>
 __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom<NO> tg, int64_t P,
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                 lrank[k] = 0;
                 if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
             }
-            __syncthreads();
+            lds_barrier();
             // b. exclusive scan of lhist (in place)
             uint32_t cnt_sum = 0;
             uint32_t cnt[kMaxBpt];
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                 if (lane >= o) incl += v;
             }
             if (lane == kWave - 1) wsum[wave] = incl;
-            __syncthreads();
+            lds_barrier();
             uint32_t run = incl - cnt_sum;
             for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
             uint32_t n_valid = 0;
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                 if (q < bpt && i < NT) lhist[i] = run;  // exclusive offset inside the sub-chunk
                 run += cnt[q];
             }
-            __syncthreads();
+            lds_barrier();
             // c. place into LDS in tile order; remember the global destination
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // d. write-out in LDS (= tile) order; e. advance cursors, clear the histogram
             for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[dest[i]] = recs[i];
             // advance the cursors by the owned bins' counts (kept in registers since the scan)
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                     lhist[i] = 0;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
