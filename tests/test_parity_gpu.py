@@ -701,7 +701,7 @@ def test_random_configurations_against_oracle(oracle, dev, seed):
     npdt, tdt = DTYPES[rng.integers(2)]
     algo = ALGOS[rng.integers(len(ALGOS))]
     P = int(rng.choice([1, 63, 64, 65, 255, 257, 1023, 1025, 4095, 4097, 8193, 20481, 50_000]))
-    B = int(rng.integers(1, 5))
+    B = int(rng.choice([1, 2, 3, 4, 5, 9, 17, 33]))  # pose groups of 1 ... 16 (+ remainders)
     grid = tuple(int(g) for g in rng.integers(3, 150 if n_out == 2 else 90, size=n_out))
     spread = float(rng.choice([0.05, 0.4, 0.9]))
     pts = (spread * rng.normal(size=(P, n_in))).astype(npdt)
@@ -719,3 +719,15 @@ def test_random_configurations_against_oracle(oracle, dev, seed):
     pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), T(pts, dev), T(R, dev), T(t, dev),
                                   T(bg, dev), T(ow, dev), T(pw, dev), algo=algo)
     _compare(ref_out, ref_pb, out, pb, npdt)
+    if seed % 3 == 0 and algo != "chunked":  # the fused squared-error pullback on the same case
+        target = np.asfortranarray(rng.normal(size=grid + (B,)).astype(npdt))
+        rp, loss = dpr_amd.raster_residual_pullback_(out, grid_to_dev(target, dev), T(pts, dev),
+                                                     T(R, dev), T(t, dev), T(bg, dev), T(ow, dev),
+                                                     T(pw, dev), scale=-2.0, algo=algo)
+        o = out.cpu().numpy().reshape(grid + (B,))
+        ref_rp, ref_loss = oracle.residual_pullback(o, target, pts, R, t, ow, pw, scale=-2.0,
+                                                    dtype=npdt)
+        assert_close(rp.points, ref_rp.points, tol(npdt, "points"), "residual ds_dpoints")
+        assert_close(rp.rotation, ref_rp.rotation, tol(npdt, "pose"), "residual ds_drotation")
+        assert_close(rp.out_weight, ref_rp.out_weight, tol(npdt, "pose"), "residual ds_dout_weight")
+        assert_close(loss, ref_loss.astype(npdt).reshape(loss.shape), tol(npdt, "out"), "loss")
