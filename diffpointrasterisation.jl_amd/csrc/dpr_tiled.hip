@@ -610,7 +610,6 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
     T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
-    constexpr int NV = tile_voxels<NO>();
     __shared__ double acc[NVH];
     if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
     const WorkItem item = items[blockIdx.x];
@@ -721,37 +720,46 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)acc[i];
         return;
     }
-    // owned voxels: out = background + acc   (plain stores, rows of TX contiguous values)
+    // Flush, one LDS row (TX + 1 cells along x) at a time: the row's y/z coordinates, bounds
+    // and base offsets are computed once per row, a lane only adds its x.  Owned rows leave
+    // as out = background + acc (plain stores of TX contiguous values); the rows of the upper
+    // y / z halo and the x == TX column go to the compact per-tile halo buffer (always fully
+    // written, zeros included).
+    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+    constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
+    constexpr int ROWS = NVH / (TX + 1);   // (TY + 1) [* (TZ + 1)]
+    constexpr int RPW = kWave / TX;        // rows per wave pass (1 for TX = 64, 2 for TX = 32)
+    static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
     const double bgv = bg ? (double)bg[b] : 0.0;
     T* o = out + b * gd.G;
-    for (int i = threadIdx.x; i < NV; i += kSplatThreads) {
-        int l[NO], rem = i;
-        int off = 0, stride = 1;
-        bool ok = true;
-#pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            l[d] = rem % TileDims<NO>::T[d];
-            rem /= TileDims<NO>::T[d];
-            const int gcoord = x0[d] + l[d];
-            ok = ok && gcoord < gd.n[d];
-            off += gcoord * stride;
-            stride *= gd.n[d];
-        }
-        if (ok) o[off] = (T)(bgv + acc[lds_index<NO>(l)]);
-    }
-    // upper halo -> compact per-tile buffer (always fully written, zeros included)
     T* hb = halo + (size_t)item.tile * halo_count<NO>();
-    for (int i = threadIdx.x; i < NVH; i += kSplatThreads) {
-        int h[NO], rem = i;
-        bool is_halo = false;
-#pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            h[d] = rem % (TileDims<NO>::T[d] + 1);
-            rem /= TileDims<NO>::T[d] + 1;
-            is_halo = is_halo || (h[d] == TileDims<NO>::T[d]);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int x = lane % TX;
+    const bool x_ok = x0[0] + x < gd.n[0];
+    for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += (kSplatThreads / kWave) * RPW) {
+        int row = row0 + lane / TX;
+        if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+        if (row >= ROWS) continue;
+        const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+        const double a = acc[row * (TX + 1) + x];
+        const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
+        if (owned) {
+            const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+            const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+            if (in && x_ok)
+                o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x] =
+                    (T)(bgv + a);
+        } else {
+            int h[NO];
+            h[0] = x;
+            h[1] = l1;
+            if (NO == 3) h[NO - 1] = l2;
+            hb[halo_index<NO>(h)] = (T)a;
         }
-        if (is_halo) hb[halo_index<NO>(h)] = (T)acc[i];
     }
+    // x == TX column: the X-face of the halo buffer is indexed by the row number
+    for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
+        hb[row] = (T)acc[row * (TX + 1) + TX];
 }
 
 // ------------------------------------------------------------------ forward K5
