@@ -691,6 +691,54 @@ def test_runs_on_the_callers_stream_and_in_hip_graphs(oracle, dev, algo):
     _compare(ref_out2, ref_pb2, out, pb, np.float32)
 
 
+def test_concurrent_host_threads_on_their_own_streams(oracle, dev):
+    """SURVEY.md 8b "Threading": the library is re-entrant -- several host threads, each with
+    its own stream, workspace and outputs, call it at the same time (ctypes drops the GIL
+    during the call) and every thread gets the oracle's answer; error strings are per thread."""
+    import threading
+
+    cases = []
+    for k, (algo, n_out, grid_n) in enumerate([("tiled", 3, 44), ("atomic", 3, 30), ("tiled", 2, 120),
+                                                ("chunked", 3, 40)]):
+        d = D.make(n_points=25_000 + 1000 * k, n_in=3, n_out=n_out, batch=2, grid_n=grid_n,
+                   seed=50 + k, dtype=np.float32)
+        cases.append((algo, d))
+    results, errors = [None] * len(cases), []
+
+    def worker(i):
+        try:
+            algo, d = cases[i]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev),
+                        T(d.backgrounds, dev), T(d.weights, dev), T(d.point_weights, dev))
+                g = grid_to_dev(d.ds_dout, dev)
+                for _ in range(5):  # keep the threads overlapping for a while
+                    out = dpr_amd.raster(d.grid, *args, algo=algo)
+                    pb = dpr_amd.raster_pullback_(g, *args, algo=algo)
+                if i == 0:  # a failing call in one thread must not disturb the others
+                    with pytest.raises(dpr_amd.DprError):
+                        dpr_amd.raster_(out, *args, algo="atomic", keep_binning=True,
+                                        workspace=torch.empty(1 << 20, dtype=torch.uint8, device=dev))
+            stream.synchronize()
+            results[i] = (out, pb)
+        except Exception as e:  # surfaced in the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(cases))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for (algo, d), (out, pb) in zip(cases, results):
+        ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds,
+                                d.weights, d.point_weights, dtype=np.float32)
+        ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                        d.point_weights, dtype=np.float32)
+        _compare(ref_out, ref_pb, out, pb, np.float32)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_configurations_against_oracle(oracle, dev, seed):
     """Seeded fuzz over shapes the fixed tests do not hit: random point counts (incl. sizes
