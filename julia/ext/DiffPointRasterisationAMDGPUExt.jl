@@ -152,4 +152,56 @@ function DiffPointRasterisation.default_ds_dpoint_weight_batched(
     return similar(points, T)
 end
 
+# ---- optional: squared-error loss without materialising ds_dout -------------------------------
+# `raster_residual_pullback!(out, target, scale, points, ...; loss)`: the README's explicit
+# recipe (README.md:151-165: ds_dout = 2 .* (target .- raster(...)); raster_pullback!(...)) in
+# one call to dpr_raster_residual_pullback_*; `out` is the result of raster! for the same
+# arguments, `loss[b] = sum(abs2, out[.., b] - target[.., b])`.  Not part of the reference API.
+function raster_residual_pullback!(
+    out::ROCArray{T,N_out_p1},
+    target::ROCArray{T,N_out_p1},
+    scale::Real,
+    points::ROCVector{<:StaticVector{N_in,T}},
+    rotation::AbstractVector{<:StaticMatrix{N_out,N_in,<:Number}},
+    translation::AbstractVector{<:StaticVector{N_out,<:Number}},
+    out_weight::ROCOrFillVector{<:Number},
+    point_weight::ROCOrFillVector{<:Number},
+    loss::ROCVector{T},
+    ds_dpoints::ROCMatrix{T},
+    ds_drotation::ROCArray{T,3},
+    ds_dtranslation::ROCMatrix{T},
+    ds_dbackground::ROCVector{T},
+    ds_dout_weight::ROCVector{T},
+    ds_dpoint_weight::ROCVector{T},
+) where {T<:Union{Float32,Float64},N_in,N_out,N_out_p1}
+    @argcheck N_out == N_out_p1 - 1
+    @argcheck size(out) == size(target)
+    P, B = length(points), size(out, N_out_p1)
+    @argcheck length(loss) == B
+    rot, tr = devbuf(rotation, T), devbuf(translation, T)
+    ow, pw = devbuf(out_weight, T), devbuf(point_weight, T)
+    grid = collect(Int64, size(out)[1:N_out])
+    ws = workspace(1, T, N_in, N_out, grid, P, B)
+    GC.@preserve out target points rot tr ow pw ws begin
+        args = (AMDGPU.stream().stream, N_in, N_out, grid, P, B, devptr(out, T), devptr(target, T),
+            Float64(scale), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(ow, T),
+            devptr(pw, T), devptr(loss, T), devptr(ds_dpoints, T), devptr(ds_drotation, T),
+            devptr(ds_dtranslation, T), devptr(ds_dbackground, T), devptr(ds_dout_weight, T),
+            devptr(ds_dpoint_weight, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws))
+        st = T === Float32 ?
+            ccall((:dpr_raster_residual_pullback_f32, libdpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Cdouble, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t), args...) :
+            ccall((:dpr_raster_residual_pullback_f64, libdpr), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Cdouble, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t), args...)
+        check(st)
+    end
+    return (;
+        points=ds_dpoints,
+        rotation=ds_drotation,
+        translation=ds_dtranslation,
+        background=ds_dbackground,
+        out_weight=ds_dout_weight,
+        point_weight=ds_dpoint_weight,
+        loss=loss,
+    )
+end
+
 end  # module
