@@ -947,48 +947,64 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         z.v[0] = z.v[1] = z.v[2] = z.v[3] = T(0);
         rec[P] = z;  // spare slot: the gradient of every rejected point
     }
-    // stage ds_dout tile + upper halo; sum the owned voxels for ds_dbackground (residual
-    // mode: ds_dout = scale * (out - target) formed here, squared residuals summed for loss)
+    // Stage the ds_dout tile + upper halo in LDS, one row (TX + 1 cells along x) at a time: the
+    // row's y / z coordinates, bounds and base offset are computed once per row, a lane only
+    // adds its x; kRB rows are in flight per wave.  Cells beyond the grid are staged as 0.
+    // Owned voxels are summed for ds_dbackground (residual mode: ds_dout = scale * (out -
+    // target) formed here, squared residuals summed for the loss).
     double bg_sum = 0.0, sq_sum = 0.0;
     {
-        // all loads are issued (clamped addresses, no branches) before the first LDS write
-        constexpr int IT = (NVH + kGatherThreads - 1) / kGatherThreads;
-        T v[IT], tv[IT];
-        bool own[IT], inside[IT];
+        constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+        constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
+        constexpr int ROWS = NVH / (TX + 1);
+        constexpr int RPW = kWave / TX;  // rows per wave pass (1 for TX = 64, 2 for TX = 32)
+        constexpr int kRB = 8;           // row passes in flight
+        static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
+        const bool first_part = (item.part_nparts & 0xffffu) == 0;
+        const int lane = threadIdx.x & (kWave - 1);
+        const int x = lane % TX;
+        const bool x_ok = x0[0] + x < gd.n[0];
+        constexpr int STEP = (kGatherThreads / kWave) * RPW;
+        for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += STEP * kRB) {
+            T v[kRB], tv[kRB];
+            bool in[kRB], owned[kRB];
+            int lrow[kRB];
 #pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int i = threadIdx.x + k * kGatherThreads;
-            int rem = i, off = 0, stride = 1;
-            bool ok = i < NVH, owned = true;
-#pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                const int l = rem % (TileDims<NO>::T[d] + 1);
-                rem /= TileDims<NO>::T[d] + 1;
-                const int gcoord = x0[d] + l;
-                ok = ok && gcoord < gd.n[d];
-                owned = owned && l < TileDims<NO>::T[d];
-                off += gcoord * stride;
-                stride *= gd.n[d];
+            for (int k = 0; k < kRB; ++k) {
+                int row = row0 + k * STEP + lane / TX;
+                if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+                const bool live = row < ROWS;
+                const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+                const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+                in[k] = live && x_ok && g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+                owned[k] = in[k] && l1 < TY && (NO == 2 || l2 < TZ);
+                lrow[k] = live ? row * (TX + 1) + x : -1;
+                const size_t off =
+                    ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x;
+                v[k] = gb[in[k] ? off : 0];
+                tv[k] = tb ? tb[in[k] ? off : 0] : T(0);
             }
-            const T x = gb[ok ? off : 0];
-            tv[k] = tb ? tb[ok ? off : 0] : T(0);
-            v[k] = ok ? x : T(0);
-            own[k] = owned && ok;
-            inside[k] = ok;
-        }
-        if (tb) {
 #pragma unroll
-            for (int k = 0; k < IT; ++k) {
-                const T d = v[k] - tv[k];
-                if (own[k] && (item.part_nparts & 0xffffu) == 0) sq_sum += (double)d * (double)d;
-                v[k] = inside[k] ? rs.scale * d : T(0);
+            for (int k = 0; k < kRB; ++k) {
+                T val = in[k] ? v[k] : T(0);
+                if (tb) {
+                    const T d = val - (in[k] ? tv[k] : T(0));
+                    if (owned[k] && first_part) sq_sum += (double)d * (double)d;
+                    val = rs.scale * d;
+                }
+                if (lrow[k] >= 0) tile_g[lrow[k]] = val;
+                if (owned[k] && first_part) bg_sum += (double)val;
             }
         }
-#pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int i = threadIdx.x + k * kGatherThreads;
-            if (i < NVH) tile_g[i] = v[k];
-            if (own[k] && (item.part_nparts & 0xffffu) == 0) bg_sum += (double)v[k];
+        // the x == TX column (halo cells only): one cell per row
+        for (int row = threadIdx.x; row < ROWS; row += kGatherThreads) {
+            const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+            const int g0 = x0[0] + TX, g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+            const bool in = g0 < gd.n[0] && g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+            const size_t off = ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + g0;
+            T val = in ? gb[off] : T(0);
+            if (tb) val = in ? rs.scale * (val - tb[off]) : T(0);
+            tile_g[row * (TX + 1) + TX] = val;
         }
     }
     __syncthreads();
