@@ -611,8 +611,10 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
     __shared__ double acc[NVH];
-    if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
+    // the item and the item count are fetched together (the list is allocated for the whole
+    // grid): one memory latency, not two, before the block can start
     const WorkItem item = items[blockIdx.x];
+    if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
     // item.tile = (pose within the group) * NT + tile
     const int tile = (int)(item.tile % (uint32_t)tg.NT);
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         const uint32_t ru = r + u * step;
         nxt[u] = rec[ru < r1 ? ru : (r1 > item.begin ? r1 - 1 : item.begin)];
     }
-    __syncthreads();
+    lds_barrier();  // LDS phases only: prefetched records stay in flight
     while (r < r1) {
         Rec4<T> cur[kPF];
 #pragma unroll
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
             }
         }
     }
-    __syncthreads();
+    lds_barrier();  // LDS phases only: prefetched records stay in flight
     if ((item.part_nparts >> 16) > 1) {
         // part of a split tile: the whole LDS tile goes to this part's overflow slab;
         // k_halo_gather sums the parts
@@ -926,8 +928,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     constexpr int NW = kGatherThreads / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
+    const WorkItem item = items[blockIdx.x];  // fetched together with the item count
     if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
-    const WorkItem item = items[blockIdx.x];
     const int tile = (int)(item.tile % (uint32_t)tg.NT);
     const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
     int x0[NO], tc[NO];
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
             tile_g[row * (TX + 1) + TX] = val;
         }
     }
-    __syncthreads();
+    lds_barrier();  // LDS phases only: prefetched records stay in flight
     const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     // per-thread sums of the per-pose scalars: T within the thread (few records each),
     // f64 across threads / tiles
