@@ -574,6 +574,45 @@ def test_full_size_properties(dev, algo, config):
     assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), np.sqrt(P))
 
 
+def test_batched_projection_share_properties(dev, monkeypatch):
+    """BASELINE.json config 4 at a one-GPU share (10M points -> 512^2 orthographic projection,
+    8 of the 64 poses a GPU owns; the poses are binned as one pose group): mass per pose,
+    batch == loop of singles, pose groups == per-pose pipeline == direct kernels, and the
+    adjoint identity <g, out - bg> = ow * d/d(ow) per pose."""
+    P, n, B = 10_000_000, 512, 8
+    f32 = dict(device=dev, dtype=torch.float32)
+    pts = _ball_points(P, dev, torch.float32)
+    rng = np.random.default_rng(5)
+    R = T(D.random_rotations(rng, B)[:, :2, :].astype(np.float32), dev)
+    t = T((0.05 * rng.normal(size=(B, 2))).clip(-0.1, 0.1).astype(np.float32), dev)
+    ow = torch.linspace(0.5, 2.0, B, **f32)
+    bg = torch.linspace(-1.0, 1.0, B, **f32)
+    out = dpr_amd.raster((n, n), pts, R, t, bg, ow, algo="tiled")
+    sums = out.double().sum(dim=(0, 1)).cpu().numpy()
+    expect = ow.double().cpu().numpy() * P + bg.double().cpu().numpy() * n * n
+    np.testing.assert_allclose(sums, expect, rtol=2e-4)
+    single = dpr_amd.raster((n, n), pts, R[5], t[5], float(bg[5]), float(ow[5]), algo="tiled")
+    assert_close(out[..., 5], single.cpu().numpy(), 2e-5, "pose 5 of the batch vs single call")
+    g = torch.randn(B, n, n, **f32).permute(2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow, algo="tiled")
+    lhs = (g.double() * (out.double() - bg.double())).sum(dim=(0, 1)).cpu().numpy()
+    rhs = (ow.double() * pb.out_weight.double()).cpu().numpy()
+    np.testing.assert_allclose(lhs, rhs, rtol=2e-3, atol=2e-3 * np.sqrt(P))
+    np.testing.assert_allclose(pb.background.double().cpu().numpy(),
+                               g.double().sum(dim=(0, 1)).cpu().numpy(), rtol=0, atol=1e-3 * n)
+    # the same batch through the per-pose pipeline and through the direct kernels
+    monkeypatch.setenv("DPR_POSE_GROUP", "1")
+    out1 = dpr_amd.raster((n, n), pts, R, t, bg, ow, algo="tiled")
+    pb1 = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow, algo="tiled")
+    monkeypatch.delenv("DPR_POSE_GROUP")
+    assert_close(out, out1.cpu().numpy(), 2e-5, "pose groups vs per-pose pipeline: out")
+    assert_close(pb.points, pb1.points.cpu().numpy(), 1e-4, "pose groups vs per-pose: ds_dpoints")
+    assert_close(pb.rotation, pb1.rotation.cpu().numpy(), 1e-3, "pose groups vs per-pose: ds_drotation")
+    pb_a = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow, algo="atomic")
+    assert_close(pb.points, pb_a.points.cpu().numpy(), 1e-4, "tiled vs atomic: ds_dpoints")
+    assert_close(pb.translation, pb_a.translation.cpu().numpy(), 1e-3, "tiled vs atomic: ds_dtranslation")
+
+
 @pytest.mark.parametrize("algo", ["tiled", "chunked"])
 def test_large_grid_fp64_properties(dev, algo):
     """BASELINE.json config 5 shape per pose (512^3 fp64 grid, 16384 tiles: the binning
