@@ -1142,27 +1142,47 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
 // ds_dpoint_weight (coalesced stores; accumulating over poses when !FIRST_POSE).  A pose
 // group contributes nb records per point, summed here in registers.
 template <typename T, int NI, bool FIRST_POSE>
-__global__ __launch_bounds__(256) void k_unpermute(int64_t P, int nb,
-                                                   const Rec4<T>* __restrict__ grad,
-                                                   const uint32_t* __restrict__ slot_of,
-                                                   T* __restrict__ ds_dpoints,
-                                                   T* __restrict__ ds_dpw) {
-    const int64_t p = (int64_t)xcd_slice(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (p >= P) return;
-    Rec4<T> g = grad[slot_of[p]];
-    for (int j = 1; j < nb; ++j) {
-        const Rec4<T> gj = grad[slot_of[(size_t)j * P + p]];
+__global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
+                                                    const Rec4<T>* __restrict__ grad,
+                                                    const uint32_t* __restrict__ slot_of,
+                                                    T* __restrict__ ds_dpoints,
+                                                    T* __restrict__ ds_dpw) {
+    // One block covers kUPB * 1024 consecutive points = one sub-chunk of the scatter: points of
+    // a sub-chunk that fell into the same tile sit next to each other in that tile's record
+    // run, so the 64-byte sectors this block fetches are shared among its own threads.
+    constexpr int kUPB = 4;
+    const int64_t base = (int64_t)xcd_slice(blockIdx.x, gridDim.x) * (kUPB * 1024) + threadIdx.x;
+    uint32_t slot[kUPB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g.v[k] += gj.v[k];
+    for (int k = 0; k < kUPB; ++k) {
+        const int64_t p = base + k * 1024;
+        slot[k] = slot_of[p < P ? p : P - 1];
     }
-    if (FIRST_POSE) {
+    Rec4<T> g[kUPB];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = g.v[j];
-        ds_dpw[p] = g.v[3];
-    } else {
+    for (int k = 0; k < kUPB; ++k) g[k] = grad[slot[k]];
+    for (int j = 1; j < nb; ++j) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] += g.v[j];
-        ds_dpw[p] += g.v[3];
+        for (int k = 0; k < kUPB; ++k) {
+            const int64_t p = base + k * 1024;
+            const Rec4<T> gj = grad[slot_of[(size_t)j * P + (p < P ? p : P - 1)]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) g[k].v[c] += gj.v[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kUPB; ++k) {
+        const int64_t p = base + k * 1024;
+        if (p >= P) continue;
+        if (FIRST_POSE) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = g[k].v[j];
+            ds_dpw[p] = g[k].v[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] += g[k].v[j];
+            ds_dpw[p] += g[k].v[3];
+        }
     }
 }
 
@@ -1580,13 +1600,13 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             else DPR_LAUNCH_GATHER(false, true, true);
             stage_mark(st);
             if (P > 0) {
-                const dim3 ug((unsigned)((P + 255) / 256));
+                const dim3 ug((unsigned)((P + 4095) / 4096));
                 if (b == 0)
-                    hipLaunchKernelGGL((k_unpermute<T, NI, true>), ug, dim3(256), 0, st, P,
+                    hipLaunchKernelGGL((k_unpermute<T, NI, true>), ug, dim3(1024), 0, st, P,
                                        (int)nb, (const Rec4<T>*)(ws + pl.off_rec),
                                        (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
                 else
-                    hipLaunchKernelGGL((k_unpermute<T, NI, false>), ug, dim3(256), 0, st, P,
+                    hipLaunchKernelGGL((k_unpermute<T, NI, false>), ug, dim3(1024), 0, st, P,
                                        (int)nb, (const Rec4<T>*)(ws + pl.off_rec),
                                        (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
             }
