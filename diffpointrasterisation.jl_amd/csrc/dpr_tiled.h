@@ -1,4 +1,5 @@
-// DPR_ALGO_TILED (declarations; implementation in dpr_tiled_impl.h)
+// DPR_ALGO_TILED / DPR_ALGO_CHUNKED entry points shared between dpr_api.hip, dpr_tiled.hip,
+// dpr_chunked.hip and dpr_sort.hip
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

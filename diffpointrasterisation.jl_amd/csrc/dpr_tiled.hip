@@ -54,9 +54,6 @@ template <int NO> struct TileDims;
 #ifndef DPR_TZ3
 #define DPR_TZ3 8
 #endif
-#ifndef DPR_TILE_THREADS
-#define DPR_TILE_THREADS 512
-#endif
 template <> struct TileDims<3> {
     static constexpr int T[3] = {DPR_TX3, DPR_TY3, DPR_TZ3};
 };
