@@ -845,6 +845,59 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     T* o = out + b * gd.G;
+    if (!any_split) {
+        // Common case (no split tile anywhere): the thread's voxels are handled with every load
+        // issued before the first store -- branch-free, invalid neighbour combinations read
+        // halo[0] and are multiplied away -- so the ~IT dependent round trips of the general
+        // loop below collapse into one.
+        constexpr int IT = (low_face_count<NO>() + 255) / 256;
+        T cur[IT];
+        double add[IT];
+        int offs[IT];
+        bool act[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            int l[NO];
+            low_face_coords<NO>(i < low_face_count<NO>() ? i : 0, l);
+            int off = 0, stride = 1;
+            bool ok = i < low_face_count<NO>(), low = false;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int gcoord = x0[d] + l[d];
+                ok = ok && gcoord < gd.n[d];
+                low = low || (l[d] == 0 && tc[d] > 0);
+                off += gcoord * stride;
+                stride *= gd.n[d];
+            }
+            act[k] = ok && low;
+            offs[k] = act[k] ? off : 0;
+            cur[k] = o[offs[k]];
+            add[k] = 0.0;
+#pragma unroll
+            for (int m = 1; m < (1 << NO); ++m) {
+                bool valid = act[k];
+                int h[NO];
+                int src = 0, tstride = 1;
+#pragma unroll
+                for (int d = 0; d < NO; ++d) {
+                    const bool in_m = (m >> d) & 1;
+                    valid = valid && (!in_m || (l[d] == 0 && tc[d] > 0));
+                    h[d] = in_m ? TileDims<NO>::T[d] : l[d];
+                    src += (tc[d] - (in_m ? 1 : 0)) * tstride;
+                    tstride *= tg.nt[d];
+                }
+                const size_t hi = valid ? (size_t)(src + pbase) * halo_count<NO>() + halo_index<NO>(h)
+                                        : (size_t)0;
+                const T hv = halo[hi];
+                add[k] += valid ? (double)hv : 0.0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k)
+            if (act[k]) o[offs[k]] = (T)((double)cur[k] + add[k]);
+        return;
+    }
     const uint32_t my_parts = split ? tile_parts[ptile] : 1u;
     const double bgv = bg ? (double)bg[b] : 0.0;
     for (int i = i_begin + threadIdx.x; i < i_end; i += i_step) {
