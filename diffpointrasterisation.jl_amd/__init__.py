@@ -9,11 +9,12 @@ from .interface import (DimensionMismatch, PullbackResult, empty_grid, raster, r
                         raster_pullback_, raster_residual_pullback_, resolve_algo, sort_points,
                         to_grid_layout, workspace_bytes)
 from .timing import stage_times
+from .autograd import raster_ad
 from .sharded import (raster_point_sharded, raster_pullback_point_sharded_,
                       raster_pullback_sharded_, raster_sharded, shard_range)
 
 __all__ = [
-    "raster", "raster_", "raster_pullback_", "raster_residual_pullback_", "PullbackResult",
+    "raster", "raster_", "raster_ad", "raster_pullback_", "raster_residual_pullback_", "PullbackResult",
     "DimensionMismatch", "DprError",
     "empty_grid", "to_grid_layout", "workspace_bytes", "resolve_algo", "sort_points", "build", "lib",
     "stage_times", "raster_sharded", "raster_pullback_sharded_", "shard_range",
