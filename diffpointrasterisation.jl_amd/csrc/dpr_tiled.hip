@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/dpr.h"
 #include "dpr_device.h"
@@ -173,6 +174,17 @@ template <int NO> __device__ __forceinline__ int halo_index(const int (&h)[NO]) 
 template <typename T> struct alignas(4 * sizeof(T)) Rec4 {
     T v[4];
 };
+// Compact record {x, y, z} (12 / 24 bytes) for a forward-only binning with default point
+// weights on the write-combining scatter: a quarter less record traffic (C3 forward 266 -> 257
+// us).  A binning that a pullback consumes keeps 4-word records: the gradient record
+// overwrites them in place, and a separate gradient buffer costs the un-permute more (it falls
+// out of the Infinity Cache) than the smaller records save.
+template <typename T> struct Rec3 {
+    T v[3];
+};
+template <typename T, bool W3> struct RecSel { using type = Rec4<T>; };
+template <typename T> struct RecSel<T, true> { using type = Rec3<T>; };
+template <typename T, bool W3> using RecT = typename RecSel<T, W3>::type;
 __device__ __forceinline__ float idx_to_slot(uint32_t i, float) { return __uint_as_float(i); }
 __device__ __forceinline__ double idx_to_slot(uint32_t i, double) {
     return __longlong_as_double((long long)i);
@@ -453,13 +465,14 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
 // 16-byte pieces (measured: 10 M scattered 16-byte stores cost ~75 us more than coalesced
 // ones, profiles/r01_experiments.md).
 //   LDS: cursor[NT * nb] (dynamic) | lhist[NT] (dynamic) | recs[S] | dest[S]
-template <typename T, int NI, int NO, bool HAS_PW, int S, bool GROUP>
+template <typename T, int NI, int NO, bool HAS_PW, int S, bool GROUP, bool W3>
 __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
     int nb, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
-    Rec4<T>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
+    RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
     T* __restrict__ ds_dpw, int zero_dropped) {
+    static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kBinThreads;  // points per thread per sub-chunk
     // Pose group (nb > 1): the S points of a sub-chunk stay in registers while the poses of the
     // group are binned one after the other, each into its own NT bins -- the runs that are
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     extern __shared__ uint32_t dyn[];
     uint32_t* cursor = dyn;        // [NTe]
     uint32_t* lhist = dyn + NTe;   // [NT]
-    __shared__ Rec4<T> recs[S];
+    __shared__ RecT<T, W3> recs[S];
     __shared__ uint32_t dest[S];
     __shared__ uint32_t wsum[kBinThreads / kWave];
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
@@ -564,10 +577,10 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                 if (tile[k] >= 0) {
                     const uint32_t sidx = lhist[tile[k]] + lrank[k];
                     const uint32_t d = cur[tile[k]] + lrank[k];
-                    Rec4<T> r;
+                    RecT<T, W3> r;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
-                    r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+                    if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
                     recs[sidx] = r;
                     dest[sidx] = d;
                     if (slot_j) slot_j[p] = d;
@@ -599,9 +612,9 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
 }
 
 // ------------------------------------------------------------------ forward K4
-template <typename T, int NI, int NO, bool HAS_PW>
+template <typename T, int NI, int NO, bool HAS_PW, bool W3>
 __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
-    GridDesc<NO> gd, TileGeom<NO> tg, const Rec4<T>* __restrict__ rec,
+    GridDesc<NO> gd, TileGeom<NO> tg, const RecT<T, W3>* __restrict__ rec,
     const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
     const uint32_t* __restrict__ tile_slab, const T* __restrict__ rot,
     const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
 #define DPR_PF 2
 #endif
     constexpr int kPF = DPR_PF;
-    Rec4<T> nxt[kPF];
+    RecT<T, W3> nxt[kPF];
 #pragma unroll
     for (int u = 0; u < kPF; ++u) {
         const uint32_t ru = r + u * step;
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     }
     lds_barrier();  // LDS phases only: prefetched records stay in flight
     while (r < r1) {
-        Rec4<T> cur[kPF];
+        RecT<T, W3> cur[kPF];
 #pragma unroll
         for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
         const uint32_t r_cur = r;
@@ -660,12 +673,12 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         }
 #pragma unroll
         for (int u = 0; u < kPF; ++u) {
-            const Rec4<T> rc = cur[u];
+            const RecT<T, W3> rc = cur[u];
             const bool active = r_cur + u * step < r1;
             T pt[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
-            const T w = HAS_PW ? ps.ow * rc.v[3] : ps.ow * T(1);  // src/raster.jl:52
+            const T w = HAS_PW ? ps.ow * rc.v[HAS_PW ? 3 : 0] : ps.ow * T(1);  // src/raster.jl:52
             int ref0[NO];
             T dlo[NO];
             ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
@@ -1448,6 +1461,21 @@ template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
     return DPR_OK;
 }
 
+// Which scatter a binning uses: the write-combining one whenever its LDS tables fit and the
+// original indices are not needed as a separate array.
+static bool scatter_is_wc(int NT, int nb, bool has_pw, bool want_idx) {
+    const int wc = env_int("DPR_SCATTER_WC", 1) || nb > 1;
+    const bool needs_idx = has_pw && want_idx && env_int("DPR_BWD_UNPERMUTE", 1) == 0 && nb == 1;
+    return wc && NT * nb <= 4096 && !needs_idx;
+}
+
+// Compact 3-word records: default point weights, write-combining scatter, forward-only binning
+// (nothing downstream needs the original index or room for a gradient record).
+static bool records_are_compact(int NT, int nb, bool has_pw, bool want_idx) {
+    if (has_pw || want_idx || !env_int("DPR_COMPACT_RECORDS", 1)) return false;
+    return scatter_is_wc(NT, nb, has_pw, want_idx);
+}
+
 template <typename T, int NI, int NO, bool HAS_PW, bool WANT_IDX>
 static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                           const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
@@ -1455,21 +1483,26 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
                           int zero_dropped) {
     // write-combining variant: needs 2 NT counters + the sub-chunk in LDS, and does not
     // produce rec_idx (only the direct-store pullback mode with point weights reads that)
-    const int wc = env_int("DPR_SCATTER_WC", 1) || nb > 1;
-    const bool needs_idx =
-        HAS_PW && WANT_IDX && env_int("DPR_BWD_UNPERMUTE", 1) == 0 && nb == 1;
-    if (wc && tg.NT * nb <= 4096 && !needs_idx) {
+    if (scatter_is_wc(tg.NT, nb, HAS_PW, WANT_IDX)) {
         constexpr int S = (sizeof(T) == 4) ? 4096 : 2048;
         const size_t lds2 = (size_t)tg.NT * (nb + 1) * 4;
-#define DPR_LAUNCH_WC(GROUP)                                                                      \
-    hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S, GROUP>), dim3(pl.nblk),               \
+#define DPR_LAUNCH_WC(GROUP, W3)                                                                  \
+    hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S, GROUP, W3>), dim3(pl.nblk),           \
                        dim3(kBinThreads), lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, \
                        b, nb, (const uint32_t*)(ws + pl.off_counts),                             \
-                       (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),   \
+                       (const uint32_t*)(ws + pl.off_tile_start),                                \
+                       (RecT<T, W3>*)(ws + pl.off_rec),                     \
                        WANT_IDX ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr, d_pts,     \
                        d_pw, zero_dropped)
-        if (nb > 1) DPR_LAUNCH_WC(true);
-        else DPR_LAUNCH_WC(false);
+        if constexpr (!HAS_PW) {
+            if (records_are_compact(tg.NT, nb, false, WANT_IDX)) {
+                if (nb > 1) DPR_LAUNCH_WC(true, true);
+                else DPR_LAUNCH_WC(false, true);
+                return DPR_OK;
+            }
+        }
+        if (nb > 1) DPR_LAUNCH_WC(true, false);
+        else DPR_LAUNCH_WC(false, false);
 #undef DPR_LAUNCH_WC
         return DPR_OK;
     }
@@ -1570,15 +1603,17 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
         if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
                                            (int)nb, keep, (T*)nullptr, (T*)nullptr, 0))
             return rc;
-#define DPR_LAUNCH_SPLAT(HAS_PW)                                                                 \
-    hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW>), dim3(pl.max_items),                   \
-                       dim3(kSplatThreads), 0, st, gd, tg, (const Rec4<T>*)(ws + pl.off_rec),   \
+#define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
+    hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
+                       dim3(kSplatThreads), 0, st, gd, tg,                                      \
+                       (const RecT<T, W3>*)(ws + pl.off_rec),              \
                        (const WorkItem*)(ws + pl.off_items),                                    \
                        (const uint32_t*)(ws + pl.off_nitems),                                   \
                        (const uint32_t*)(ws + pl.off_tslab), rot, trans, ow, bg, b, out, halo,  \
                        ovf, blocked)
-        if (pw) DPR_LAUNCH_SPLAT(true);
-        else DPR_LAUNCH_SPLAT(false);
+        if (pw) DPR_LAUNCH_SPLAT(true, false);
+        else if (records_are_compact(tg.NT, (int)nb, false, keep)) DPR_LAUNCH_SPLAT(false, true);
+        else DPR_LAUNCH_SPLAT(false, false);
 #undef DPR_LAUNCH_SPLAT
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>),
