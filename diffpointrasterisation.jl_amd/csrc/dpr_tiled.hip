@@ -1239,8 +1239,8 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
         if (p >= P) continue;
         if (FIRST_POSE) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = g[k].v[j];
-            ds_dpw[p] = g[k].v[3];
+            for (int j = 0; j < NI; ++j) __builtin_nontemporal_store(g[k].v[j], &ds_dpoints[p * NI + j]);
+            __builtin_nontemporal_store(g[k].v[3], &ds_dpw[p]);
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] += g[k].v[j];
