@@ -583,9 +583,9 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
                     if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
                     recs[sidx] = r;
                     dest[sidx] = d;
-                    if (slot_j) slot_j[p] = d;
+                    if (slot_j) __builtin_nontemporal_store(d, &slot_j[p]);
                 } else if (p < hi) {
-                    if (slot_j) slot_j[p] = Pe;  // spare slot
+                    if (slot_j) __builtin_nontemporal_store(Pe, &slot_j[p]);  // spare slot
                     if (zero_dropped) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
@@ -759,8 +759,9 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
             const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
             const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
             if (in && x_ok)
-                o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x] =
-                    (T)(bgv + a);
+                __builtin_nontemporal_store(
+                    (T)(bgv + a),
+                    &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
         } else {
             int h[NO];
             h[0] = x;
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
                 lrow[k] = live ? row * (TX + 1) + x : -1;
                 const size_t off =
                     ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x;
-                v[k] = gb[in[k] ? off : 0];
+                v[k] = __builtin_nontemporal_load(&gb[in[k] ? off : 0]);
                 tv[k] = tb ? tb[in[k] ? off : 0] : T(0);
             }
 #pragma unroll
@@ -1219,7 +1220,7 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
 #pragma unroll
     for (int k = 0; k < kUPB; ++k) {
         const int64_t p = base + k * 1024;
-        slot[k] = slot_of[p < P ? p : P - 1];
+        slot[k] = __builtin_nontemporal_load(&slot_of[p < P ? p : P - 1]);
     }
     Rec4<T> g[kUPB];
 #pragma unroll
