@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
                 const size_t off =
                     ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x;
                 v[k] = __builtin_nontemporal_load(&gb[in[k] ? off : 0]);
-                tv[k] = tb ? tb[in[k] ? off : 0] : T(0);
+                tv[k] = tb ? __builtin_nontemporal_load(&tb[in[k] ? off : 0]) : T(0);
             }
 #pragma unroll
             for (int k = 0; k < kRB; ++k) {
