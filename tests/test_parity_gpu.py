@@ -422,7 +422,7 @@ def test_residual_pullback_reuses_forward_binning_and_rejects_chunked(oracle, de
 @pytest.mark.parametrize("n_in,n_out,grid_n,batch", [(3, 2, 96, 21), (3, 3, 40, 19), (2, 2, 64, 7)])
 @pytest.mark.parametrize("with_pw", [False, True])
 def test_pose_groups_equal_oracle(oracle, dev, npdt, tdt, n_in, n_out, grid_n, batch, with_pw):
-    """Grids with few tiles bin up to 16 poses together ((pose, tile) bins, DESIGN.md 4.5):
+    """Grids with few tiles bin up to 16 poses together ((pose, tile) bins, DESIGN.md 4.6):
     odd batch sizes decompose into groups of 16 / 4 / 2 / 1 poses.  Forward, pullback and the
     residual pullback against the oracle; a clustered cloud makes some (pose, tile) bins split."""
     d = D.make(n_points=30_000, n_in=n_in, n_out=n_out, batch=batch, grid_n=grid_n, seed=41, dtype=npdt)
