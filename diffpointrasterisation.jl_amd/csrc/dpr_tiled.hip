@@ -1031,6 +1031,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         const int x = lane % TX;
         const bool x_ok = x0[0] + x < gd.n[0];
         constexpr int STEP = (kGatherThreads / kWave) * RPW;
+        // an unsplit tile's ds_dout cells are read by this block only (plus the neighbours' halo
+        // rows): streamed with non-temporal loads; the parts of a split tile re-read them
+        auto stage_rows = [&](auto nt_tag) {
+        constexpr bool NT = decltype(nt_tag)::value;
         for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += STEP * kRB) {
             T v[kRB], tv[kRB];
             bool in[kRB], owned[kRB];
@@ -1047,8 +1051,9 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
                 lrow[k] = live ? row * (TX + 1) + x : -1;
                 const size_t off =
                     ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x;
-                v[k] = __builtin_nontemporal_load(&gb[in[k] ? off : 0]);
-                tv[k] = tb ? __builtin_nontemporal_load(&tb[in[k] ? off : 0]) : T(0);
+                const size_t oc = in[k] ? off : 0;
+                v[k] = NT ? __builtin_nontemporal_load(&gb[oc]) : gb[oc];
+                tv[k] = tb ? (NT ? __builtin_nontemporal_load(&tb[oc]) : tb[oc]) : T(0);
             }
 #pragma unroll
             for (int k = 0; k < kRB; ++k) {
@@ -1062,6 +1067,9 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
                 if (owned[k] && first_part) bg_sum += (double)val;
             }
         }
+        };
+        if ((item.part_nparts >> 16) > 1) stage_rows(std::false_type{});
+        else stage_rows(std::true_type{});
         // the x == TX column (halo cells only): one cell per row
         for (int row = threadIdx.x; row < ROWS; row += kGatherThreads) {
             const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
