@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
 // thread per ORIGINAL point: gradient record(s) of its slot(s) -> ds_dpoints /
 // ds_dpoint_weight (coalesced stores; accumulating over poses when !FIRST_POSE).  A pose
 // group contributes nb records per point, summed here in registers.
-template <typename T, int NI, bool FIRST_POSE>
+template <typename T, int NI, bool FIRST_POSE, int kUPB>
 __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
                                                     const Rec4<T>* __restrict__ grad,
                                                     const uint32_t* __restrict__ slot_of,
@@ -1222,7 +1222,6 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
     // One block covers kUPB * 1024 consecutive points = one sub-chunk of the scatter: points of
     // a sub-chunk that fell into the same tile sit next to each other in that tile's record
     // run, so the 64-byte sectors this block fetches are shared among its own threads.
-    constexpr int kUPB = 4;
     const int64_t base = (int64_t)xcd_slice(blockIdx.x, gridDim.x) * (kUPB * 1024) + threadIdx.x;
     uint32_t slot[kUPB];
 #pragma unroll
@@ -1694,15 +1693,21 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             else DPR_LAUNCH_GATHER(false, true, true);
             stage_mark(st);
             if (P > 0) {
-                const dim3 ug((unsigned)((P + 4095) / 4096));
-                if (b == 0)
-                    hipLaunchKernelGGL((k_unpermute<T, NI, true>), ug, dim3(1024), 0, st, P,
-                                       (int)nb, (const Rec4<T>*)(ws + pl.off_rec),
-                                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
-                else
-                    hipLaunchKernelGGL((k_unpermute<T, NI, false>), ug, dim3(1024), 0, st, P,
-                                       (int)nb, (const Rec4<T>*)(ws + pl.off_rec),
-                                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw);
+                // one pose: a block covers a whole scatter sub-chunk (4 points per thread); a
+                // pose group already has nb gradient records in flight per point
+#define DPR_LAUNCH_UNPERM(FIRST, UPB)                                                            \
+    hipLaunchKernelGGL((k_unpermute<T, NI, FIRST, UPB>),                                         \
+                       dim3((unsigned)((P + UPB * 1024 - 1) / (UPB * 1024))), dim3(1024), 0, st, \
+                       P, (int)nb, (const Rec4<T>*)(ws + pl.off_rec),                            \
+                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw)
+                if (nb > 1) {
+                    if (b == 0) DPR_LAUNCH_UNPERM(true, 1);
+                    else DPR_LAUNCH_UNPERM(false, 1);
+                } else {
+                    if (b == 0) DPR_LAUNCH_UNPERM(true, 4);
+                    else DPR_LAUNCH_UNPERM(false, 4);
+                }
+#undef DPR_LAUNCH_UNPERM
             }
         } else {
             if (pw) {
