@@ -1,25 +1,43 @@
 #!/usr/bin/env python3
-"""Headline benchmark: M points/s for forward + pullback, 10 M 3-D points -> 256^3 fp32 grid
-(BASELINE.json metric; config C3 = `configs[2]`), one pose per GPU.
+"""Benchmark of the raster! / raster_pullback! hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  python bench.py --gpus N --steps K --warmup W [--config C1..C5] [--shard poses|points]
 
-A "step" is one raster! + one raster_pullback! of this rank's pose over the full point
-cloud, inputs already resident in HBM.  At N > 1 the global problem is a batch of N poses
-sharded one per rank (weak scaling) and each step ends with the all-reduce(sum) of the
-fused [ds_dpoints | ds_dpoint_weight] buffer -- the only exchange the batched pullback has
-(/root/reference/src/raster_pullback.jl:141,146).  By default that all-reduce runs on RCCL's
-stream while the next step's kernels run (double-buffered; all of them complete inside the
-timed region); `--no-overlap-exchange` serialises it.
+BASELINE.json metric: "M points/s fwd+bwd, 10M pts -> 256^3 grid; HBM GB/s vs roofline".
+A "step" is one raster! + one raster_pullback! over this rank's share of the workload with all
+inputs already resident in HBM.  `value` counts (point, pose) pairs processed per second by
+the whole job.
 
-Besides the contract's JSON line fields this prints `roofline` (dominant kernel, HIP-event
-timed on the stream the kernels run on) and, on rank 0 at N = 1, `cpu_baseline` (the CPU
-oracle's threaded port of the reference algorithm on a bounded sample of the same workload).
+  N = 1 (default)   config C3 = BASELINE.json configs[2]: 10 M 3-D points -> 256^3 fp32, one pose.
+  N > 1 (default)   config C4 = configs[3]: 10 M points -> 512^2 projections, 512 poses GLOBAL,
+                    sharded over the ranks with `shard_range` (STRONG scaling: the job is fixed),
+                    one all-reduce(sum) of the fused [ds_dpoints | ds_dpoint_weight] buffer per
+                    step -- the only exchange the batched pullback has
+                    (/root/reference/src/raster_pullback.jl:112-147).  `--config C4 --gpus 1` is
+                    the 1-GPU point of the same curve; `--config C5` is the 50 M -> 512^3 fp64,
+                    64-pose job.
+  single-pose configs at N > 1:  `--shard poses` (weak: one pose per rank, all-reduce of the
+                    point gradients) or `--shard points` (strong: each rank owns a block of the
+                    points, all-reduce of the grid forward, of 13 scalars backward).
+
+Launching: with N > 1 and no RANK/WORLD_SIZE in the environment this script starts its own N
+rank processes (children are started BEFORE anything touches the GPU; the parent never does)
+with MASTER_ADDR=127.0.0.1.  Under `python -m torch.distributed.run ... bench.py --gpus N` the
+ranks are already there and each process runs as one rank.  One rank per GPU, RCCL ("nccl").
+DPR_BENCH_BACKEND=gloo is a rehearsal of the control flow on a box with fewer GPUs than ranks
+(ranks share devices, the exchange goes through host memory); never a measured configuration.
+
+Besides the contract's JSON fields the line carries `roofline` (forward call, HIP events on the
+launch stream, algorithmic bytes over device time), `no_share` (the same step when the pullback
+re-bins instead of reusing the forward's binning: what the plain C entry points give) and, on
+rank 0 at N = 1, `cpu_baseline` (threaded CPU port of the reference algorithm from oracle/, on
+a bounded sample of the same workload).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,42 +47,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+METRIC = "M points/s fwd+bwd, 10M pts→256³ grid; HBM GB/s vs roofline"
 CONFIGS = {
-    # name: (P, n_in, grid, dtype)
-    "C2": (1_000_000, 3, (128, 128, 128), "f32"),
-    "C3": (10_000_000, 3, (256, 256, 256), "f32"),
+    # BASELINE.json configs[0..4]
+    "C1": dict(P=1_000, n_in=2, grid=(5, 5), dt="f64", B=1, identity=True, ops="fwd+bwd",
+               what="1k random 2-D points -> 5x5, identity pose (plumbing)"),
+    "C2": dict(P=1_000_000, n_in=3, grid=(128, 128, 128), dt="f32", B=1, ops="fwd",
+               what="1M 3-D points -> 128^3 fp32, single pose, forward raster!"),
+    "C3": dict(P=10_000_000, n_in=3, grid=(256, 256, 256), dt="f32", B=1, ops="fwd+bwd",
+               what="10M 3-D points -> 256^3 fp32, single pose, raster! + raster_pullback!"),
+    "C4": dict(P=10_000_000, n_in=3, grid=(512, 512), dt="f32", B=512, ops="fwd+bwd",
+               what="10M 3-D points -> 512^2 orthographic projections, batch of 512 poses"),
+    "C5": dict(P=50_000_000, n_in=3, grid=(512, 512, 512), dt="f64", B=64, ops="fwd+bwd",
+               what="50M 3-D points -> 512^3 fp64, batch of 64 poses"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0  # measured float4 copy ceiling (same guide)
-
-
-def synth_inputs(cfg, rank, device, order, dist_kind="gauss"):
-    """points 0.4*N(0,I) seed 0 (test/data.jl:22,27); rotation uniform on
-    SO(3), translation 0.1*N(0,I), seed 1 (+rank); ds_dout N(0,1) seed 2 (+rank)."""
-    import torch
-
-    from tests import data as D
-
-    P, n_in, grid, dt = CONFIGS[cfg]
-    npdt = np.float32 if dt == "f32" else np.float64
-    rng = np.random.default_rng(0)
-    pts = (0.4 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
-    if dist_kind == "uniform":  # diagnostic only (balanced tiles); not the headline workload
-        pts = (1.1 * rng.random(size=(P, n_in), dtype=np.float32) - 0.55).astype(npdt)
-    if dist_kind == "tight":  # diagnostic only: a compact cluster, few heavily loaded tiles
-        pts = (0.1 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
-    if order == "morton":
-        pts = pts[morton_order(pts)]
-    prng = np.random.default_rng(1 + rank)
-    R = D.random_rotations(prng, 1, n_in)[:, : len(grid), :].astype(npdt)
-    t = (0.1 * prng.normal(size=(1, len(grid)))).astype(npdt)
-    tdt = torch.float32 if dt == "f32" else torch.float64
-    gen = torch.Generator(device=device)
-    gen.manual_seed(2 + rank)
-    g = torch.randn((1,) + tuple(reversed(grid)), device=device, dtype=tdt, generator=gen)
-    g = g.permute(*reversed(range(g.ndim)))  # [i1, i2, i3, b] view, reference memory order
-    to = lambda a: torch.as_tensor(a, device=device)
-    return dict(points=to(pts), R=to(R), t=to(t), ds_dout=g, np_points=pts, np_R=R, np_t=t)
 
 
 def morton_order(pts, bits=10):
@@ -77,50 +75,93 @@ def morton_order(pts, bits=10):
     return np.argsort(code, kind="stable")
 
 
-def algorithmic_bytes(cfg, with_point_weight=False):
+def synth_points(cfg, order="random", dist_kind="gauss"):
+    """points 0.4*N(0,I), seed 0 (test/data.jl:22,27)."""
+    c = CONFIGS[cfg]
+    P, n_in = c["P"], c["n_in"]
+    npdt = np.float32 if c["dt"] == "f32" else np.float64
+    rng = np.random.default_rng(0)
+    pts = (0.4 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
+    if dist_kind == "uniform":  # diagnostic only (balanced tiles); not the headline workload
+        pts = (1.1 * rng.random(size=(P, n_in), dtype=np.float32) - 0.55).astype(npdt)
+    if dist_kind == "tight":  # diagnostic only: a compact cluster, few heavily loaded tiles
+        pts = (0.1 * rng.standard_normal(size=(P, n_in), dtype=np.float32)).astype(npdt)
+    if order == "morton":
+        pts = pts[morton_order(pts)]
+    return pts
+
+
+def synth_poses(cfg, B, seed):
+    """rotation uniform on SO(3) (projection = its first rows), translation 0.1*N(0,I)
+    (test/data.jl:29-30, 54-56); C1: identity pose."""
+    from tests import data as D
+
+    c = CONFIGS[cfg]
+    n_in, n_out = c["n_in"], len(c["grid"])
+    npdt = np.float32 if c["dt"] == "f32" else np.float64
+    prng = np.random.default_rng(seed)
+    if c.get("identity"):
+        R = np.broadcast_to(np.eye(n_out, n_in), (B, n_out, n_in)).copy()
+        t = np.zeros((B, n_out))
+    else:
+        R = D.random_rotations(prng, B, n_in)[:, :n_out, :]
+        t = 0.1 * prng.normal(size=(B, n_out))
+    return R.astype(npdt), t.astype(npdt)
+
+
+def algorithmic_bytes(cfg, B, P=None, with_point_weight=False):
     """A_fwd = s[P(N_in+w) + B G]; A_bwd = s[P(N_in+w) + B G + P N_in + P]."""
-    P, n_in, grid, dt = CONFIGS[cfg]
-    s = 4 if dt == "f32" else 8
-    G = int(np.prod(grid))
+    c = CONFIGS[cfg]
+    P = c["P"] if P is None else P
+    s = 4 if c["dt"] == "f32" else 8
+    G = int(np.prod(c["grid"]))
     w = 1 if with_point_weight else 0
-    a_fwd = s * (P * (n_in + w) + G)
-    a_bwd = s * (P * (n_in + w) + G + P * n_in + P)
+    a_fwd = s * (P * (c["n_in"] + w) + B * G)
+    a_bwd = s * (P * (c["n_in"] + w) + B * G + P * c["n_in"] + P)
     return a_fwd, a_bwd
 
 
-def load_traffic_profile(args, algo_f):
+def load_traffic_profile(cfg, algo_f, order):
     """HBM bytes per forward call from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in
     separate rocprofv3 passes of this same command and corrected as MI355X_MICROARCH.md
     prescribes); measured offline, committed under profiles/ -- bench.py cannot profile itself."""
-    path = os.path.join(ROOT, "profiles", "r01_c3_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        prof = json.load(f)
-    key = f"{args.config}/{algo_f}/{args.order}"
-    ent = prof.get("forward", {}).get(key)
-    if not ent:
-        return None
-    return {"bytes": ent["hbm_bytes_corrected"], "source": f"profiles/r01_c3_hbm_traffic.json[{key}]"}
+    for name in ("r02_c3_hbm_traffic.json", "r01_c3_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            prof = json.load(f)
+        key = f"{cfg}/{algo_f}/{order}"
+        ent = prof.get("forward", {}).get(key)
+        if ent:
+            return {"bytes": ent["hbm_bytes_corrected"], "source": f"profiles/{name}[{key}]"}
+    return None
 
 
-def cpu_baseline(cfg, inp, budget_s=20.0):
-    """Threaded CPU port of the reference algorithm (oracle/, kind "port") on a bounded
-    sample: the first `n` points of the same cloud into the same grid, n chosen so the
-    fwd+bwd pair takes roughly `budget_s` seconds."""
+def cpu_baseline(cfg, np_points, np_R, np_t, np_g, budget_s=20.0):
+    """Threaded CPU port of the reference algorithm (oracle/, kind "port") on a bounded sample:
+    the first `n` points of the same cloud (and at most 2 poses) into the same grid, n chosen
+    so that the pass takes roughly `budget_s` seconds."""
     from oracle import oracle
 
-    P, n_in, grid, dt = CONFIGS[cfg]
-    npdt = np.float32 if dt == "f32" else np.float64
+    c = CONFIGS[cfg]
+    P, grid = c["P"], c["grid"]
+    npdt = np.float32 if c["dt"] == "f32" else np.float64
     threads = oracle.max_threads()
-    g = np.asfortranarray(inp["ds_dout"].cpu().numpy())
+    nb = min(2, np_R.shape[0])
+    R, t = np_R[:nb], np_t[:nb]  # the oracle takes batched arguments
+    bwd = "bwd" in c["ops"]
+    g = None
+    if bwd:
+        g = np_g if np_g.ndim == len(grid) + 1 else np_g[..., None]
+        g = np.asfortranarray(g[..., :nb])
 
     def run(n):
         t0 = time.perf_counter()
-        oracle.raster(grid, inp["np_points"][:n], inp["np_R"], inp["np_t"], dtype=npdt, threaded=True)
+        oracle.raster(grid, np_points[:n], R, t, dtype=npdt, threaded=True)
         t1 = time.perf_counter()
-        oracle.raster_pullback(g, inp["np_points"][:n], inp["np_R"], inp["np_t"], dtype=npdt,
-                               threaded=True)
+        if bwd:
+            oracle.raster_pullback(g, np_points[:n], R, t, dtype=npdt, threaded=True)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 
@@ -129,36 +170,61 @@ def cpu_baseline(cfg, inp, budget_s=20.0):
     rate = n / max(f + b, 1e-9)
     n2 = int(min(P, max(n, rate * budget_s)))
     f, b = run(n2)
-    return {
-        "value": round(n2 / (f + b) / 1e6, 4), "unit": "M points/s", "cores": threads,
+    poses = nb
+    res = {
+        "value": round(n2 * poses / (f + b) / 1e6, 4), "unit": "M points/s", "cores": threads,
         "kind": "port",
-        "sample": f"first {n2} of {P} points, same grid/pose; fwd {f:.2f}s on {threads} threads "
-                  f"(atomic scatter), bwd {b:.2f}s on 1 thread (the reference's batched pullback "
-                  f"is serial within a pose, src/raster_pullback.jl:39,115-139)",
-        "fwd_M_points_s": round(n2 / f / 1e6, 4), "bwd_M_points_s": round(n2 / b / 1e6, 4),
+        "sample": f"first {n2} of {P} points x {poses} pose(s), same grid/poses; fwd {f:.2f}s on "
+                  f"{threads} threads (atomic scatter)"
+                  + (f", bwd {b:.2f}s (threads over pose chunks; a single pose is serial, "
+                     f"src/raster_pullback.jl:39,115-139)" if bwd else ""),
+        "fwd_M_points_s": round(n2 * poses / f / 1e6, 4),
     }
+    if bwd:
+        res["bwd_M_points_s"] = round(n2 * poses / b / 1e6, 4)
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled", "chunked"])
-    ap.add_argument("--order", default="random", choices=["random", "morton"],
-                    help="point order in memory: as generated, or pre-sorted (pose-independent)")
-    ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform", "tight"])
-    ap.add_argument("--no-overlap-exchange", action="store_true",
-                    help="N > 1: finish each step's all-reduce before the next step starts")
-    ap.add_argument("--no-share-binning", action="store_true",
-                    help="make the pullback redo the binning instead of reusing the forward's")
-    ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary measurement on Morton-sorted points")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
+
+def launch_ranks(n):
+    """Start `n` rank processes of this script (one per GPU) and relay rank 0's output.  The
+    parent imports neither torch nor the HIP library: nothing here touches a GPU."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:  # one rank failed: the others would wait for it forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     import torch
 
     import dpr_amd
@@ -166,13 +232,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    # DPR_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs
-    # than ranks (ranks share devices, the all-reduce goes through host memory); never the
-    # measured configuration.
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} "
+                         f"(launch with --nproc-per-node {args.gpus}, or without a launcher)")
     backend = os.environ.get("DPR_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    if ndev == 0:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(
+            f"bench.py --gpus {world} needs {world} visible HIP devices, found {ndev} (one rank "
+            f"per GPU over RCCL).  DPR_BENCH_BACKEND=gloo rehearses the control flow with ranks "
+            f"sharing devices; it is not a measured configuration.")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
@@ -184,67 +256,118 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    P, n_in, grid, dt = CONFIGS[args.config]
+    cfg = args.config or ("C3" if world == 1 else "C4")
+    c = CONFIGS[cfg]
+    P, n_in, grid, dt = c["P"], c["n_in"], c["grid"], c["dt"]
+    n_out = len(grid)
     s_elem = 4 if dt == "f32" else 8
-    inp = synth_inputs(args.config, rank, device, args.order, args.dist)
-    tdt = inp["points"].dtype
-    out = dpr_amd.empty_grid(grid, 1, tdt, device)
-    fused = torch.empty(P * (n_in + 1), dtype=tdt, device=device)
-    d_pts = fused[: P * n_in].view(P, n_in)
-    d_pw = fused[P * n_in:]
-    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P, 1, n_in, tdt, args.algo),
-                   dpr_amd.workspace_bytes("pullback", grid, P, 1, n_in, tdt, args.algo))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    batched = c["B"] > 1
+    do_bwd = "bwd" in c["ops"]
+    shard = args.shard or ("poses" if batched or world == 1 else "poses")
+    if batched and shard != "poses":
+        raise SystemExit("batched configs shard over poses")
 
-    algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P, 1, n_in)
-    algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P, 1, n_in)
+    # ---- the rank's share of the job
+    np_pts = synth_points(cfg, args.order, args.dist)
+    if batched:
+        B_global = args.poses or c["B"]
+        lo, hi = dpr_amd.shard_range(B_global, rank, world)
+        np_R, np_t = synth_poses(cfg, B_global, seed=1)
+        np_R, np_t = np_R[lo:hi], np_t[lo:hi]
+        scaling = "strong"
+        P_local, p_lo = P, 0
+    elif shard == "points" and world > 1:
+        B_global = 1
+        lo, hi = 0, 1
+        np_R, np_t = synth_poses(cfg, 1, seed=1)
+        p_lo, p_hi = dpr_amd.shard_range(P, rank, world)
+        np_pts = np_pts[p_lo:p_hi]
+        P_local = p_hi - p_lo
+        scaling = "strong"
+    else:  # one pose per rank
+        B_global = world
+        lo, hi = rank, rank + 1
+        np_R, np_t = synth_poses(cfg, 1, seed=1 + rank)
+        scaling = "weak"
+        P_local, p_lo = P, 0
+    B_local = hi - lo
+    to = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
+    points = to(np_pts)
+    single_call = not batched  # single-pose signature (rotation is a matrix)
+    R = to(np_R[0] if single_call else np_R)
+    t = to(np_t[0] if single_call else np_t)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(2 + (0 if shard == "points" else rank))
+    gshape = tuple(reversed(grid)) if single_call else (B_local,) + tuple(reversed(grid))
+    g = None
+    if do_bwd and B_local > 0:
+        g = torch.randn(gshape, device=device, dtype=tdt, generator=gen)
+        g = g.permute(*reversed(range(g.ndim)))  # [i1, .., iN(, b)] view, reference memory order
+    out = dpr_amd.empty_grid(grid, None if single_call else B_local, tdt, device)
+    fused = torch.empty(P_local * (n_in + 1), dtype=tdt, device=device)
+    Bq = max(B_local, 1)
+    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P_local, Bq, n_in, tdt, args.algo),
+                   dpr_amd.workspace_bytes("pullback", grid, P_local, Bq, n_in, tdt, args.algo))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
+    algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P_local, Bq, n_in)
+    algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P_local, Bq, n_in)
     # The pullback reuses the tile binning its forward call built in the same step (what an
     # rrule caches between `raster` and its pullback closure); nothing is carried across steps.
-    share = (not args.no_share_binning) and algo_f == algo_b and algo_f in ("tiled", "chunked")
+    # Single pose only (DPR_FLAG_KEEP_BINNING needs B == 1).
+    can_share = single_call and do_bwd and algo_f == algo_b and algo_f in ("tiled", "chunked")
+    share = can_share and not args.no_share_binning
 
-    def fwd(keep=share):
-        dpr_amd.raster_(out, inp["points"], inp["R"], inp["t"], algo=algo_f, workspace=ws,
-                        keep_binning=keep)
+    def fwd(keep=None):
+        if B_local > 0:
+            dpr_amd.raster_(out, points, R, t, algo=algo_f, workspace=ws,
+                            keep_binning=share if keep is None else keep)
 
-    def bwd(reuse=share):
-        dpr_amd.raster_pullback_(inp["ds_dout"], inp["points"], inp["R"], inp["t"],
-                                 ds_dpoints=d_pts, ds_dpoint_weight=d_pw, algo=algo_b,
-                                 workspace=ws, reuse_binning=reuse)
+    def bwd(buf=fused, reuse=None):
+        if B_local == 0:
+            buf.zero_()  # a rank may own no pose when B < world size
+            return None
+        return dpr_amd.raster_pullback_(g, points, R, t, ds_dpoints=buf[: P_local * n_in].view(P_local, n_in),
+                                 ds_dpoint_weight=buf[P_local * n_in:], algo=algo_b, workspace=ws,
+                                 reuse_binning=share if reuse is None else reuse)
 
-    # Exchange of the point gradients (N > 1).  Default: the all-reduce of step k runs on RCCL's
-    # own stream while step k+1 computes into the other half of a double buffer (a rank that
-    # works through its poses one after the other overlaps exactly like this); every
-    # all-reduce is finished before the timed region's closing barrier.  --no-overlap-exchange
-    # waits for it inside the step.
-    overlap = world > 1 and backend == "nccl" and not args.no_overlap_exchange
+    # ---- exchange.  Pose sharding: all-reduce(sum) of the fused point-gradient buffer; by
+    # default step k's all-reduce runs on RCCL's stream under step k+1's kernels (double buffer;
+    # every all-reduce completes inside the timed region).  Point sharding: the forward
+    # all-reduces the grid, the pullback the per-pose scalars (13 values), inside the step.
+    pose_exchange = world > 1 and shard == "poses" and do_bwd
+    overlap = pose_exchange and backend == "nccl" and not args.no_overlap_exchange
     fused_alt = torch.empty_like(fused) if overlap else None
     pending = [None, None]
     step_no = [0]
 
-    def exchange(buf):
-        if world > 1:
-            if backend == "nccl":
-                return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=overlap)
-            host = buf.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            buf.copy_(host)
+    def all_reduce(buf, async_op=False):
+        if backend == "nccl":
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
+        host = buf.cpu()  # rehearsal backend: through host memory
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        buf.copy_(host)
         return None
 
-    def step():
+    def step(share_step=None):
         k = step_no[0] & 1 if overlap else 0
         step_no[0] += 1
         buf = fused_alt if k else fused
         if pending[k] is not None:
             pending[k].wait()  # the launch stream waits until this buffer's all-reduce is done
             pending[k] = None
-        fwd()
-        dpr_amd.raster_pullback_(inp["ds_dout"], inp["points"], inp["R"], inp["t"],
-                                 ds_dpoints=buf[: P * n_in].view(P, n_in),
-                                 ds_dpoint_weight=buf[P * n_in:], algo=algo_b, workspace=ws,
-                                 reuse_binning=share)
-        pending[k] = exchange(buf)
+        fwd(share_step)
+        if world > 1 and shard == "points":
+            all_reduce(out.permute(*reversed(range(out.ndim))))  # the contiguous grid buffer
+        if do_bwd:
+            res = bwd(buf, share_step)
+            if pose_exchange:
+                pending[k] = all_reduce(buf, async_op=overlap)
+            elif world > 1 and shard == "points":
+                # the per-pose sums of the one pose: ds_drotation | ds_dtranslation | ds_dout_weight
+                all_reduce(torch.cat([res.rotation.reshape(-1), res.translation.reshape(-1),
+                                      res.out_weight.reshape(-1)]))
 
     def drain():
         for k in (0, 1):
@@ -258,125 +381,199 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps, share_step=None):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(share_step)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt[0])
+        return el
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu",
-                          dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
+    elapsed = timed(args.steps)
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * P / (elapsed / args.steps) / 1e6  # M points/s, whole job
+    units = (B_global * P) if shard != "points" else P  # (point, pose) pairs per step, whole job
+    value = units / (elapsed / args.steps) / 1e6
 
     # ---- per-pass device time with HIP events on the launch stream (torch's current stream);
     # forward and pullback are timed inside fwd+bwd pairs (the pullback consumes -- and, when it
     # reuses the binning, destroys -- what its forward left in the workspace)
-    reps = max(5, min(args.steps, 20))
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(reps)]
+    reps = max(3, min(args.steps, 20))
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    evs = [(ev(), ev(), ev()) for _ in range(reps)]
     for e0, e1, e2 in evs:
         e0.record()
         fwd()
         e1.record()
-        bwd()
+        if do_bwd:
+            bwd()
         e2.record()
     torch.cuda.synchronize()
     ms_fwd = float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in evs]))
     ms_bwd = float(np.mean([e1.elapsed_time(e2) for _, e1, e2 in evs]))
-    a_fwd, a_bwd = algorithmic_bytes(args.config)
-    st_f = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
-    st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps, prepare=fwd)
-    stages = {"raster": {"algo": algo_f, **{k: round(v, 4) for k, v in st_f.items()}},
-              "pullback": {"algo": algo_b, **{k: round(v, 4) for k, v in st_b.items()}}}
-    # dominant kernel of the forward call, with the bytes that kernel itself has to move
-    kernel_bytes = {  # tiled pipeline, fp32/fp64 record = 4 values
-        "count": s_elem * P * n_in, "scatter": s_elem * P * n_in + 4 * s_elem * P,
-        "tile_splat": 4 * s_elem * P + s_elem * int(np.prod(grid)), "splat": a_fwd,
-        "chunk_splat": a_fwd}
-    dom = max((k for k in st_f if k != "total"), key=lambda k: st_f[k])
-    dominant = {"stage": dom, "ms": round(st_f[dom], 4)}
-    if dom in kernel_bytes:
-        dominant["bytes_moved_by_this_kernel"] = kernel_bytes[dom]
-        dominant["GBps"] = round(kernel_bytes[dom] / (st_f[dom] * 1e-3) / 1e9, 1)
-        dominant["frac_of_peak"] = round(kernel_bytes[dom] / (st_f[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    traffic = load_traffic_profile(args, algo_f)
-
-    # the same forward as a stand-alone call (no binning kept for a pullback: compact records,
-    # no slot map) -- what a forward-only user of raster! gets
-    fevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            for _ in range(reps)]
-    fwd(keep=False)
-    for e0, e1 in fevs:
-        e0.record()
-        fwd(keep=False)
-        e1.record()
-    torch.cuda.synchronize()
-    ms_fwd_alone = float(np.mean([e0.elapsed_time(e1) for e0, e1 in fevs]))
+    a_fwd, a_bwd = algorithmic_bytes(cfg, max(B_local, 1), P_local)
+    gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
     roof = {
         "bound": "hbm", "kernel": "raster! (all launches of one forward call, as run in the step)",
-        "achieved": round(a_fwd / (ms_fwd * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "traffic": traffic["bytes"] if traffic else None,
-        "traffic_source": traffic["source"] if traffic else None,
-        "dominant_kernel": dominant,
+        "achieved": round(gbs(a_fwd, ms_fwd), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(gbs(a_fwd, ms_fwd) / HBM_PEAK_GBS, 4), "traffic": None,
         "algorithmic_bytes": a_fwd, "ms": round(ms_fwd, 4),
-        "frac_of_measured_copy_peak": round(a_fwd / (ms_fwd * 1e-3) / 1e9 / HBM_COPY_GBS, 4),
-        "forward_stand_alone": {"ms": round(ms_fwd_alone, 4),
-                                "achieved": round(a_fwd / (ms_fwd_alone * 1e-3) / 1e9, 2),
-                                "frac": round(a_fwd / (ms_fwd_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "pullback": {"algorithmic_bytes": a_bwd, "ms": round(ms_bwd, 4),
-                     "achieved": round(a_bwd / (ms_bwd * 1e-3) / 1e9, 2),
-                     "frac": round(a_bwd / (ms_bwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "frac_of_measured_copy_peak": round(gbs(a_fwd, ms_fwd) / HBM_COPY_GBS, 4),
     }
-    if stages:
+    traffic = load_traffic_profile(cfg, algo_f, args.order)
+    if traffic:
+        roof["traffic"], roof["traffic_source"] = traffic["bytes"], traffic["source"]
+    if do_bwd:
+        roof["pullback"] = {"algorithmic_bytes": a_bwd, "ms": round(ms_bwd, 4),
+                            "achieved": round(gbs(a_bwd, ms_bwd), 2),
+                            "frac": round(gbs(a_bwd, ms_bwd) / HBM_PEAK_GBS, 4)}
+    if batched:
+        roof["note"] = ("batched poses re-read the points per pose (group): the per-call "
+                        "algorithmic bytes count them once, BASELINE.md section 3")
+    if single_call and B_local == 1:
+        st_f = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
+        stages = {"raster": {"algo": algo_f, **{k: round(v, 4) for k, v in st_f.items()}}}
+        if do_bwd:
+            st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps, prepare=fwd)
+            stages["pullback"] = {"algo": algo_b, **{k: round(v, 4) for k, v in st_b.items()}}
         roof["stages"] = stages
+        dom = max((k for k in st_f if k != "total"), key=lambda k: st_f[k])
+        roof["dominant_stage"] = {"stage": dom, "ms": round(st_f[dom], 4)}
+        if can_share:
+            # the same forward as a stand-alone call (no binning kept for a pullback)
+            fevs = [(ev(), ev()) for _ in range(reps)]
+            fwd(keep=False)
+            for e0, e1 in fevs:
+                e0.record()
+                fwd(keep=False)
+                e1.record()
+            torch.cuda.synchronize()
+            ms_alone = float(np.mean([e0.elapsed_time(e1) for e0, e1 in fevs]))
+            roof["forward_stand_alone"] = {"ms": round(ms_alone, 4),
+                                           "achieved": round(gbs(a_fwd, ms_alone), 2),
+                                           "frac": round(gbs(a_fwd, ms_alone) / HBM_PEAK_GBS, 4)}
 
+    exchange = "none"
+    if world > 1 and shard == "poses" and do_bwd:
+        exchange = (f"all-reduce(sum) of [ds_dpoints|ds_dpoint_weight] ({backend})"
+                    + (", overlapped with the next step's kernels (double buffer)" if overlap
+                       else ", inside the step"))
+    elif world > 1 and shard == "points":
+        exchange = f"all-reduce(sum) of the grid (forward) and of the per-pose scalars ({backend})"
     line = {
-        "metric": "M points/s fwd+bwd, 10M pts→256³ grid; HBM GB/s vs roofline",
-        "value": round(value, 3), "unit": "M points/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
-        "config": {"workload": f"{args.config}: {P} 3-D points ({ {'gauss': '0.4*N(0,I)', 'uniform': 'uniform(-.55,.55)', 'tight': '0.1*N(0,I)'}[args.dist] }, {args.order} order) -> "
-                               f"{'x'.join(map(str, grid))} {dt} grid, one pose per GPU, "
-                               f"raster! + raster_pullback!",
-                   "algo": {"raster": algo_f, "pullback": algo_b}, "pullback_reuses_forward_binning": share,
-                   "poses_global": world, "point_order": args.order,
-                   "exchange": (f"all-reduce(sum) of [ds_dpoints|ds_dpoint_weight] ({backend})"
-                                + (", overlapped with the next step's kernels (double buffer)"
-                                   if overlap else ", inside the step")
-                                if world > 1 else "none")},
+        "metric": METRIC, "value": round(value, 3), "unit": "M points/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dt,
+        "data": "synthetic",
+        "config": {
+            "workload": f"{cfg}: {c['what']}; points "
+                        f"{ {'gauss': '0.4*N(0,I)', 'uniform': 'uniform(-.55,.55)', 'tight': '0.1*N(0,I)'}[args.dist] }"
+                        f", {args.order} order; {c['ops']}",
+            "algo": {"raster": algo_f, "pullback": algo_b if do_bwd else None},
+            "pullback_reuses_forward_binning": bool(share), "poses_global": B_global,
+            "poses_per_rank": B_local if world == 1 else f"{B_global // world}..{-(-B_global // world)}",
+            "sharding": shard if world > 1 else "none", "point_order": args.order,
+            "exchange": exchange},
         "roofline": roof,
     }
-    if world == 1 and args.order == "random" and not args.no_secondary:
+    if can_share and not args.no_share_binning and world == 1:
+        # the drop-in number: plain entry points (no KEEP/REUSE flags), the pullback re-bins
+        for _ in range(max(1, args.warmup)):
+            step(False)
+        el = timed(args.steps, False)
+        line["no_share"] = {"ms_per_step": round(el / args.steps * 1e3, 4),
+                            "value": round(units / (el / args.steps) / 1e6, 3),
+                            "unit": "M points/s",
+                            "what": "pullback re-bins (plain dpr_raster_* / dpr_raster_pullback_* "
+                                    "entry points, no DPR_FLAG_KEEP/REUSE_BINNING)"}
+    if world == 1 and args.order == "random" and not args.no_secondary and cfg in ("C2", "C3"):
         # secondary line: the same cloud pre-sorted once in the model frame (Morton order; the
         # sort is pose-independent, so a user amortises it over poses and iterations)
-        inp["points"], _perm = dpr_amd.sort_points(inp["points"])  # dpr_sort_points_f32
+        sorted_pts, _perm = dpr_amd.sort_points(points)  # dpr_sort_points_f32
+        points_random = points
+        points = sorted_pts
+        coherent_kw = {}
+
+        def fwd_c(keep=None):
+            dpr_amd.raster_(out, points, R, t, algo=algo_f, workspace=ws,
+                            keep_binning=share if keep is None else keep, **coherent_kw)
+
+        def bwd_c():
+            dpr_amd.raster_pullback_(g, points, R, t, ds_dpoints=fused[: P * n_in].view(P, n_in),
+                                     ds_dpoint_weight=fused[P * n_in:], algo=algo_b,
+                                     workspace=ws, reuse_binning=share, **coherent_kw)
+
+        def step_c():
+            fwd_c()
+            if do_bwd:
+                bwd_c()
+
         for _ in range(args.warmup):
-            step()
+            step_c()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step_c()
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / args.steps
-        st_fm = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
-        st_bm = dpr_amd.stage_times(bwd, "pullback", algo_b, reps, prepare=fwd)
-        line["coherent_input"] = {
-            "point_order": "morton (dpr_sort_points once, not timed)", "value": round(P / el / 1e6, 3),
-            "unit": "M points/s", "ms_per_step": round(el * 1e3, 4),
-            "raster_ms": round(st_fm["total"], 4), "pullback_ms": round(st_bm["total"], 4),
-            "raster_frac_of_hbm_peak": round(a_fwd / (st_fm["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        st_fm = dpr_amd.stage_times(fwd_c, "raster", algo_f, reps)
+        coh = {"point_order": "morton (dpr_sort_points once, not timed)",
+               "value": round(P / el / 1e6, 3), "unit": "M points/s",
+               "ms_per_step": round(el * 1e3, 4), "raster_ms": round(st_fm["total"], 4),
+               "raster_frac_of_hbm_peak": round(gbs(a_fwd, st_fm["total"]) / HBM_PEAK_GBS, 4),
+               "raster_stages": {k: round(v, 4) for k, v in st_fm.items()}}
+        if do_bwd:
+            st_bm = dpr_amd.stage_times(bwd_c, "pullback", algo_b, reps, prepare=fwd_c)
+            coh["pullback_ms"] = round(st_bm["total"], 4)
+        line["coherent_input"] = coh
+        points = points_random
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.config, inp, args.cpu_budget)
+        np_g = None
+        if do_bwd:
+            np_g = (g[..., :2] if batched else g).cpu().numpy()
+        line["cpu_baseline"] = cpu_baseline(cfg, np_pts, np_R, np_t, np_g, args.cpu_budget)
     if rank == 0:
-        print(json.dumps(line, ensure_ascii=False))
+        print(json.dumps(line, ensure_ascii=False), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: C3 at --gpus 1, C4 (512 poses, strong scaling) at --gpus N > 1")
+    ap.add_argument("--shard", default=None, choices=["poses", "points"],
+                    help="single-pose configs at N > 1: one pose per rank (weak) or a block of "
+                         "the points per rank (strong)")
+    ap.add_argument("--poses", type=int, default=None,
+                    help="batched configs: global number of poses (default: the config's)")
+    ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled", "chunked"])
+    ap.add_argument("--order", default="random", choices=["random", "morton"],
+                    help="point order in memory: as generated, or pre-sorted (pose-independent)")
+    ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform", "tight"])
+    ap.add_argument("--no-overlap-exchange", action="store_true",
+                    help="N > 1: finish each step's all-reduce before the next step starts")
+    ap.add_argument("--no-share-binning", action="store_true",
+                    help="make the pullback redo the binning instead of reusing the forward's")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurement on Morton-sorted points")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # children first; this process never touches a GPU
+    run_rank(args)
 
 
 if __name__ == "__main__":
