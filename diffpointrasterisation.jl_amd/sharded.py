@@ -74,7 +74,7 @@ def raster_pullback_sharded_(ds_dout_local, points, rotation_local, translation_
         n_out = rotation_local.shape[1]
         z = lambda *s: torch.zeros(s, dtype=dtype, device=points.device)
         res = PullbackResult(d_pts, z(0, n_out, n_in), z(0, n_out), z(0), z(0), d_pw)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():  # also at world size 1: the same stream hand-over as at N ranks
         dist.all_reduce(fused_buffer, op=dist.ReduceOp.SUM, group=group)
     return PullbackResult(d_pts, res.rotation, res.translation, res.background, res.out_weight,
                           d_pw)
@@ -99,7 +99,7 @@ def raster_point_sharded(grid_size, points_local, rotation, translation, backgro
     bg = background if rank == 0 else None  # the background must be counted once
     out = local_raster(grid_size, points_local, rotation, translation, bg, out_weight,
                        point_weight_local, **kw)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         flat = out.permute(*reversed(range(out.ndim)))  # the contiguous buffer behind the view
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return out
@@ -115,7 +115,7 @@ def raster_pullback_point_sharded_(ds_dout, points_local, rotation, translation,
     dist = _dist()
     res = local_pullback(ds_dout, points_local, rotation, translation, background, out_weight,
                          point_weight_local, **kw)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         rot, tr, ow = res.rotation, res.translation, res.out_weight
         fused = torch.cat([rot.reshape(-1), tr.reshape(-1), ow.reshape(-1)])
         dist.all_reduce(fused, op=dist.ReduceOp.SUM, group=group)

@@ -1,0 +1,318 @@
+"""GPU tests of the BASELINE.json configurations at their stated one-GPU sizes, of the plain
+(non-`_ex`) C entry points exactly as INTEGRATION.md binds them, of AUTO at a size where it
+picks the tiled pipeline against the oracle (with the SURVEY.md 8(c) flip report), and of the
+sharded drivers with the real HIP local compute under an RCCL ("nccl") process group."""
+import ctypes
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import dpr_amd
+from tests import data as D
+from tests.conftest import ROOT
+from tests.test_parity_gpu import T, _ball_points, _compare, assert_close, grid_to_dev, tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    dpr_amd.lib()  # fail loudly if the extension is missing: there is no fallback
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ C1, literally
+@pytest.mark.parametrize("algo", ["auto", "atomic", "tiled", "chunked"])
+def test_c1_1k_points_5x5_identity(oracle, dev, algo):
+    """BASELINE.json configs[0]: 1 000 random 2-D points -> 5x5 grid, identity pose, fp64,
+    raster + raster_pullback! against the oracle (src/raster.jl:5-34, raster_pullback.jl:2-82)."""
+    rng = np.random.default_rng(0)
+    pts = 0.4 * rng.standard_normal(size=(1000, 2))
+    R, t = np.eye(2)[None], np.zeros((1, 2))
+    g = np.asfortranarray(rng.normal(size=(5, 5, 1)))
+    ref = oracle.raster((5, 5), pts, R, t)
+    rpb = oracle.raster_pullback(g, pts, R, t)
+    out = dpr_amd.raster((5, 5), T(pts, dev), T(R[0], dev), T(t[0], dev), algo=algo)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g[..., 0], dev), T(pts, dev), T(R[0], dev),
+                                  T(t[0], dev), algo=algo)
+    assert_close(out, ref[..., 0], 1e-10, "out")
+    assert_close(pb.points, rpb.points, 1e-10, "ds_dpoints")
+    assert_close(pb.rotation, rpb.rotation[0], 1e-10, "ds_drotation")
+    assert_close(pb.translation, rpb.translation[0], 1e-10, "ds_dtranslation")
+    assert_close(pb.point_weight, rpb.point_weight, 1e-10, "ds_dpoint_weight")
+    assert abs(float(pb.background) - rpb.background[0]) <= 1e-10 * abs(rpb.background[0])
+    assert abs(float(pb.out_weight) - rpb.out_weight[0]) <= 1e-10 * abs(rpb.out_weight[0])
+
+
+# ------------------------------------------------------------------ C4 at its one-GPU share
+def test_c4_share_64_poses(dev):
+    """BASELINE.json configs[3] at the share one of 8 GPUs owns: 10 M points -> 512^2
+    orthographic projections, 64 poses, fp32, AUTO.  Size-independent properties: mass per
+    pose, a pose of the batch == the single-pose call, adjoint identity
+    <g, out - bg> = ow * d/d(ow) per pose, ds_dbackground = sum(ds_dout)."""
+    P, n, B = 10_000_000, 512, 64
+    f32 = dict(device=dev, dtype=torch.float32)
+    pts = _ball_points(P, dev, torch.float32)
+    rng = np.random.default_rng(5)
+    R = T(D.random_rotations(rng, B)[:, :2, :].astype(np.float32), dev)
+    t = T((0.05 * rng.normal(size=(B, 2))).clip(-0.1, 0.1).astype(np.float32), dev)
+    ow = torch.linspace(0.5, 2.0, B, **f32)
+    bg = torch.linspace(-1.0, 1.0, B, **f32)
+    out = dpr_amd.raster((n, n), pts, R, t, bg, ow)
+    sums = out.double().sum(dim=(0, 1)).cpu().numpy()
+    expect = ow.double().cpu().numpy() * P + bg.double().cpu().numpy() * n * n
+    np.testing.assert_allclose(sums, expect, rtol=2e-4)
+    for b in (0, 37, 63):
+        single = dpr_amd.raster((n, n), pts, R[b], t[b], float(bg[b]), float(ow[b]))
+        assert_close(out[..., b], single.cpu().numpy(), 2e-5, f"pose {b} of the batch vs single call")
+    g = torch.randn(B, n, n, **f32).permute(2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow)
+    lhs = (g.double() * (out.double() - bg.double())).sum(dim=(0, 1)).cpu().numpy()
+    rhs = (ow.double() * pb.out_weight.double()).cpu().numpy()
+    np.testing.assert_allclose(lhs, rhs, rtol=2e-3, atol=2e-3 * np.sqrt(P))
+    np.testing.assert_allclose(pb.background.double().cpu().numpy(),
+                               g.double().sum(dim=(0, 1)).cpu().numpy(), rtol=0, atol=1e-3 * n)
+    # batch == sum over a loop of single-pose pullbacks (test/util.jl:26-34), on 3 poses
+    sub = [5, 21, 50]
+    pb_sub = dpr_amd.raster_pullback_(dpr_amd.to_grid_layout(g[..., sub]), pts, R[sub], t[sub],
+                                      bg[sub], ow[sub])
+    acc = torch.zeros_like(pb_sub.points)
+    for k, b in enumerate(sub):
+        one = dpr_amd.raster_pullback_(dpr_amd.to_grid_layout(g[..., b]), pts, R[b], t[b],
+                                       float(bg[b]), float(ow[b]))
+        acc += one.points
+        assert_close(pb_sub.rotation[k], one.rotation.cpu().numpy(), 1e-3, "ds_drotation")
+    assert_close(pb_sub.points, acc.cpu().numpy(), 1e-4, "batched ds_dpoints == sum of singles")
+
+
+# ------------------------------------------------------------------ C5 at its one-GPU share
+def test_c5_share_8_poses(dev):
+    """BASELINE.json configs[4] at the share one of 8 GPUs owns: 50 M points -> 512^3 fp64,
+    8 poses (out and ds_dout: 8.6 GB each).  Mass per pose, constant-sensitivity pullback,
+    adjoint identity per pose."""
+    P, n, B = 50_000_000, 512, 8
+    f64 = dict(device=dev, dtype=torch.float64)
+    pts = _ball_points(P, dev, torch.float64, seed=3)
+    rng = np.random.default_rng(2)
+    R = T(D.random_rotations(rng, B), dev)
+    t = T((0.05 * rng.normal(size=(B, 3))).clip(-0.1, 0.1), dev)
+    ow = torch.linspace(0.5, 1.5, B, **f64)
+    out = dpr_amd.raster((n, n, n), pts, R, t, None, ow)
+    for b in range(B):
+        assert abs(float(out[..., b].sum()) - float(ow[b]) * P) <= 1e-9 * P
+    g = torch.randn(B, n, n, n, **f64).permute(3, 2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, None, ow)
+    for b in range(B):
+        gb = g[..., b]
+        assert abs(float(pb.background[b]) - float(gb.sum())) <= 1e-8 * float(gb.abs().sum())
+        lhs = float((gb * out[..., b]).sum())
+        rhs = float(ow[b]) * float(pb.out_weight[b])
+        assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.0)
+    del out
+    g.fill_(0.5)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, None, ow)
+    assert float(pb.points.abs().max()) <= 1e-9 * n * B
+    assert_close(pb.point_weight, np.full(P, 0.5 * float(ow.sum())), 1e-12)
+
+
+@pytest.mark.parametrize("algo", ["auto", "tiled"])
+def test_512_cube_fp64_vs_oracle(oracle, dev, algo):
+    """HIP vs oracle on the C5 grid (512^3 fp64: 16384 tiles) with 1e5 points, all optional
+    arguments given, two poses."""
+    d = D.make(n_points=100_000, n_in=3, n_out=3, batch=2, grid_n=512, seed=21, dtype=np.float64)
+    opt = (d.backgrounds, d.weights, d.point_weights)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, *opt)
+    out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev),
+                         *[T(o, dev) for o in opt], algo=algo)
+    assert_close(out, ref_out, 1e-10, "out")
+    del ref_out, out
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, opt[1], opt[2])
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), T(d.points, dev), T(d.rotations, dev),
+                                  T(d.translations, dev), *[T(o, dev) for o in opt], algo=algo)
+    for name in ("points", "rotation", "translation", "background", "out_weight", "point_weight"):
+        assert_close(getattr(pb, name), getattr(ref_pb, name), 1e-10, name)
+
+
+# ------------------------------------------------------------------ AUTO -> tiled vs oracle, flip report
+def _cell_flips(pts32, R, t, n):
+    """Number of (point, axis) pairs whose cell choice ceil(coord - 1/2) differs between fp32
+    and fp64 arithmetic on the same fp32 inputs (src/raster.jl:88-99 evaluated both ways)."""
+    R32, t32 = R.astype(np.float32), t.astype(np.float32)
+    proj = pts32[:, 0:1] * R32[:, 0][None]
+    for j in range(1, pts32.shape[1]):
+        proj = proj + pts32[:, j:j + 1] * R32[:, j][None]
+    c32 = (proj - (np.float32(-1) - t32)) * np.float32(n / 2) - np.float32(0.5)
+    c64 = ((pts32.astype(np.float64) @ R32.astype(np.float64).T) - (-1.0 - t32.astype(np.float64))) * (n / 2) - 0.5
+    return int((np.ceil(c32) != np.ceil(c64)).sum())
+
+
+def test_c2_full_size_auto_vs_oracle_with_flip_report(oracle, dev):
+    """BASELINE.json configs[1] at full size (1 M points -> 128^3, fp32, one pose) with
+    algo="auto" -- which resolves to the TILED pipeline here -- against the fp32 AND the fp64
+    oracle; prints the SURVEY.md 8(c) report: max-abs errors and the number of fp32-vs-fp64
+    cell-selection flips."""
+    P, n = 1_000_000, 128
+    assert dpr_amd.resolve_algo("raster", (n,) * 3, P, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (n,) * 3, P, 1, 3) == "tiled"
+    rng = np.random.default_rng(0)
+    pts = (0.4 * rng.standard_normal(size=(P, 3), dtype=np.float32))
+    R = D.random_rotations(np.random.default_rng(1), 1).astype(np.float32)
+    t = (0.1 * np.random.default_rng(1).normal(size=(1, 3))).astype(np.float32)
+    g = np.asfortranarray(rng.standard_normal(size=(n, n, n, 1), dtype=np.float32))
+    ref32 = oracle.raster((n,) * 3, pts, R, t, dtype=np.float32)
+    ref64 = oracle.raster((n,) * 3, pts, R, t, dtype=np.float64)
+    out = dpr_amd.raster((n,) * 3, T(pts, dev), T(R[0], dev), T(t[0], dev))  # algo="auto"
+    o = out.cpu().numpy()
+    assert_close(o, ref32[..., 0], tol(np.float32, "out"), "out vs fp32 oracle")
+    assert_close(o, ref64[..., 0].astype(np.float32), 5e-5, "out vs fp64 oracle")
+    rpb = oracle.raster_pullback(g, pts, R, t, dtype=np.float32)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g[..., 0], dev), T(pts, dev), T(R[0], dev), T(t[0], dev))
+    assert_close(pb.points, rpb.points, tol(np.float32, "points"), "ds_dpoints")
+    assert_close(pb.rotation, rpb.rotation[0], tol(np.float32, "pose"), "ds_drotation")
+    assert_close(pb.translation, rpb.translation[0], tol(np.float32, "pose"), "ds_dtranslation")
+    report = {
+        "config": "C2: 1M points -> 128^3 fp32, algo=auto (tiled)",
+        "out_max_abs_err_vs_fp32_oracle": float(np.abs(o - ref32[..., 0]).max()),
+        "out_max_abs_err_vs_fp64_oracle": float(np.abs(o - ref64[..., 0]).max()),
+        "out_max_abs": float(np.abs(ref64).max()),
+        "ds_dpoints_max_abs_err_vs_fp32_oracle": float(np.abs(pb.points.cpu().numpy() - rpb.points).max()),
+        "cell_selection_flips_fp32_vs_fp64": _cell_flips(pts, R[0], t[0], n),
+        "point_axis_pairs": 3 * P,
+    }
+    print("PARITY-REPORT " + json.dumps(report))
+    outdir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
+        with open(os.path.join(outdir, "parity_report_c2.json"), "w") as f:
+            json.dump(report, f, indent=1)
+
+
+# ------------------------------------------------------------------ the plain C entry points
+def _vp(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("suf,npdt,tdt", [("f32", np.float32, torch.float32),
+                                          ("f64", np.float64, torch.float64)])
+def test_plain_entry_points_as_integration_md_binds_them(oracle, dev, suf, npdt, tdt):
+    """dpr_raster_<T>, dpr_raster_pullback_<T> and dpr_raster_residual_pullback_<T> through raw
+    ctypes with exactly the argument lists of INTEGRATION.md / the Julia extension's ccalls,
+    workspace sized by dpr_workspace_bytes_<T>(op, algo=0, ...), P = 3e5 so that AUTO picks
+    the tiled pipeline; results against the oracle."""
+    L = dpr_amd.lib()
+    P, n, B = 300_000, 96, 1
+    d = D.make(n_points=P, n_in=3, n_out=3, batch=B, grid_n=n, seed=5, dtype=npdt)
+    grid = np.array([n, n, n], dtype=np.int64)
+    gp = grid.ctypes.data_as(ctypes.c_void_p)
+    assert L.dpr_resolve_algo(dpr_amd._lib.OP_RASTER, 3, 3, gp, P, B) == dpr_amd._lib.ALGO_TILED
+    wsq = getattr(L, f"dpr_workspace_bytes_{suf}")
+    need = max(wsq(dpr_amd._lib.OP_RASTER, 0, 3, 3, gp, P, B),
+               wsq(dpr_amd._lib.OP_PULLBACK, 0, 3, 3, gp, P, B))
+    assert 0 < need < 1 << 32
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    pts = T(d.points, dev)
+    rot_cm = T(np.ascontiguousarray(np.transpose(d.rotations, (0, 2, 1))), dev)  # col-major poses
+    trans, bg, ow, pw = T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev), T(d.point_weights, dev)
+    out = torch.full((B, n, n, n), float("nan"), dtype=tdt, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = getattr(L, f"dpr_raster_{suf}")(stream, 3, 3, gp, P, B, _vp(out), _vp(pts), _vp(rot_cm),
+                                         _vp(trans), _vp(bg), _vp(ow), _vp(pw), _vp(ws), need)
+    assert rc == 0, dpr_amd._lib.last_error()
+    ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                        d.point_weights, dtype=npdt)
+    assert_close(out.permute(3, 2, 1, 0), ref, tol(npdt, "out"), "dpr_raster out")
+    g = torch.as_tensor(np.ascontiguousarray(np.transpose(d.ds_dout, (3, 2, 1, 0))), device=dev)
+    outs = [torch.full(s, float("nan"), dtype=tdt, device=dev)
+            for s in [(P, 3), (B, 3, 3), (B, 3), (B,), (B,), (P,)]]
+    rc = getattr(L, f"dpr_raster_pullback_{suf}")(
+        stream, 3, 3, gp, P, B, _vp(g), _vp(pts), _vp(rot_cm), _vp(trans), _vp(ow), _vp(pw),
+        *[_vp(o) for o in outs], _vp(ws), need)
+    assert rc == 0, dpr_amd._lib.last_error()
+    rpb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                 d.point_weights, dtype=npdt)
+    assert_close(outs[0], rpb.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(outs[1].transpose(1, 2), rpb.rotation, tol(npdt, "pose"), "ds_drotation")
+    assert_close(outs[2], rpb.translation, tol(npdt, "pose"), "ds_dtranslation")
+    assert_close(outs[3], rpb.background, tol(npdt, "pose"), "ds_dbackground")
+    assert_close(outs[4], rpb.out_weight, tol(npdt, "pose"), "ds_dout_weight")
+    assert_close(outs[5], rpb.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    # residual form: out, target, scale ... loss, six outputs
+    target = torch.as_tensor(np.ascontiguousarray(np.transpose(d.ds_dout, (3, 2, 1, 0))), device=dev)
+    loss = torch.full((B,), float("nan"), dtype=tdt, device=dev)
+    outs2 = [torch.full_like(o, float("nan")) for o in outs]
+    rc = getattr(L, f"dpr_raster_residual_pullback_{suf}")(
+        stream, 3, 3, gp, P, B, _vp(out), _vp(target), ctypes.c_double(2.0), _vp(pts), _vp(rot_cm),
+        _vp(trans), _vp(ow), _vp(pw), _vp(loss), *[_vp(o) for o in outs2], _vp(ws), need)
+    assert rc == 0, dpr_amd._lib.last_error()
+    res, ref_loss = oracle.residual_pullback(ref, d.ds_dout, d.points, d.rotations, d.translations,
+                                             d.weights, d.point_weights, scale=2.0, dtype=npdt)
+    assert_close(outs2[0], res.points, 10 * tol(npdt, "points"), "residual ds_dpoints")
+    assert_close(loss, ref_loss.astype(npdt), 1e-4 if npdt == np.float32 else 1e-10, "loss")
+
+
+# ------------------------------------------------------------------ sharded drivers over RCCL
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.fixture()
+def nccl_world1(dev):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pose_and_point_sharded_drivers_with_hip_compute_over_nccl(oracle, dev, nccl_world1):
+    """`raster_sharded` / `raster_pullback_sharded_` and the point-sharded pair with their
+    default (HIP) local compute inside an RCCL process group of one rank: the kernels libdpr
+    enqueues on torch's stream feed the fused buffer / the grid straight into
+    `dist.all_reduce` (which runs on RCCL's own stream).  Compared with the oracle."""
+    npdt = np.float32
+    d = D.make(n_points=400_000, n_in=3, n_out=3, batch=3, grid_n=64, seed=9, dtype=npdt)
+    pts, Rs, ts = T(d.points, dev), T(d.rotations, dev), T(d.translations, dev)
+    bgs, ows, pw = T(d.backgrounds, dev), T(d.weights, dev), T(d.point_weights, dev)
+    out_local, (lo, hi) = dpr_amd.raster_sharded(d.grid, pts, Rs, ts, bgs, ows, pw)
+    assert (lo, hi) == (0, 3)
+    ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                        d.point_weights, dtype=npdt)
+    assert_close(out_local, ref, tol(npdt, "out"), "raster_sharded out")
+    g = grid_to_dev(d.ds_dout, dev)
+    fused = torch.full((d.n_points * 4,), float("nan"), dtype=torch.float32, device=dev)
+    res = dpr_amd.raster_pullback_sharded_(g, pts, Rs, ts, bgs, ows, pw, fused_buffer=fused)
+    rpb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                 d.point_weights, dtype=npdt)
+    torch.cuda.synchronize()
+    assert res.points.data_ptr() == fused.data_ptr()
+    _compare(ref, rpb, out_local, res, npdt)
+    # point sharding (single-pose style problems): grid all-reduce forward, scalars backward
+    out2 = dpr_amd.raster_point_sharded(d.grid, pts, Rs, ts, bgs, ows, pw)
+    assert_close(out2, ref, tol(npdt, "out"), "raster_point_sharded out")
+    res2 = dpr_amd.raster_pullback_point_sharded_(g, pts, Rs, ts, bgs, ows, pw)
+    _compare(ref, rpb, out2, res2, npdt)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one rank per GPU)")
+def test_bench_two_ranks_over_rccl(tmp_path):
+    """bench.py --gpus 2 from a bare shell: its own launcher, one rank per GPU, RCCL exchange."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--poses", "8",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
