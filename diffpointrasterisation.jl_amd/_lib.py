@@ -27,6 +27,13 @@ ALGO_TILED = 2
 ALGO_CHUNKED = 3
 FLAG_KEEP_BINNING = 1
 FLAG_REUSE_BINNING = 2
+
+
+def flag_max_pose_group(n: int) -> int:
+    """DPR_FLAG_MAX_POSE_GROUP(n) of include/dpr.h (0 = library default)."""
+    if not 0 <= int(n) <= 16:
+        raise ValueError("max_pose_group must be in 0..16")
+    return (int(n) & 0xFF) << 8
 ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED, "chunked": ALGO_CHUNKED}
 
 EXPORTS = [
@@ -34,6 +41,7 @@ EXPORTS = [
     "dpr_resolve_algo", "dpr_sort_points_workspace_bytes", "dpr_sort_points_f32",
     "dpr_sort_points_f64",
     "dpr_workspace_bytes_f32", "dpr_workspace_bytes_f64",
+    "dpr_workspace_bytes_ex_f32", "dpr_workspace_bytes_ex_f64",
     "dpr_raster_f32", "dpr_raster_f64", "dpr_raster_ex_f32", "dpr_raster_ex_f64",
     "dpr_raster_pullback_f32", "dpr_raster_pullback_f64",
     "dpr_raster_pullback_ex_f32", "dpr_raster_pullback_ex_f64",
@@ -95,6 +103,9 @@ def lib() -> ctypes.CDLL:
         f = getattr(L, f"dpr_workspace_bytes_{suf}")
         f.restype = sz
         f.argtypes = [i, i, i, i, vp, i64, i64]
+        f = getattr(L, f"dpr_workspace_bytes_ex_{suf}")
+        f.restype = sz
+        f.argtypes = [i, i, ctypes.c_uint, i, i, vp, i64, i64]
         # stream, n_in, n_out, grid, P, B, out, points, rot, trans, bg, ow, pw, ws, ws_bytes
         f = getattr(L, f"dpr_raster_{suf}")
         f.restype = i

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <initializer_list>
 #include <string>
 
 #include "../../include/dpr.h"
@@ -112,10 +113,12 @@ static int raster_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64_t
 // The kernels move records as 16/32-byte vectors and scalars as T: a misaligned pointer
 // would fault on the device, so it is refused here.
 template <typename T>
-static int check_alignment(const void* ws, const void* a, const void* b) {
+static int check_alignment(const void* ws, std::initializer_list<const void*> data) {
     if (ws && ((uintptr_t)ws & 255))
         return fail(DPR_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-    if (((uintptr_t)a | (uintptr_t)b) & (sizeof(T) - 1))
+    uintptr_t bits = 0;
+    for (const void* p : data) bits |= (uintptr_t)p;  // NULL (optional argument) adds nothing
+    if (bits & (sizeof(T) - 1))
         return fail(DPR_ERR_INVALID_ARG, "a data pointer is not aligned to its element type");
     return DPR_OK;
 }
@@ -132,13 +135,13 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
     if (P > 0 && !points) return fail(DPR_ERR_INVALID_ARG, "points is NULL with P > 0");
     if ((P + kBlock - 1) / kBlock > 0x7fffffffLL)
         return fail(DPR_ERR_INVALID_ARG, "P too large");
-    if (int rc = check_alignment<T>(ws, out, points)) return rc;
+    if (int rc = check_alignment<T>(ws, {out, points, rot, trans, bg, ow, pw})) return rc;
     hipStream_t st = (hipStream_t)stream;
     algo = resolve_algo(algo, DPR_OP_RASTER, n_out, grid, P, B, G);
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                       \
     if (n_in == NI && n_out == NO) {                                                           \
-        if (algo == DPR_ALGO_ATOMIC && flags == 0)                                             \
+        if (algo == DPR_ALGO_ATOMIC && !(flags & 3u))                                           \
             return raster_atomic<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow, \
                                             pw);                                               \
         if (algo == DPR_ALGO_TILED)                                                            \
@@ -230,13 +233,14 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     if (!rot || !trans) return fail(DPR_ERR_INVALID_ARG, "rotation/translation is NULL");
     if (!d_rot || !d_trans || !d_bg || !d_ow)
         return fail(DPR_ERR_INVALID_ARG, "a per-pose output pointer is NULL");
-    if (int rc = check_alignment<T>(ws, g, points)) return rc;
-    if (int rc = check_alignment<T>(nullptr, d_pts, rs.target)) return rc;
+    if (int rc = check_alignment<T>(ws, {g, points, rot, trans, ow, pw, d_pts, d_rot, d_trans, d_bg,
+                                         d_ow, d_pw, rs.target, rs.loss}))
+        return rc;
     algo = resolve_algo(algo, DPR_OP_PULLBACK, n_out, grid, P, B, G);
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                         \
     if (n_in == NI && n_out == NO) {                                                             \
-        if (algo == DPR_ALGO_ATOMIC && flags == 0)                                               \
+        if (algo == DPR_ALGO_ATOMIC && !(flags & 3u))                                             \
             return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw,   \
                                               d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, rs);      \
         if (algo == DPR_ALGO_TILED)                                                              \
@@ -259,8 +263,8 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
 }
 
 template <typename T>
-static size_t workspace_impl(int op, int algo, int n_in, int n_out, const int64_t* grid, int64_t P,
-                             int64_t B) {
+static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_out,
+                             const int64_t* grid, int64_t P, int64_t B) {
     int64_t G = 0;
     if (check_common(n_in, n_out, grid, P, B, &G)) return (size_t)-1;
     if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK) {
@@ -269,7 +273,13 @@ static size_t workspace_impl(int op, int algo, int n_in, int n_out, const int64_
     }
     algo = resolve_algo(algo, op, n_out, grid, P, B, G);
     if (algo == DPR_ALGO_ATOMIC) return 0;
-    if (algo == DPR_ALGO_TILED) return tiled_workspace_bytes(sizeof(T), op, n_in, n_out, grid, P, B);
+    if (algo == DPR_ALGO_TILED) {
+        const size_t n = tiled_workspace_bytes(sizeof(T), op, flags, n_in, n_out, grid, P, B);
+        if (n == (size_t)-1)
+            fail(DPR_ERR_UNSUPPORTED_ALGO,
+                 "DPR_ALGO_TILED: grid needs too many tiles or P >= 2^32 (the call would be refused)");
+        return n;
+    }
     if (algo == DPR_ALGO_CHUNKED) return chunked_workspace_bytes(n_out, grid, P, B);
     fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
     return (size_t)-1;
@@ -308,11 +318,19 @@ int dpr_stage_timing_end(void) {
 
 size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t* grid,
                                int64_t P, int64_t B) {
-    return dpr::workspace_impl<float>(op, algo, n_in, n_out, grid, P, B);
+    return dpr::workspace_impl<float>(op, algo, 0u, n_in, n_out, grid, P, B);
 }
 size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t* grid,
                                int64_t P, int64_t B) {
-    return dpr::workspace_impl<double>(op, algo, n_in, n_out, grid, P, B);
+    return dpr::workspace_impl<double>(op, algo, 0u, n_in, n_out, grid, P, B);
+}
+size_t dpr_workspace_bytes_ex_f32(int op, int algo, unsigned flags, int n_in, int n_out,
+                                  const int64_t* grid, int64_t P, int64_t B) {
+    return dpr::workspace_impl<float>(op, algo, flags, n_in, n_out, grid, P, B);
+}
+size_t dpr_workspace_bytes_ex_f64(int op, int algo, unsigned flags, int n_in, int n_out,
+                                  const int64_t* grid, int64_t P, int64_t B) {
+    return dpr::workspace_impl<double>(op, algo, flags, n_in, n_out, grid, P, B);
 }
 
 #define DPR_DEFINE(SUF, T)                                                                        \

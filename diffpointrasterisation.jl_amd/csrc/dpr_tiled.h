@@ -15,8 +15,8 @@ void stage_mark(hipStream_t st);
 
 bool tiled_supported(int n_out, const int64_t* grid);
 bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G);
-size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
-                             int64_t P, int64_t B);
+size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int n_out,
+                             const int64_t* grid, int64_t P, int64_t B);
 
 template <typename T, int NI, int NO>
 int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B, T* out,

@@ -35,7 +35,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/dpr.h"
 #include "dpr_device.h"
@@ -301,6 +305,53 @@ __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts,
     }
 }
 
+// What a DPR_FLAG_KEEP_BINNING forward leaves at the start of the workspace, and what a
+// DPR_FLAG_REUSE_BINNING pullback checks ON THE DEVICE before it trusts the work list, the
+// records and the slot map: problem shape, element size, the identity of the point / weight
+// buffers and the pose VALUES (bit patterns).  state: kBinValid after a KEEP forward, 0 after
+// any other binning and after the pullback that consumed it (its gradient records overwrite
+// the point records in place, so a second reuse must not pass).  A pullback that finds no
+// matching header launches nothing that touches memory through the stale lists and returns
+// NaN in every output (loud, not silent).
+constexpr uint32_t kBinMagic = 0x44505242u, kBinValid = 1u;
+struct alignas(16) BinHeader {
+    uint32_t magic, state;
+    uint32_t elem, n_in, n_out, has_pw;
+    int64_t P;
+    int32_t grid[3];
+    uint32_t verdict;  // written by the consuming pullback's first kernel: 1 = header matched
+    uint64_t points, pw;
+    unsigned char pose[96];  // rotation | translation bytes of pose 0 (<= 9 + 3 doubles)
+};
+template <typename T, int NI, int NO>
+static BinHeader make_header(const int64_t* grid, int64_t P, const T* points, const T* pw) {
+    BinHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = kBinMagic;
+    h.elem = (uint32_t)sizeof(T);
+    h.n_in = NI;
+    h.n_out = NO;
+    h.has_pw = pw ? 1u : 0u;
+    h.P = P;
+    for (int d = 0; d < NO; ++d) h.grid[d] = (int32_t)grid[d];
+    h.points = (uint64_t)(uintptr_t)points;
+    h.pw = (uint64_t)(uintptr_t)pw;
+    return h;
+}
+// device side: does the workspace header match `want` and the pose in memory?
+__device__ __forceinline__ bool header_matches(const BinHeader* hdr, const BinHeader& want,
+                                               const uint32_t* rot, int rot_words,
+                                               const uint32_t* trans, int trans_words) {
+    bool ok = hdr->magic == kBinMagic && hdr->state == kBinValid && hdr->elem == want.elem &&
+              hdr->n_in == want.n_in && hdr->n_out == want.n_out && hdr->has_pw == want.has_pw &&
+              hdr->P == want.P && hdr->grid[0] == want.grid[0] && hdr->grid[1] == want.grid[1] &&
+              hdr->grid[2] == want.grid[2] && hdr->points == want.points && hdr->pw == want.pw;
+    const uint32_t* pose = (const uint32_t*)hdr->pose;
+    for (int i = 0; i < rot_words; ++i) ok = ok && pose[i] == rot[i];
+    for (int i = 0; i < trans_words; ++i) ok = ok && pose[rot_words + i] == trans[i];
+    return ok;
+}
+
 // One unit of work of the tile kernels: a contiguous record range of one tile.  Tiles with
 // more than `cap` records are split into several items (parts) so that a clustered cloud
 // (few heavily loaded tiles) still fills the chip; the parts of a split tile leave their LDS
@@ -320,7 +371,18 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ tile_parts,
                                                    uint32_t* __restrict__ tile_slab,
                                                    uint32_t* __restrict__ split_list,
-                                                   uint32_t* __restrict__ n_split) {
+                                                   uint32_t* __restrict__ n_split, BinHeader hdr,
+                                                   BinHeader* __restrict__ hdr_out,
+                                                   const unsigned char* __restrict__ rot,
+                                                   int rot_bytes,
+                                                   const unsigned char* __restrict__ trans,
+                                                   int trans_bytes) {
+    // header of this binning (state = kBinValid only for a KEEP_BINNING forward)
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < rot_bytes; ++i) hdr.pose[i] = rot[i];
+        for (int i = 0; i < trans_bytes; ++i) hdr.pose[rot_bytes + i] = trans[i];
+        *hdr_out = hdr;
+    }
     __shared__ uint32_t wsum[16], wslab[16];
     __shared__ uint32_t s_nsplit;
     if (threadIdx.x == 0) s_nsplit = 0;
@@ -986,14 +1048,26 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b0,
     T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials,
-    Residual<T> rs) {
+    Residual<T> rs, BinHeader want, BinHeader* hdr) {
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NVAL = NO * NI + NO + 3;  // dR | dt | d out_weight | d background | loss
     constexpr int NW = kGatherThreads / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
-    const WorkItem item = items[blockIdx.x];  // fetched together with the item count
+    if (want.magic) {
+        // DPR_FLAG_REUSE_BINNING: trust the lists in the workspace only if a KEEP_BINNING forward
+        // with the same problem, buffers and pose wrote them and nobody has consumed them since
+        const bool ok = header_matches(hdr, want, (const uint32_t*)(rot + b0 * (NO * NI)),
+                                       NO * NI * (int)(sizeof(T) / 4),
+                                       (const uint32_t*)(trans + b0 * NO), NO * (int)(sizeof(T) / 4));
+        if (blockIdx.x == 0 && threadIdx.x == 0) hdr->verdict = ok ? 1u : 0u;
+        if (!ok) return;  // k_unpermute / k_pose_reduce turn the verdict into NaN outputs
+    }
+    WorkItem item = items[blockIdx.x];  // fetched together with the item count
     if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
+    // record ranges never leave the record buffer, whatever the lists say
+    if (item.end > (uint32_t)P) item.end = (uint32_t)P;
+    if (item.begin > item.end) item.begin = item.end;
     const int tile = (int)(item.tile % (uint32_t)tg.NT);
     const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
     int x0[NO], tc[NO];
@@ -1218,7 +1292,22 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
                                                     const Rec4<T>* __restrict__ grad,
                                                     const uint32_t* __restrict__ slot_of,
                                                     T* __restrict__ ds_dpoints,
-                                                    T* __restrict__ ds_dpw) {
+                                                    T* __restrict__ ds_dpw,
+                                                    const BinHeader* __restrict__ hdr) {
+    if (hdr && hdr->verdict != 1u) {
+        // REUSE_BINNING without a matching KEEP_BINNING forward: no gradient was computed
+        const T nan = T(__builtin_nanf(""));
+        const int64_t b0 = (int64_t)blockIdx.x * (kUPB * 1024) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < kUPB; ++k) {
+            const int64_t p = b0 + k * 1024;
+            if (p >= P) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = nan;
+            ds_dpw[p] = nan;
+        }
+        return;
+    }
     // One block covers kUPB * 1024 consecutive points = one sub-chunk of the scatter: points of
     // a sub-chunk that fell into the same tile sit next to each other in that tile's record
     // run, so the 64-byte sectors this block fetches are shared among its own threads.
@@ -1269,13 +1358,16 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
                                                       T* __restrict__ ds_dtranslation,
                                                       T* __restrict__ ds_dbackground,
                                                       T* __restrict__ ds_dout_weight,
-                                                      T* __restrict__ loss) {
+                                                      T* __restrict__ loss, BinHeader* hdr) {
     __shared__ double wsum[16];
     const int k = blockIdx.x;
     const uint32_t j = blockIdx.y;
     const int64_t b = b0 + j;
     double s = 0.0;
-    const int n = (int)*n_items;
+    const bool stale = hdr && hdr->verdict != 1u;  // see k_tile_gather
+    // the binning is consumed: the gradient records have overwritten the point records
+    if (hdr && k == 0 && j == 0 && threadIdx.x == 0) hdr->state = 0u;
+    const int n = stale ? 0 : (int)*n_items;
     if (gridDim.y == 1) {
         for (int t = threadIdx.x; t < n; t += 1024) s += partials[(size_t)k * max_items + t];
     } else {
@@ -1289,6 +1381,7 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (stale) tot = __builtin_nan("");
         if (k < NO * NI)
             ds_drotation[b * (NO * NI) + k] = (T)tot;
         else if (k < NO * NI + NO)
@@ -1305,10 +1398,29 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
 // ------------------------------------------------------------------ host side
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// experiment knobs (environment overrides of compiled-in defaults)
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
+// Experiment knobs: environment overrides of the compiled-in defaults, read ONCE per process
+// (function-local static: thread-safe, no getenv on the call path) and clamped to valid ranges.
+struct Knobs {
+    int cap3d_div, cap2d_div, pose_group, scatter_wc, bwd_unpermute, compact_records, splat_blocked;
+};
+static const Knobs& knobs() {
+    static const Knobs k = [] {
+        auto env_int = [](const char* name, int dflt, int lo, int hi) {
+            const char* v = getenv(name);
+            int x = v ? atoi(v) : dflt;
+            return x < lo ? lo : (x > hi ? hi : x);
+        };
+        Knobs q;
+        q.cap3d_div = env_int("DPR_CAP3D_DIV", 256, 1, 1 << 20);
+        q.cap2d_div = env_int("DPR_CAP2D_DIV", 2048, 0, 1 << 20);  // 0: use the 3-D rule
+        q.pose_group = env_int("DPR_POSE_GROUP", 16, 1, 16);
+        q.scatter_wc = env_int("DPR_SCATTER_WC", 1, 0, 1);
+        q.bwd_unpermute = env_int("DPR_BWD_UNPERMUTE", 1, 0, 1);
+        q.compact_records = env_int("DPR_COMPACT_RECORDS", 1, 0, 1);
+        q.splat_blocked = env_int("DPR_SPLAT_BLOCKED", 1, 0, 1);
+        return q;
+    }();
+    return k;
 }
 
 // Workspace layout (identical for raster and pullback so that a pullback can reuse the
@@ -1321,7 +1433,7 @@ struct Plan {
     uint32_t cap;    // records per work item above which a tile is split
     int max_items;   // NT + worst-case number of extra parts
     int max_slabs;   // overflow slabs (parts of split tiles)
-    size_t off_counts, off_totals, off_tile_start, off_items, off_nitems, off_tparts, off_tslab,
+    size_t off_hdr, off_counts, off_totals, off_tile_start, off_items, off_nitems, off_tparts, off_tslab,
         off_split, off_rec, off_idx, off_slot, off_aux, total;
 };
 
@@ -1331,9 +1443,13 @@ struct Plan {
 // the fixed per-launch costs (scans, halo pass, reductions, launch gaps) are shared.  Measured
 // (tools/pose_group_probe.py): 10 M points -> 512^2, 485 -> 383 us per pose (fwd + bwd);
 // 1 M points -> 128^3, 149 -> 65 us per pose.
+// Memory: records and slot map are sized P * g (20 / 36 bytes per point-pose), so a group of g
+// poses multiplies that part of the workspace by g -- bounded by P * g <= 2^27 (2.7 GB fp32,
+// 4.8 GB fp64) and by the caller through DPR_FLAG_MAX_POSE_GROUP(n) (include/dpr.h).
 constexpr int kMaxGroup = 16;
-static int pose_group(int NT, int64_t P, int64_t B) {
-    const int limit = env_int("DPR_POSE_GROUP", kMaxGroup);
+static int pose_group(int NT, int64_t P, int64_t B, int max_group) {
+    int limit = knobs().pose_group;
+    if (max_group > 0 && max_group < limit) limit = max_group;
     int bg = 1;
     while (bg * 2 <= limit && bg * 2 <= kMaxGroup && bg * 2 <= B && NT * bg * 2 <= 4096 &&
            P * bg * 2 <= ((int64_t)1 << 27))  // records of a group: <= 2 GiB (fp32)
@@ -1341,9 +1457,9 @@ static int pose_group(int NT, int64_t P, int64_t B) {
     return bg;
 }
 
-static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B) {
+static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group) {
     Plan pl;
-    pl.bg = pose_group(NT1, P1, B);
+    pl.bg = pose_group(NT1, P1, B, max_group);
     const int NT = NT1 * pl.bg;          // bins
     const int64_t P = P1 * pl.bg;        // records
     int64_t nblk = (P1 + 8191) / 8192;
@@ -1357,6 +1473,8 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B) {
     pl.nblk = (int)nblk;
     pl.chunk = chunk;
     size_t o = 0;
+    pl.off_hdr = o;  // BinHeader: what a KEEP_BINNING forward left, checked by a REUSE pullback
+    o += align_up(sizeof(BinHeader));
     pl.off_counts = o;
     o += align_up((size_t)nblk * NT * 4);
     pl.off_totals = o;
@@ -1366,12 +1484,12 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B) {
     // split threshold: ~P/256 records (even a fully clustered cloud then yields >= 256 items,
     // one per CU, while the headline Gaussian cloud has no tile above it), at least 4096; a
     // split tile's parts hold more than cap/2 records each
-    int64_t cap = P / env_int("DPR_CAP3D_DIV", 256);
+    int64_t cap = P / knobs().cap3d_div;
     if (cap < 4096) cap = 4096;
     if (n_out == 2) {
         // 2-D grids have few tiles (256 at 512^2) with cheap LDS tiles (8.7 KB): split
         // earlier so that a dense projection still gives the chip ~2048 items
-        cap = env_int("DPR_CAP2D_DIV", 2048) > 0 ? P / env_int("DPR_CAP2D_DIV", 2048) : cap;
+        cap = knobs().cap2d_div > 0 ? P / knobs().cap2d_div : cap;
         if (cap < 2048) cap = 2048;
     }
     pl.cap = (uint32_t)cap;
@@ -1432,16 +1550,17 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
     // poses on a grid that forms pose groups: the fixed cost is shared, the forward pays from
     // ~6e4 points; the direct pullback kernel, which keeps a point in registers across the poses
     // of a slice, stays ahead up to ~3e5 points (~6e5 when the grid is too large for groups).
-    const bool grouped = B >= 4 && pose_group(NT, P, B) >= 4;
+    const bool grouped = B >= 4 && pose_group(NT, P, B, 0) >= 4;
     if (op == DPR_OP_RASTER) return P >= (grouped ? 60000 : 250000);
     if (B >= 4) return P >= (grouped ? 300000 : 600000);
     return P >= 250000;
 }
 
-size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int64_t* grid,
-                             int64_t P, int64_t B) {
+size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int n_out,
+                             const int64_t* grid, int64_t P, int64_t B) {
     (void)op;
     (void)n_in;
+    if (P >= (int64_t)1 << 32) return (size_t)-1;  // refused by raster_tiled / pullback_tiled
     int NT;
     if (n_out == 3) {
         TileGeom<3> tg;
@@ -1452,7 +1571,7 @@ size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int
         if (!make_geom<2>(grid, &tg)) return (size_t)-1;
         NT = tg.NT;
     }
-    return make_plan(elem, n_out, NT, P, B).total;
+    return make_plan(elem, n_out, NT, P, B, (int)((flags >> 8) & 0xffu)).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -1462,25 +1581,34 @@ size_t tiled_workspace_bytes(size_t elem, int op, int n_in, int n_out, const int
             return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Dynamic LDS above 48 KiB has to be allowed per kernel (and per device): done once for the
+// maximum the kernel can ask for (128 KiB of cursors at kMaxTiles), not per call.
 template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        DPR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bytes));
+    if (bytes <= 48 * 1024) return DPR_OK;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;  // (kernel, device) already raised
+    int dev = 0;
+    DPR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({(const void*)kernel, dev})) return DPR_OK;
+    DPR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kMaxTiles * 4));
+    done.insert({(const void*)kernel, dev});
     return DPR_OK;
 }
 
 // Which scatter a binning uses: the write-combining one whenever its LDS tables fit and the
 // original indices are not needed as a separate array.
 static bool scatter_is_wc(int NT, int nb, bool has_pw, bool want_idx) {
-    const int wc = env_int("DPR_SCATTER_WC", 1) || nb > 1;
-    const bool needs_idx = has_pw && want_idx && env_int("DPR_BWD_UNPERMUTE", 1) == 0 && nb == 1;
+    const int wc = knobs().scatter_wc || nb > 1;
+    const bool needs_idx = has_pw && want_idx && knobs().bwd_unpermute == 0 && nb == 1;
     return wc && NT * nb <= 4096 && !needs_idx;
 }
 
 // Compact 3-word records: default point weights, write-combining scatter, forward-only binning
 // (nothing downstream needs the original index or room for a gradient record).
 static bool records_are_compact(int NT, int nb, bool has_pw, bool want_idx) {
-    if (has_pw || want_idx || !env_int("DPR_COMPACT_RECORDS", 1)) return false;
+    if (has_pw || want_idx || !knobs().compact_records) return false;
     return scatter_is_wc(NT, nb, has_pw, want_idx);
 }
 
@@ -1530,7 +1658,7 @@ template <typename T, int NI, int NO>
 static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                       const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
                       const T* rot, const T* trans, int64_t b, int nb, bool want_idx, T* d_pts,
-                      T* d_pw, int zero_dropped) {
+                      T* d_pw, int zero_dropped, bool keep_valid = false) {
     uint32_t* counts = (uint32_t*)(ws + pl.off_counts);
     uint32_t* totals = (uint32_t*)(ws + pl.off_totals);
     uint32_t* tile_start = (uint32_t*)(ws + pl.off_tile_start);
@@ -1548,10 +1676,17 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     stage_mark(st);
     hipLaunchKernelGGL(k_colscan, dim3((NTe + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st,
                        counts, pl.nblk, NTe, totals);
+    int64_t grid64[3] = {1, 1, 1};
+    for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
+    BinHeader hdr = make_header<T, NI, NO>(grid64, P, points, pw);
+    hdr.state = keep_valid ? kBinValid : 0u;  // only a KEEP_BINNING forward may be reused
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, NTe, pl.cap, tile_start,
                        (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
                        (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
-                       (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split));
+                       (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split), hdr,
+                       (BinHeader*)(ws + pl.off_hdr),
+                       (const unsigned char*)(rot + b * (NO * NI)), (int)(NO * NI * sizeof(T)),
+                       (const unsigned char*)(trans + b * NO), (int)(NO * sizeof(T)));
     stage_mark(st);
     int rc;
     if (pw) {
@@ -1596,7 +1731,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     if (keep && B != 1)
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
                     (long long)B);
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B);
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu));
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
@@ -1605,11 +1740,11 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     T* halo = (T*)(ws + pl.off_aux);
     T* ovf = (T*)(ws + pl.off_aux +
                   align_up((size_t)tg.NT * pl.bg * halo_count<NO>() * sizeof(T)));
-    const int blocked = env_int("DPR_SPLAT_BLOCKED", 1);
+    const int blocked = knobs().splat_blocked;
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
         if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
-                                           (int)nb, keep, (T*)nullptr, (T*)nullptr, 0))
+                                           (int)nb, keep, (T*)nullptr, (T*)nullptr, 0, keep))
             return rc;
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
@@ -1652,7 +1787,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     if (reuse && B != 1)
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
                     (long long)B);
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B);
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu));
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -1661,7 +1796,10 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     double* partials = (double*)(ws + pl.off_aux);
     constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
-    const bool unperm1 = env_int("DPR_BWD_UNPERMUTE", 1) != 0;
+    const bool unperm1 = knobs().bwd_unpermute != 0;
+    BinHeader want = make_header<T, NI, NO>(grid, P, points, pw);
+    if (!reuse) want.magic = 0;  // own binning: nothing to validate
+    BinHeader* hdr = reuse ? (BinHeader*)(ws + pl.off_hdr) : (BinHeader*)nullptr;
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
         // a pose group always goes through the gradient records (several (pose, tile) blocks
@@ -1687,7 +1825,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                        dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P * nb, \
                        (const uint32_t*)(ws + pl.off_idx), (const WorkItem*)(ws + pl.off_items), \
                        (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,  \
-                       b, d_pts, d_pw, partials, rs)
+                       b, d_pts, d_pw, partials, rs, want, hdr)
         if (unperm) {
             if (pw) DPR_LAUNCH_GATHER(true, true, true);
             else DPR_LAUNCH_GATHER(false, true, true);
@@ -1699,7 +1837,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     hipLaunchKernelGGL((k_unpermute<T, NI, FIRST, UPB>),                                         \
                        dim3((unsigned)((P + UPB * 1024 - 1) / (UPB * 1024))), dim3(1024), 0, st, \
                        P, (int)nb, (const Rec4<T>*)(ws + pl.off_rec),                            \
-                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw)
+                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw, (const BinHeader*)hdr)
                 if (nb > 1) {
                     if (b == 0) DPR_LAUNCH_UNPERM(true, 1);
                     else DPR_LAUNCH_UNPERM(false, 1);
@@ -1725,7 +1863,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                            dim3(rs.target ? NVAL + 1 : NVAL, (unsigned)nb), dim3(1024), 0, st,
                            (const double*)partials, (const WorkItem*)(ws + pl.off_items),
                            (const uint32_t*)(ws + pl.off_nitems), pl.max_items, tg.NT, b, d_rot,
-                           d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr);
+                           d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr, hdr);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());

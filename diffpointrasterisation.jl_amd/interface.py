@@ -117,9 +117,9 @@ def _stream_ptr(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _workspace(op, algo, suf, n_in, n_out, grid_arr, P, B, device, workspace):
-    need = getattr(_lib.lib(), f"dpr_workspace_bytes_{suf}")(
-        op, algo, n_in, n_out, grid_arr.ctypes.data_as(ctypes.c_void_p), P, B)
+def _workspace(op, algo, suf, n_in, n_out, grid_arr, P, B, device, workspace, flags=0):
+    need = getattr(_lib.lib(), f"dpr_workspace_bytes_ex_{suf}")(
+        op, algo, flags, n_in, n_out, grid_arr.ctypes.data_as(ctypes.c_void_p), P, B)
     if need == ctypes.c_size_t(-1).value:
         raise _lib.DprError(_lib.ERR_INVALID_ARG, _lib.last_error())
     if need == 0:
@@ -133,14 +133,17 @@ def _workspace(op, algo, suf, n_in, n_out, grid_arr, P, B, device, workspace):
 
 
 def workspace_bytes(op: str, grid_size, n_points: int, batch: int, n_in: int, dtype=torch.float32,
-                    algo: str = "auto") -> int:
+                    algo: str = "auto", max_pose_group: int = 0) -> int:
+    """dpr_workspace_bytes_ex_*: device bytes `op` needs.  `max_pose_group` (1..16, 0 = default)
+    bounds how many poses of a batch the tiled path bins together -- the speed / memory trade of
+    DPR_FLAG_MAX_POSE_GROUP (include/dpr.h)."""
     import numpy as np
 
     grid_arr = np.asarray(grid_size, dtype=np.int64)
     opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
-    need = getattr(_lib.lib(), f"dpr_workspace_bytes_{_SUFFIX[dtype]}")(
-        opc, _lib.ALGOS[algo], n_in, len(grid_size), grid_arr.ctypes.data_as(ctypes.c_void_p),
-        n_points, batch)
+    need = getattr(_lib.lib(), f"dpr_workspace_bytes_ex_{_SUFFIX[dtype]}")(
+        opc, _lib.ALGOS[algo], _lib.flag_max_pose_group(max_pose_group), n_in, len(grid_size),
+        grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
     if need == ctypes.c_size_t(-1).value:
         raise _lib.DprError(_lib.ERR_INVALID_ARG, _lib.last_error())
     return int(need)
@@ -215,7 +218,8 @@ def _canonicalise(points, rotation, translation, background, out_weight, point_w
 
 # --------------------------------------------------------------------------- forward
 def raster(grid_size, points, rotation, translation, background=None, out_weight=None,
-           point_weight=None, *, algo: str = "auto", workspace=None) -> torch.Tensor:
+           point_weight=None, *, algo: str = "auto", workspace=None,
+           max_pose_group: int = 0) -> torch.Tensor:
     """Allocating forward (src/interface.jl:62-77).  Returns `out[i_1..i_N]` for a single
     pose (rotation is a matrix) or `out[i_1..i_N, b]` for a batch."""
     device = _device_of(points)
@@ -225,12 +229,12 @@ def raster(grid_size, points, rotation, translation, background=None, out_weight
                                       else len(rotation))
     out = empty_grid(tuple(grid_size), batch, dtype, device)
     return raster_(out, points, rotation, translation, background, out_weight, point_weight,
-                   algo=algo, workspace=workspace)
+                   algo=algo, workspace=workspace, max_pose_group=max_pose_group)
 
 
 def raster_(out, points, rotation, translation, background=None, out_weight=None,
             point_weight=None, *, algo: str = "auto", workspace=None,
-            keep_binning: bool = False) -> torch.Tensor:
+            keep_binning: bool = False, max_pose_group: int = 0) -> torch.Tensor:
     """In-place forward, the reference's `raster!`.  `out` is fully overwritten and
     returned (same object).  Enqueued on torch's current stream; not synchronised.
     `keep_binning=True` (tiled algorithm, one pose, explicit `workspace`) leaves the binning
@@ -255,10 +259,11 @@ def raster_(out, points, rotation, translation, background=None, out_weight=None
     suf = _SUFFIX[c["dtype"]]
     algo_c = _lib.ALGOS[algo]
     with torch.cuda.device(c["device"]):
+        flags = _lib.flag_max_pose_group(max_pose_group)
         ws, ws_bytes = _workspace(_lib.OP_RASTER, algo_c, suf, c["n_in"], c["n_out"], grid_arr,
-                                  c["P"], c["B"], c["device"], workspace)
+                                  c["P"], c["B"], c["device"], workspace, flags)
         fn = getattr(_lib.lib(), f"dpr_raster_ex_{suf}")
-        flags = _lib.FLAG_KEEP_BINNING if keep_binning else 0
+        flags |= _lib.FLAG_KEEP_BINNING if keep_binning else 0
         if keep_binning and workspace is None:
             raise ValueError("keep_binning needs a caller-owned workspace")
         _lib.check(fn(_stream_ptr(c["device"]), algo_c, flags, c["n_in"], c["n_out"],
@@ -273,7 +278,7 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
                      point_weight=None, *, ds_dpoints=None, ds_drotation=None,
                      ds_dtranslation=None, ds_dbackground=None, ds_dout_weight=None,
                      ds_dpoint_weight=None, algo: str = "auto", workspace=None,
-                     reuse_binning: bool = False) -> PullbackResult:
+                     reuse_binning: bool = False, max_pose_group: int = 0) -> PullbackResult:
     """The reference's `raster_pullback!` (src/interface.jl:196-308).  Optional keyword
     arguments are pre-allocated outputs (the reference's `points=`, `rotation=`, ... kwargs,
     src/interface.jl:278-291); they are OVERWRITTEN and returned by identity.  Unlike the
@@ -285,7 +290,8 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
     out_weight (B,); point_weight (P,)."""
     return _pullback(ds_dout, None, points, rotation, translation, background, out_weight,
                      point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
-                     ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning)
+                     ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning,
+                     max_pose_group)
 
 
 def raster_residual_pullback_(out, target, points, rotation, translation, background=None,
@@ -312,7 +318,8 @@ def raster_residual_pullback_(out, target, points, rotation, translation, backgr
 
 def _pullback(ds_dout, residual, points, rotation, translation, background, out_weight,
               point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
-              ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning):
+              ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning,
+              max_pose_group=0):
     import numpy as np
 
     c = _canonicalise(points, rotation, translation, background, out_weight, point_weight,
@@ -376,9 +383,10 @@ def _pullback(ds_dout, residual, points, rotation, translation, background, out_
     suf = _SUFFIX[dtype]
     algo_c = _lib.ALGOS[algo]
     with torch.cuda.device(dev):
+        flags = _lib.flag_max_pose_group(max_pose_group)
         ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
-                                  workspace)
-        flags = _lib.FLAG_REUSE_BINNING if reuse_binning else 0
+                                  workspace, flags)
+        flags |= _lib.FLAG_REUSE_BINNING if reuse_binning else 0
         if reuse_binning and workspace is None:
             raise ValueError("reuse_binning needs the workspace of the preceding raster_ call")
         head = (_stream_ptr(dev), algo_c, flags, n_in, n_out,

@@ -87,6 +87,19 @@ extern "C" {
  * (src/raster_pullback.jl:20-22). */
 #define DPR_FLAG_KEEP_BINNING 1u
 #define DPR_FLAG_REUSE_BINNING 2u
+/* A REUSE_BINNING pullback validates ON THE DEVICE that the workspace holds the binning of a
+ * KEEP_BINNING forward with the same P, grid, element type, points / point_weight buffers and
+ * pose values, and that no pullback has consumed it yet (the gradient records overwrite the
+ * point records).  If not, nothing is read through the stale lists and all six outputs (and
+ * `loss`) come back as NaN; the status is still 0 because the host cannot see the mismatch
+ * without synchronising.
+ *
+ * DPR_FLAG_MAX_POSE_GROUP(n), n in 1..16 (0 = library default 16): DPR_ALGO_TILED bins up to n
+ * poses of a batch together when the grid has few tiles (n * tiles <= 4096).  Larger groups are
+ * faster (the points are read once per group) but the record / slot-map part of the workspace
+ * grows n-fold: (20 | 36) bytes * P * n for fp32 | fp64 -- e.g. 10 M points, 512^2 grid:
+ * 0.28 GB at n = 1, 1.66 GB at n = 8.  Pass the same flags to dpr_workspace_bytes_ex_*. */
+#define DPR_FLAG_MAX_POSE_GROUP(n) (((unsigned)(n) & 0xffu) << 8)
 
 int dpr_version(void);
 
@@ -113,11 +126,18 @@ int dpr_stage_timing_end(void);
 /* Bytes of caller-provided device workspace needed by `op` with `algo`
  * (may be 0).  Returns (size_t)-1 on invalid arguments.  The workspace pointer must be
  * 256-byte aligned (DPR_ERR_WORKSPACE otherwise; hipMalloc / AMDGPU.jl / torch allocations
- * are); data pointers must be aligned to their element type. */
+ * are); every non-NULL data pointer must be aligned to its element type
+ * (DPR_ERR_INVALID_ARG otherwise, before any launch).  DPR_ALGO_TILED with a shape it would
+ * refuse (more than 32768 tiles, P >= 2^32) returns (size_t)-1 here too. */
 size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B);
 size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B);
+/* The same for a call that will pass `flags` (only DPR_FLAG_MAX_POSE_GROUP changes the size). */
+size_t dpr_workspace_bytes_ex_f32(int op, int algo, unsigned flags, int n_in, int n_out,
+                                  const int64_t *grid, int64_t P, int64_t B);
+size_t dpr_workspace_bytes_ex_f64(int op, int algo, unsigned flags, int n_in, int n_out,
+                                  const int64_t *grid, int64_t P, int64_t B);
 
 /* Forward: out[.., b] = background[b] + sum_p splat(R[b] p + t[b]) * out_weight[b] * point_weight[p]
  * `out` is fully overwritten (src/raster.jl:27). */

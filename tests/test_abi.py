@@ -145,6 +145,29 @@ def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
     rc = fn(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, ctypes.c_void_p(d.value + 2), d,
             d, d, None, None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_INVALID_ARG and "aligned" in dpr_amd._lib.last_error()
+    # every data pointer is checked, not only out / points
+    rc = fn(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, d, d, ctypes.c_void_p(d.value + 2),
+            d, None, None, None, None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "aligned" in dpr_amd._lib.last_error()
+    rc = fn(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None,
+            ctypes.c_void_p(d.value + 1), None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "aligned" in dpr_amd._lib.last_error()
+    pbx = getattr(L, f"dpr_raster_pullback_ex_{suf}")
+    rc = pbx(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, *([d] * 4), None, None, d,
+             ctypes.c_void_p(d.value + 2), *([d] * 4), None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "aligned" in dpr_amd._lib.last_error()
+    # a workspace query for a call that TILED would refuse fails too
+    wsq = getattr(L, f"dpr_workspace_bytes_{suf}")
+    assert wsq(0, dpr_amd._lib.ALGO_TILED, 3, 3, gp, 1 << 32, 1) == ctypes.c_size_t(-1).value
+    big = np.array([4096, 4096, 64], dtype=np.int64)
+    assert wsq(0, dpr_amd._lib.ALGO_TILED, 3, 3, big.ctypes.data_as(ctypes.c_void_p), 1000, 1) == ctypes.c_size_t(-1).value
+    # pose-group cap: smaller workspace, same call otherwise
+    wsx = getattr(L, f"dpr_workspace_bytes_ex_{suf}")
+    g2 = np.array([512, 512], dtype=np.int64)
+    g2p = g2.ctypes.data_as(ctypes.c_void_p)
+    full = wsx(0, dpr_amd._lib.ALGO_TILED, 0, 3, 2, g2p, 1_000_000, 8)
+    capped = wsx(0, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.flag_max_pose_group(1), 3, 2, g2p, 1_000_000, 8)
+    assert 0 < capped < full / 3 and full == wsq(0, dpr_amd._lib.ALGO_TILED, 3, 2, g2p, 1_000_000, 8)
     # the residual pullback needs a target and has no chunked variant
     rp = getattr(L, f"dpr_raster_residual_pullback_ex_{suf}")
     rc = rp(None, dpr_amd._lib.ALGO_ATOMIC, 0, 3, 3, gp, 1000, 1, d, None, 2.0, d, d, d, None, None,

@@ -280,6 +280,42 @@ def test_pullback_reusing_forward_binning(oracle, dev, algo, npdt, tdt, n_in, n_
         dpr_amd.raster_(out, *args, algo="atomic", workspace=ws, keep_binning=True)
 
 
+def test_reuse_binning_is_validated_on_the_device(oracle, dev):
+    """DPR_FLAG_REUSE_BINNING without a matching DPR_FLAG_KEEP_BINNING forward (stale workspace,
+    other pose, other points, binning already consumed) must not read through stale lists:
+    every output comes back NaN instead of silently wrong; the matching pair is exact."""
+    d = D.make(n_points=300_000, n_in=3, n_out=3, batch=1, grid_n=64, seed=17, dtype=np.float32)
+    pts, R, t = T(d.points, dev), T(d.rotations[0], dev), T(d.translations[0], dev)
+    g = grid_to_dev(d.ds_dout[..., 0], dev)
+    ws = torch.zeros(dpr_amd.workspace_bytes("pullback", d.grid, d.n_points, 1, 3, torch.float32,
+                                             "tiled"), dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, None, torch.float32, dev)
+    isnan = lambda pb: all(bool(torch.isnan(x).all()) for x in pb)
+    # (a) nothing was kept (zeroed workspace)
+    assert isnan(dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws, reuse_binning=True))
+    # (b) a forward WITHOUT keep_binning
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws)
+    assert isnan(dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws, reuse_binning=True))
+    # (c) the matching pair works ...
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws, keep_binning=True)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws, reuse_binning=True)
+    ref = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, dtype=np.float32)
+    assert_close(pb.points, ref.points, 1e-4, "ds_dpoints")
+    assert_close(pb.rotation, ref.rotation[0], 1e-3, "ds_drotation")
+    # ... once: the gradient records have overwritten the binning
+    assert isnan(dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws, reuse_binning=True))
+    # (d) kept for another pose / another point buffer
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws, keep_binning=True)
+    assert isnan(dpr_amd.raster_pullback_(g, pts, R, t + 0.01, algo="tiled", workspace=ws,
+                                          reuse_binning=True))
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws, keep_binning=True)
+    assert isnan(dpr_amd.raster_pullback_(g, pts.clone(), R, t, algo="tiled", workspace=ws,
+                                          reuse_binning=True))
+    # and a pullback that re-bins is unaffected by whatever the workspace holds
+    pb2 = dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws)
+    assert_close(pb2.points, ref.points, 1e-4, "ds_dpoints (own binning)")
+
+
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
 @pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 96), (3, 2, 200), (2, 2, 150)])
 def test_chunked_on_spatially_sorted_points(oracle, dev, npdt, tdt, n_in, n_out, grid_n):
@@ -637,7 +673,7 @@ def test_full_size_properties(dev, algo, config):
     assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), np.sqrt(P))
 
 
-def test_batched_projection_share_properties(dev, monkeypatch):
+def test_batched_projection_share_properties(dev):
     """BASELINE.json config 4 at a one-GPU share (10M points -> 512^2 orthographic projection,
     8 of the 64 poses a GPU owns; the poses are binned as one pose group): mass per pose,
     batch == loop of singles, pose groups == per-pose pipeline == direct kernels, and the
@@ -664,10 +700,10 @@ def test_batched_projection_share_properties(dev, monkeypatch):
     np.testing.assert_allclose(pb.background.double().cpu().numpy(),
                                g.double().sum(dim=(0, 1)).cpu().numpy(), rtol=0, atol=1e-3 * n)
     # the same batch through the per-pose pipeline and through the direct kernels
-    monkeypatch.setenv("DPR_POSE_GROUP", "1")
-    out1 = dpr_amd.raster((n, n), pts, R, t, bg, ow, algo="tiled")
-    pb1 = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow, algo="tiled")
-    monkeypatch.delenv("DPR_POSE_GROUP")
+    out1 = dpr_amd.raster((n, n), pts, R, t, bg, ow, algo="tiled", max_pose_group=1)
+    pb1 = dpr_amd.raster_pullback_(g, pts, R, t, bg, ow, algo="tiled", max_pose_group=1)
+    assert (dpr_amd.workspace_bytes("raster", (n, n), P, B, 3, torch.float32, "tiled", max_pose_group=1)
+            < dpr_amd.workspace_bytes("raster", (n, n), P, B, 3, torch.float32, "tiled") / 3)
     assert_close(out, out1.cpu().numpy(), 2e-5, "pose groups vs per-pose pipeline: out")
     assert_close(pb.points, pb1.points.cpu().numpy(), 1e-4, "pose groups vs per-pose: ds_dpoints")
     assert_close(pb.rotation, pb1.rotation.cpu().numpy(), 1e-3, "pose groups vs per-pose: ds_drotation")

@@ -27,12 +27,11 @@ def t_ms(fn, reps=5):
     return float(np.median([x.elapsed_time(y) for x, y in e]))
 ref = None
 for grp in a.groups:
-    os.environ["DPR_POSE_GROUP"] = str(grp)
-    wsb = max(dpr_amd.workspace_bytes("pullback", grid, a.P, B, 3, dt, "tiled"), 16)
+    wsb = max(dpr_amd.workspace_bytes("pullback", grid, a.P, B, 3, dt, "tiled", max_pose_group=grp), 16)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    f = t_ms(lambda: dpr_amd.raster_(out, tp, R, t, algo="tiled", workspace=ws))
-    pb = dpr_amd.raster_pullback_(g, tp, R, t, algo="tiled", workspace=ws)
-    b = t_ms(lambda: dpr_amd.raster_pullback_(g, tp, R, t, algo="tiled", workspace=ws))
+    f = t_ms(lambda: dpr_amd.raster_(out, tp, R, t, algo="tiled", workspace=ws, max_pose_group=grp))
+    pb = dpr_amd.raster_pullback_(g, tp, R, t, algo="tiled", workspace=ws, max_pose_group=grp)
+    b = t_ms(lambda: dpr_amd.raster_pullback_(g, tp, R, t, algo="tiled", workspace=ws, max_pose_group=grp))
     chk = (float(out.double().sum()), float(pb.points.double().abs().sum()))
     print(f"P={a.P} grid={grid} B={B} group<={grp:2d}: fwd {f / B * 1e3:7.1f} us/pose  bwd {b / B * 1e3:7.1f} us/pose  "
           f"({a.P * B / (f + b) / 1e6:6.1f} G point-poses/s fwd+bwd)  ws {wsb / 2**20:.0f} MiB  chk {chk[0]:.6e} {chk[1]:.6e}", flush=True)
