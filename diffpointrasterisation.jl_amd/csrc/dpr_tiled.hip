@@ -373,15 +373,32 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ split_list,
                                                    uint32_t* __restrict__ n_split, BinHeader hdr,
                                                    BinHeader* __restrict__ hdr_out,
-                                                   const unsigned char* __restrict__ rot,
-                                                   int rot_bytes,
-                                                   const unsigned char* __restrict__ trans,
-                                                   int trans_bytes) {
-    // header of this binning (state = kBinValid only for a KEEP_BINNING forward)
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < rot_bytes; ++i) hdr.pose[i] = rot[i];
-        for (int i = 0; i < trans_bytes; ++i) hdr.pose[rot_bytes + i] = trans[i];
-        *hdr_out = hdr;
+                                                   const uint32_t* __restrict__ rot,
+                                                   int rot_words,
+                                                   const uint32_t* __restrict__ trans,
+                                                   int trans_words) {
+    // header of this binning (state = kBinValid only for a KEEP_BINNING forward): the last wave
+    // copies the pose words, one lane the fixed fields
+    if (threadIdx.x >= 1024 - 64) {
+        const int i = threadIdx.x - (1024 - 64);
+        uint32_t* pose = (uint32_t*)hdr_out->pose;
+        if (i < rot_words) pose[i] = rot[i];
+        else if (i < rot_words + trans_words) pose[i] = trans[i - rot_words];
+        if (i == 63) {
+            hdr_out->magic = hdr.magic;
+            hdr_out->state = hdr.state;
+            hdr_out->elem = hdr.elem;
+            hdr_out->n_in = hdr.n_in;
+            hdr_out->n_out = hdr.n_out;
+            hdr_out->has_pw = hdr.has_pw;
+            hdr_out->P = hdr.P;
+            hdr_out->grid[0] = hdr.grid[0];
+            hdr_out->grid[1] = hdr.grid[1];
+            hdr_out->grid[2] = hdr.grid[2];
+            hdr_out->verdict = 0;
+            hdr_out->points = hdr.points;
+            hdr_out->pw = hdr.pw;
+        }
     }
     __shared__ uint32_t wsum[16], wslab[16];
     __shared__ uint32_t s_nsplit;
@@ -1685,8 +1702,8 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
                        (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
                        (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split), hdr,
                        (BinHeader*)(ws + pl.off_hdr),
-                       (const unsigned char*)(rot + b * (NO * NI)), (int)(NO * NI * sizeof(T)),
-                       (const unsigned char*)(trans + b * NO), (int)(NO * sizeof(T)));
+                       (const uint32_t*)(rot + b * (NO * NI)), (int)(NO * NI * sizeof(T) / 4),
+                       (const uint32_t*)(trans + b * NO), (int)(NO * sizeof(T) / 4));
     stage_mark(st);
     int rc;
     if (pw) {
