@@ -27,6 +27,7 @@ ALGO_TILED = 2
 ALGO_CHUNKED = 3
 FLAG_KEEP_BINNING = 1
 FLAG_REUSE_BINNING = 2
+FLAG_COHERENT_POINTS = 4
 
 
 def flag_max_pose_group(n: int) -> int:

@@ -33,6 +33,11 @@ int fail(int code, const char* fmt, ...) {
             return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
 
+// AUTO picks DPR_ALGO_CHUNKED (2-D grids) from these sizes on (profiles/r02_chunkown_sweep.txt:
+// the forward wins from ~2e5 points at 8+ poses, the pullback from ~2e6 points)
+constexpr int64_t kChunkOwnMinPoses = 8, kChunkOwnMinPointsFwd = 200000,
+                  kChunkOwnMinPointsBwd = 2000000;
+
 static bool dims_supported(int n_in, int n_out) {
     return (n_in == 2 && n_out == 2) || (n_in == 3 && n_out == 3) || (n_in == 3 && n_out == 2);
 }
@@ -69,6 +74,11 @@ template <int NO> static GridDesc<NO> make_grid(const int64_t* grid, int64_t G) 
 static int resolve_algo(int algo, int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
                         int64_t G) {
     if (algo != DPR_ALGO_AUTO) return algo;
+    // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside (the Morton sort
+    // of the points, 0.65 ms per 10 M, is repaid from a few poses on)
+    if (n_out == 2 && B >= kChunkOwnMinPoses && P < ((int64_t)1 << 32) &&
+        P >= (op == DPR_OP_RASTER ? kChunkOwnMinPointsFwd : kChunkOwnMinPointsBwd))
+        return DPR_ALGO_CHUNKED;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
 
@@ -147,9 +157,14 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
         if (algo == DPR_ALGO_TILED)                                                            \
             return raster_tiled<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot, trans, bg, ow,  \
                                            pw, ws, ws_bytes);                                  \
-        if (algo == DPR_ALGO_CHUNKED)                                                          \
-            return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot, trans, \
-                                             bg, ow, pw, ws, ws_bytes);                        \
+        if (algo == DPR_ALGO_CHUNKED) {                                                        \
+            if constexpr (NO == 2)                                                             \
+                return raster_chunkown<T, NI>(st, flags, grid, G, P, B, out, points, rot, trans, \
+                                              bg, ow, pw, ws, ws_bytes);                       \
+            else                                                                               \
+                return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot,   \
+                                                 trans, bg, ow, pw, ws, ws_bytes);             \
+        }                                                                                      \
     }
     DPR_CASE(2, 2)
     DPR_CASE(3, 3)
@@ -247,13 +262,20 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
             return pullback_tiled<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans, ow, pw,    \
                                              d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
                                              ws_bytes, rs);                                      \
-        if (algo == DPR_ALGO_CHUNKED && rs.target)                                               \
-            return fail(DPR_ERR_UNSUPPORTED_ALGO,                                                \
-                        "the residual pullback has no DPR_ALGO_CHUNKED variant");                \
-        if (algo == DPR_ALGO_CHUNKED)                                                            \
-            return pullback_chunked<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot, trans,   \
-                                               ow, pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw,  \
-                                               ws, ws_bytes);                                    \
+        if (algo == DPR_ALGO_CHUNKED) {                                                          \
+            if constexpr (NO == 2) {                                                             \
+                return pullback_chunkown<T, NI>(st, flags, grid, G, P, B, g, points, rot, trans, \
+                                                ow, pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, \
+                                                ws, ws_bytes, rs);                               \
+            } else {                                                                             \
+                if (rs.target)                                                                   \
+                    return fail(DPR_ERR_UNSUPPORTED_ALGO,                                        \
+                                "the residual pullback has no 3-D DPR_ALGO_CHUNKED variant");    \
+                return pullback_chunked<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot,     \
+                                                   trans, ow, pw, d_pts, d_rot, d_trans, d_bg,   \
+                                                   d_ow, d_pw, ws, ws_bytes);                    \
+            }                                                                                    \
+        }                                                                                        \
     }
     DPR_CASE(2, 2)
     DPR_CASE(3, 3)
@@ -280,7 +302,14 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
                  "DPR_ALGO_TILED: grid needs too many tiles or P >= 2^32 (the call would be refused)");
         return n;
     }
-    if (algo == DPR_ALGO_CHUNKED) return chunked_workspace_bytes(n_out, grid, P, B);
+    if (algo == DPR_ALGO_CHUNKED) {
+        if (n_out == 2) {
+            const size_t n = chunkown_workspace_bytes(sizeof(T), op, flags, n_in, P, B);
+            if (n == (size_t)-1) fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
+            return n;
+        }
+        return chunked_workspace_bytes(n_out, grid, P, B);
+    }
     fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
     return (size_t)-1;
 }

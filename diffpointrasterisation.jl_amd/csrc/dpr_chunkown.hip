@@ -1,0 +1,637 @@
+// DPR_ALGO_CHUNKED for 2-D grids (projections 3 -> 2 and 2 -> 2): CHUNK-OWNED LDS tiles, pose
+// loop inside the block.  This is the many-poses shape of the reference's README timings
+// (/root/reference/README.md:189-192, ext/DiffPointRasterisationCUDAExt.jl:19-210 keeps one point
+// and a block of poses per thread block; here a block keeps a CHUNK of points and walks the poses).
+//
+// A chunk is kChunk consecutive points of a spatially coherent (Morton-sorted) cloud: a compact
+// blob in the model frame, so under any pose its projection covers a small pixel rectangle
+// (~35 x 35 pixels for a 4096-point chunk of the 10 M-point cloud on 512^2), bounded WITHOUT
+// looking at the points again: footprint = projected centre +- sum_j |R[d,j]| h_j of the chunk's
+// 3-D bounding box.  Per block, with the chunk's points held in registers for ALL poses:
+//
+//   forward   per pose: 4 ds_add_f64 per point into the footprint tile in LDS, then the tile is
+//             flushed with global atomic adds, one image row segment (contiguous x) per wave
+//             instruction -- the 256-byte shape float atomics run at full rate in; `out` was
+//             pre-filled with the background.  A pixel of a projection collects ~40 points, so
+//             the LDS tile turns 4 global atomics per (point, pose) into ~0.3.
+//   pullback  per pose: the ds_dout footprint is staged in LDS (coalesced rows), every point
+//             gathers its 4 values from LDS; ds_dpoints / ds_dpoint_weight accumulate in
+//             registers across the poses and are stored once per point; the per-pose sums go
+//             wave -> LDS (f64) -> one partial per (block, pose), reduced by k_co_reduce.
+//             No records, no permutation, no global atomics.
+//
+// Lanes of a wave take points that are kChunk / 64 apart in the chunk (not neighbours): sorted
+// neighbours project onto the same pixels, and same-address LDS atomics serialise (26 -> 190
+// cycles per wave instruction, profiles/r02_microbench_lds_conflicts.txt).
+//
+// Input that is not known to be coherent (no DPR_FLAG_COHERENT_POINTS) is Morton-sorted into the
+// workspace first (rocPRIM radix sort, 0.65 ms for 10 M points: amortised over the poses of the
+// call) and the point gradients are scattered back through the permutation.  Whatever the order,
+// the result is correct: a (chunk, pose) whose footprint does not fit the LDS tile, and any
+// neighbour outside the footprint bound, goes to / comes from global memory directly.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/dpr.h"
+#include "dpr_device.h"
+#include "dpr_kernels_atomic.h"
+#include "dpr_tiled.h"
+
+namespace dpr {
+
+constexpr int kCOThreads = 1024;
+constexpr int kCOPPT = 4;                        // points per thread
+constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
+constexpr int kCOWaves = kCOThreads / kWave;
+constexpr int kCOCap = 9216;                     // LDS tile cells (8 bytes each): 72 KiB, 2 blocks / CU
+constexpr int kCOMaxSlice = 64;                  // poses per block (per-pose sums live in LDS)
+static_assert(kCOChunk / kWave == kCOWaves * kCOPPT, "spread assignment covers the chunk");
+
+// index of the k-th point of thread (lane, wave) inside the chunk: lanes kChunk/64 apart
+// workgroup barrier that orders LDS traffic only (global atomics / loads stay in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ int co_point(int lane, int wave, int k) {
+    return lane * (kCOChunk / kWave) + wave * kCOPPT + k;
+}
+
+template <typename T> __device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const T u = __shfl_xor(v, o, kWave);
+        v = u < v ? u : v;
+    }
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const T u = __shfl_xor(v, o, kWave);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
+// Chunk points into registers + the chunk's bounding box (centre c, half extent h), identical
+// in every thread.  Non-finite coordinates take no part in the box (such points are rejected by
+// ref_and_deltas for every pose).  Returns false when the chunk has no finite point.
+template <typename T, int NI>
+__device__ __forceinline__ bool co_load_chunk(const T* __restrict__ points,
+                                              const T* __restrict__ pw, int64_t P, int64_t base,
+                                              T (&pt)[kCOPPT][NI], T (&w)[kCOPPT],
+                                              bool (&live)[kCOPPT], T (&c)[NI], T (&h)[NI],
+                                              T (*sbox)[2 * 3]) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    T lo[NI], hi[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        lo[j] = T(INFINITY);
+        hi[j] = T(-INFINITY);
+    }
+#pragma unroll
+    for (int k = 0; k < kCOPPT; ++k) {
+        const int64_t p = base + co_point(lane, wave, k);
+        live[k] = p < P;
+        const int64_t pl = live[k] ? p : P - 1;
+        load_point<T, NI>(points, pl, pt[k]);
+        w[k] = pw ? pw[pl] : T(1);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const T x = pt[k][j];
+            if (live[k] && x - x == T(0)) {  // finite
+                lo[j] = x < lo[j] ? x : lo[j];
+                hi[j] = x > hi[j] ? x : hi[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        lo[j] = wave_min<T>(lo[j]);
+        hi[j] = wave_max<T>(hi[j]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            sbox[wave][j] = lo[j];
+            sbox[wave][3 + j] = hi[j];
+        }
+    }
+    __syncthreads();
+    bool any = true;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        T l = sbox[0][j], u = sbox[0][3 + j];
+#pragma unroll
+        for (int q = 1; q < kCOWaves; ++q) {
+            l = sbox[q][j] < l ? sbox[q][j] : l;
+            u = sbox[q][3 + j] > u ? sbox[q][3 + j] : u;
+        }
+        any = any && (l <= u);
+        c[j] = T(0.5) * l + T(0.5) * u;
+        h[j] = T(0.5) * u - T(0.5) * l;
+    }
+    return any;
+}
+
+// Pixel rectangle [lo, hi] (inclusive, clipped to the grid) that bounds every in-grid neighbour
+// of every point of the chunk under pose `ps`, with one cell of slack for rounding.  Returns the
+// number of cells (0: nothing lands in the grid; > kCOCap: does not fit the LDS tile).
+template <typename T, int NI>
+__device__ __forceinline__ int64_t co_footprint(const T (&c)[NI], const T (&h)[NI],
+                                                const Pose<T, NI, 2>& ps, const GridDesc<2>& gd,
+                                                int (&lo)[2], int (&hi)[2]) {
+    int64_t cells = 1;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        T pc = ps.R[d] * c[0], ph = (ps.R[d] < T(0) ? -ps.R[d] : ps.R[d]) * h[0];
+#pragma unroll
+        for (int j = 1; j < NI; ++j) {
+            const T r = ps.R[d + j * 2];
+            pc = pc + r * c[j];
+            ph = ph + (r < T(0) ? -r : r) * h[j];
+        }
+        ph = ph * T(1.0001) + T(1e-6);
+        const T origin = T(-1) - ps.t[d];
+        const T scale = T(gd.n[d]) / T(2);
+        T a = ((pc - ph) - origin) * scale - T(2.5);  // ref0 >= coord - 1.5, one cell of slack
+        T b = ((pc + ph) - origin) * scale + T(1.5);  // ref0 + 1 <= coord + 0.5, one cell of slack
+        // clamp before float -> int (also maps NaN to an empty range)
+        a = a > T(-4) ? a : T(-4);
+        a = a < T(gd.n[d] + 4) ? a : T(gd.n[d] + 4);
+        b = b > T(-4) ? b : T(-4);
+        b = b < T(gd.n[d] + 4) ? b : T(gd.n[d] + 4);
+        int l = (int)a, u = (int)b + 1;
+        if (!(a == a) || !(b == b)) {
+            l = 1;
+            u = 0;
+        }
+        lo[d] = l < 0 ? 0 : l;
+        hi[d] = u > gd.n[d] - 1 ? gd.n[d] - 1 : u;
+        cells *= (hi[d] >= lo[d]) ? (int64_t)(hi[d] - lo[d] + 1) : 0;
+    }
+    return cells;
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int NI, bool HAS_PW>
+__global__ __launch_bounds__(kCOThreads) void k_co_splat(GridDesc<2> gd, int64_t P, int64_t B,
+                                                         int poses_per_slice,
+                                                         const T* __restrict__ points,
+                                                         const T* __restrict__ pw,
+                                                         const T* __restrict__ rot,
+                                                         const T* __restrict__ trans,
+                                                         const T* __restrict__ ow,
+                                                         T* __restrict__ out) {
+    __shared__ double acc[kCOCap];
+    __shared__ T sbox[kCOWaves][6];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int i = threadIdx.x; i < kCOCap; i += kCOThreads) acc[i] = 0.0;
+    T pt[kCOPPT][NI], w[kCOPPT], c[NI], h[NI];
+    bool live[kCOPPT];
+    const bool any = co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P,
+                                          (int64_t)blockIdx.x * kCOChunk, pt, w, live, c, h, sbox);
+    if (!any) return;  // uniform: no finite point in this chunk
+    const int64_t b_lo = (int64_t)blockIdx.y * poses_per_slice;
+    const int64_t b_hi = (b_lo + poses_per_slice < B) ? b_lo + poses_per_slice : B;
+    const int nbs = (int)(b_hi - b_lo);
+    // Blocks start at different poses: chunks along one viewing ray project onto the same
+    // pixels, and float atomics of many workgroups into the same rows at the same time run an
+    // order of magnitude slower than spread ones.
+    const int rot0 = (int)(blockIdx.x % (unsigned)nbs);
+    for (int jb = 0; jb < nbs; ++jb) {
+        const int64_t b = b_lo + (jb + rot0) % nbs;
+        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
+        int lo[2], hi[2];
+        const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+        if (cells == 0) continue;  // uniform
+        // A footprint larger than the LDS tile (sparse tails of the cloud, incoherent input) is
+        // covered in several passes over bands of rows; only a footprint WIDER than the whole
+        // tile goes to global memory directly.
+        const int W = hi[0] - lo[0] + 1;
+        const bool direct = W > kCOCap;
+        const int band = direct ? (1 << 30) : ((cells <= kCOCap) ? (hi[1] - lo[1] + 1) : kCOCap / W);
+        T* o = out + b * gd.G;
+        for (int y0 = lo[1]; y0 <= hi[1]; y0 += band) {
+            const int y1 = (y0 + band - 1 < hi[1]) ? y0 + band - 1 : hi[1];
+            const bool first = y0 == lo[1];
+#pragma unroll
+            for (int k = 0; k < kCOPPT; ++k) {
+                int ref0[2];
+                T dlo[2];
+                const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+                const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ix = ref0[0] + (s & 1), iy = ref0[1] + (s >> 1);
+                    const bool in = ok && ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1];
+                    const T v = voxel_weight<T, 2>(dlo, s, wk);
+                    const bool in_foot = !direct && ix >= lo[0] && ix <= hi[0] && iy >= lo[1] && iy <= hi[1];
+                    if (in && in_foot) {
+                        if (iy >= y0 && iy <= y1)
+                            atomicAdd(&acc[(iy - y0) * W + (ix - lo[0])], (double)v);
+                    } else if (in && first) {  // outside the bound (rounding), or no LDS tile at all
+                        atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
+                    }
+                }
+            }
+            if (direct) break;  // uniform
+            lds_barrier();
+            // flush + re-zero: one wave per image row segment, contiguous x across the lanes
+            for (int r = wave; r <= y1 - y0; r += kCOWaves) {
+                T* orow = o + (size_t)(y0 + r) * gd.n[0] + lo[0];
+                for (int x = lane; x < W; x += kWave) {
+                    const double a = acc[r * W + x];
+                    if (a != 0.0) {
+                        atomic_add<T>(orow + x, (T)a);
+                        acc[r * W + x] = 0.0;
+                    }
+                }
+            }
+            lds_barrier();  // LDS only: the flush's atomics stay in flight
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pullback
+// partials[(slice_pose) ...]: layout [NVAL][B][nblk] (f64), NVAL = 2 NI + 2 + 1
+template <typename T, int NI, bool HAS_PW>
+__global__ __launch_bounds__(kCOThreads) void k_co_gather(
+    GridDesc<2> gd, int64_t P, int64_t B, int poses_per_slice, const T* __restrict__ g,
+    const T* __restrict__ points, const T* __restrict__ pw, const T* __restrict__ rot,
+    const T* __restrict__ trans, const T* __restrict__ ow, T* __restrict__ ds_dpoints,
+    T* __restrict__ ds_dpw, double* __restrict__ partials, int accumulate_points, Residual<T> rs) {
+    constexpr int NVAL = 2 * NI + 2 + 1;  // dR | dt | d out_weight
+    __shared__ T tile[kCOCap];
+    __shared__ T sbox[kCOWaves][6];
+    __shared__ double pacc[kCOMaxSlice][NVAL];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int i = threadIdx.x; i < kCOMaxSlice * NVAL; i += kCOThreads) (&pacc[0][0])[i] = 0.0;
+    T pt[kCOPPT][NI], w[kCOPPT], c[NI], h[NI];
+    bool live[kCOPPT];
+    const bool any = co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P,
+                                          (int64_t)blockIdx.x * kCOChunk, pt, w, live, c, h, sbox);
+    T dp[kCOPPT][NI], dpw[kCOPPT];
+#pragma unroll
+    for (int k = 0; k < kCOPPT; ++k) {
+        dpw[k] = T(0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) dp[k][j] = T(0);
+    }
+    const int64_t b_lo = (int64_t)blockIdx.y * poses_per_slice;
+    const int64_t b_hi = (b_lo + poses_per_slice < B) ? b_lo + poses_per_slice : B;
+    for (int64_t b = b_lo; any && b < b_hi; ++b) {
+        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
+        int lo[2], hi[2];
+        const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+        if (cells == 0) continue;  // uniform: no neighbour of the chunk is in the grid
+        // A footprint that does not fit the LDS tile (sparse tails of the cloud, incoherent
+        // input) is gathered from global memory directly (L2-resident image; unlike the
+        // forward's atomics these are plain loads).
+        const bool fits = cells <= kCOCap;
+        const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
+        const T* gb = g + b * gd.G;
+        const T* tb = rs.target ? rs.target + b * gd.G : nullptr;
+        if (fits) {
+            // stage the footprint of ds_dout (residual mode: scale * (out - target))
+            for (int r = wave; r < H; r += kCOWaves) {
+                const size_t off = (size_t)(lo[1] + r) * gd.n[0] + lo[0];
+                for (int x = lane; x < W; x += kWave) {
+                    T v = gb[off + x];
+                    if (tb) v = rs.scale * (v - tb[off + x]);
+                    tile[r * W + x] = v;
+                }
+            }
+            __syncthreads();
+        }
+        T vals[NVAL];
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q) vals[q] = T(0);
+#pragma unroll
+        for (int k = 0; k < kCOPPT; ++k) {
+            int ref0[2];
+            T dlo[2];
+            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+            if (!ok) continue;  // no in-range neighbour (or non-finite): empty gradient
+            const T pwi = HAS_PW ? w[k] : T(1);
+            T dcoord[2] = {T(0), T(0)}, dow_part = T(0), dpw_part = T(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ix = ref0[0] + (s & 1), iy = ref0[1] + (s >> 1);
+                const bool in = ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1];
+                const bool in_tile = fits && ix >= lo[0] && ix <= hi[0] && iy >= lo[1] && iy <= hi[1];
+                T gi = T(0);
+                if (in && in_tile) {
+                    gi = tile[(iy - lo[1]) * W + (ix - lo[0])];
+                } else if (in) {
+                    const size_t off = (size_t)iy * gd.n[0] + ix;
+                    gi = gb[off];
+                    if (tb) gi = rs.scale * (gi - tb[off]);
+                }
+                // src/raster_pullback.jl:51-60 (a dropped neighbour adds nothing: gi == 0)
+                const T dweight = voxel_weight<T, 2>(dlo, s, gi);
+                dow_part += dweight * pwi;
+                dpw_part += dweight * ps.ow;
+                const T factor = gi * ps.ow * pwi;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) dcoord[n] += factor * interp_weight<T, 2>(n, dlo, s);
+            }
+            T scaled[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));  // :67
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) vals[n + j * 2] += scaled[n] * pt[k][j];  // :69
+                vals[2 * NI + n] += scaled[n];                                         // :68
+            }
+            vals[2 * NI + 2] += dow_part;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)  // rotation' * scaled (:70)
+                dp[k][j] += ps.R[0 + j * 2] * scaled[0] + ps.R[1 + j * 2] * scaled[1];
+            dpw[k] += dpw_part;
+        }
+        if (fits) lds_barrier();  // the tile is re-staged for the next pose (LDS phases only)
+        // per-pose sums: T within the thread (kCOPPT points), f64 across lanes / waves / blocks
+#pragma unroll
+        for (int q = 0; q < NVAL; ++q) {
+            const double sum = wave_sum<double>((double)vals[q]);
+            if (lane == 0 && sum != 0.0) atomicAdd(&pacc[b - b_lo][q], sum);
+        }
+    }
+    __syncthreads();
+    const int nb = (int)(b_hi - b_lo);
+    const int64_t nblk = gridDim.x;
+    for (int i = threadIdx.x; i < nb * NVAL; i += kCOThreads) {
+        const int j = i / NVAL, q = i % NVAL;
+        partials[((size_t)q * B + (b_lo + j)) * nblk + blockIdx.x] = pacc[j][q];
+    }
+#pragma unroll
+    for (int k = 0; k < kCOPPT; ++k) {
+        const int64_t p = (int64_t)blockIdx.x * kCOChunk + co_point(lane, wave, k);
+        if (p >= P) continue;
+        if (accumulate_points) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) atomic_add<T>(ds_dpoints + p * NI + j, dp[k][j]);
+            atomic_add<T>(ds_dpw + p, dpw[k]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp[k][j];
+            ds_dpw[p] = dpw[k];
+        }
+    }
+}
+
+// partials[NVAL][B][nblk] -> ds_drotation | ds_dtranslation | ds_dout_weight.  Block per
+// (scalar, pose).
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void k_co_reduce(const double* __restrict__ partials, int64_t B,
+                                                   int64_t nblk, T* __restrict__ d_rot,
+                                                   T* __restrict__ d_trans,
+                                                   T* __restrict__ d_ow) {
+    __shared__ double wsum[4];
+    const int q = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const double* src = partials + ((size_t)q * B + b) * nblk;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < nblk; i += 256) s += src[i];
+    s = wave_sum<double>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (q < 2 * NI)
+            d_rot[b * (2 * NI) + q] = (T)tot;
+        else if (q < 2 * NI + 2)
+            d_trans[b * 2 + (q - 2 * NI)] = (T)tot;
+        else
+            d_ow[b] = (T)tot;
+    }
+}
+
+// sorted gradients back to the caller's order: dst[perm[i]] = src[i]
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void k_co_unsort(int64_t P, const uint32_t* __restrict__ perm,
+                                                   const T* __restrict__ dp_sorted,
+                                                   const T* __restrict__ dpw_sorted,
+                                                   T* __restrict__ ds_dpoints,
+                                                   T* __restrict__ ds_dpw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t p = perm[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp_sorted[i * NI + j];
+    ds_dpw[p] = dpw_sorted[i];
+}
+
+// ------------------------------------------------------------------ host side
+static size_t co_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct COPlan {
+    int64_t nblk;
+    int slices, poses_per_slice;
+    size_t off_pts, off_pw, off_perm, off_grad, off_gradw, off_part, off_sort, total;
+};
+
+size_t sort_workspace_bytes(int64_t P);
+template <typename T>
+int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
+                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes);
+
+// One layout for both operations (like DPR_ALGO_TILED): a workspace sized for `raster` also
+// serves the pullback of the same problem.
+static COPlan co_plan(size_t elem, int op, unsigned flags, int n_in, int64_t P, int64_t B) {
+    op = DPR_OP_PULLBACK;
+    COPlan pl;
+    pl.nblk = (P + kCOChunk - 1) / kCOChunk;
+    if (pl.nblk < 1) pl.nblk = 1;
+    // poses per block: all of them when the chunks alone fill the chip, else split the poses
+    // over grid.y (per-pose sums of at most kCOMaxSlice poses live in LDS)
+    int64_t slices = 1;
+    if (pl.nblk < 1024 && B > 1) slices = (1024 + pl.nblk - 1) / pl.nblk;
+    if (slices > B) slices = B;
+    int64_t pps = (B + slices - 1) / slices;
+    if (pps > kCOMaxSlice) pps = kCOMaxSlice;
+    if (pps < 1) pps = 1;
+    slices = (B + pps - 1) / pps;
+    if (slices < 1) slices = 1;
+    pl.slices = (int)slices;
+    pl.poses_per_slice = (int)pps;
+    const bool sort = !(flags & DPR_FLAG_COHERENT_POINTS);
+    size_t o = 0;
+    pl.off_pts = o;
+    if (sort) o += co_align((size_t)P * n_in * elem);
+    pl.off_pw = o;
+    if (sort) o += co_align((size_t)P * elem);
+    pl.off_perm = o;
+    if (sort) o += co_align((size_t)P * 4);
+    pl.off_grad = o;
+    if (sort && op == DPR_OP_PULLBACK) o += co_align((size_t)P * n_in * elem);
+    pl.off_gradw = o;
+    if (sort && op == DPR_OP_PULLBACK) o += co_align((size_t)P * elem);
+    pl.off_part = o;
+    if (op == DPR_OP_PULLBACK) o += co_align((size_t)(2 * n_in + 3) * (size_t)(B > 0 ? B : 1) * pl.nblk * 8);
+    pl.off_sort = o;
+    if (sort) o += co_align(sort_workspace_bytes(P));
+    pl.total = o > 0 ? o : 256;
+    return pl;
+}
+
+size_t chunkown_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int64_t P,
+                                int64_t B) {
+    if (P >= (int64_t)1 << 32) return (size_t)-1;
+    return co_plan(elem, op, flags, n_in, P, B).total;
+}
+
+#define DPR_HIP(expr)                                                                \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T, int NI>
+int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                    int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                    const T* ow, const T* pw, void* ws_, size_t ws_bytes) {
+    if (P >= (int64_t)1 << 32)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
+    const COPlan pl = co_plan(sizeof(T), DPR_OP_RASTER, flags, NI, P, B);
+    const bool sort = !(flags & DPR_FLAG_COHERENT_POINTS);
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED raster needs %zu workspace bytes, got %zu",
+                    pl.total, ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    GridDesc<2> gd;
+    gd.n[0] = (int)grid[0];
+    gd.n[1] = (int)grid[1];
+    gd.G = G;
+    const T* pts = points;
+    const T* pws = pw;
+    if (sort && P > 0) {
+        T* spts = (T*)(ws + pl.off_pts);
+        T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
+        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts, (uint32_t*)(ws + pl.off_perm),
+                                         pw, spw, ws + pl.off_sort, sort_workspace_bytes(P)))
+            return rc;
+        pts = spts;
+        pws = spw;
+    }
+    stage_mark(st);
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+        const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
+        const int64_t want = (G + kBlock - 1) / kBlock;
+        dim3 gg((unsigned)(want < 4096 ? want : 4096), (unsigned)nb);
+        hipLaunchKernelGGL(k_fill_background<T>, gg, dim3(kBlock), 0, st, out + b0 * G, G,
+                           bg ? bg + b0 : nullptr);
+    }
+    stage_mark(st);
+    if (P > 0) {
+        dim3 gg((unsigned)pl.nblk, (unsigned)pl.slices);
+        if (pws)
+            hipLaunchKernelGGL((k_co_splat<T, NI, true>), gg, dim3(kCOThreads), 0, st, gd, P, B,
+                               pl.poses_per_slice, pts, pws, rot, trans, ow, out);
+        else
+            hipLaunchKernelGGL((k_co_splat<T, NI, false>), gg, dim3(kCOThreads), 0, st, gd, P, B,
+                               pl.poses_per_slice, pts, pws, rot, trans, ow, out);
+    }
+    stage_mark(st);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+template <typename T, int NI>
+int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                      int64_t B, const T* g, const T* points, const T* rot, const T* trans,
+                      const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                      T* d_pw, void* ws_, size_t ws_bytes, Residual<T> rs) {
+    if (P >= (int64_t)1 << 32)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
+    const COPlan pl = co_plan(sizeof(T), DPR_OP_PULLBACK, flags, NI, P, B);
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE,
+                    "DPR_ALGO_CHUNKED pullback needs %zu workspace bytes, got %zu", pl.total,
+                    ws_ ? ws_bytes : (size_t)0);
+    const bool sort = !(flags & DPR_FLAG_COHERENT_POINTS);
+    char* ws = (char*)ws_;
+    GridDesc<2> gd;
+    gd.n[0] = (int)grid[0];
+    gd.n[1] = (int)grid[1];
+    gd.G = G;
+    const T* pts = points;
+    const T* pws = pw;
+    T* gp = d_pts;
+    T* gw = d_pw;
+    if (sort && P > 0) {
+        T* spts = (T*)(ws + pl.off_pts);
+        T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
+        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts, (uint32_t*)(ws + pl.off_perm),
+                                         pw, spw, ws + pl.off_sort, sort_workspace_bytes(P)))
+            return rc;
+        pts = spts;
+        pws = spw;
+        gp = (T*)(ws + pl.off_grad);
+        gw = (T*)(ws + pl.off_gradw);
+    }
+    stage_mark(st);
+    // ds_dbackground[b] = sum(ds_dout[.., b]) (and the loss of the residual form)
+    if (rs.target && rs.loss) DPR_HIP(hipMemsetAsync(rs.loss, 0, sizeof(T) * (size_t)B, st));
+    DPR_HIP(hipMemsetAsync(d_bg, 0, sizeof(T) * (size_t)B, st));
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+        const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
+        int64_t want = (G + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+        if (want * nb > 8192) want = (8192 + nb - 1) / nb;
+        if (want < 1) want = 1;
+        Residual<T> rb = rs;
+        if (rb.target) rb.target += b0 * G;
+        if (rb.loss) rb.loss += b0;
+        hipLaunchKernelGGL(k_grid_sum<T>, dim3((unsigned)want, (unsigned)nb), dim3(kBlock), 0, st,
+                           g + b0 * G, G, d_bg + b0, rb);
+    }
+    stage_mark(st);
+    double* partials = (double*)(ws + pl.off_part);
+    const int accumulate = pl.slices > 1;
+    if (P > 0) {
+        if (accumulate) {
+            DPR_HIP(hipMemsetAsync(gp, 0, sizeof(T) * (size_t)(P * NI), st));
+            DPR_HIP(hipMemsetAsync(gw, 0, sizeof(T) * (size_t)P, st));
+        }
+        dim3 gg((unsigned)pl.nblk, (unsigned)pl.slices);
+        if (pws)
+            hipLaunchKernelGGL((k_co_gather<T, NI, true>), gg, dim3(kCOThreads), 0, st, gd, P, B,
+                               pl.poses_per_slice, g, pts, pws, rot, trans, ow, gp, gw, partials,
+                               accumulate, rs);
+        else
+            hipLaunchKernelGGL((k_co_gather<T, NI, false>), gg, dim3(kCOThreads), 0, st, gd, P, B,
+                               pl.poses_per_slice, g, pts, pws, rot, trans, ow, gp, gw, partials,
+                               accumulate, rs);
+    } else {
+        DPR_HIP(hipMemsetAsync(partials, 0, (size_t)(2 * NI + 3) * (size_t)B * pl.nblk * 8, st));
+    }
+    stage_mark(st);
+    hipLaunchKernelGGL((k_co_reduce<T, NI>), dim3(2 * NI + 3, (unsigned)B), dim3(256), 0, st,
+                       (const double*)partials, B, pl.nblk, d_rot, d_trans, d_ow);
+    if (sort && P > 0)
+        hipLaunchKernelGGL((k_co_unsort<T, NI>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                           P, (const uint32_t*)(ws + pl.off_perm), (const T*)gp, (const T*)gw, d_pts,
+                           d_pw);
+    stage_mark(st);
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+#define DPR_INST_CO(T, NI)                                                                        \
+    template int raster_chunkown<T, NI>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t,  \
+                                        int64_t, T*, const T*, const T*, const T*, const T*,      \
+                                        const T*, const T*, void*, size_t);                       \
+    template int pullback_chunkown<T, NI>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, \
+                                          int64_t, const T*, const T*, const T*, const T*,        \
+                                          const T*, const T*, T*, T*, T*, T*, T*, T*, void*,      \
+                                          size_t, Residual<T>);
+DPR_INST_CO(float, 2)
+DPR_INST_CO(float, 3)
+DPR_INST_CO(double, 2)
+DPR_INST_CO(double, 3)
+}  // namespace dpr

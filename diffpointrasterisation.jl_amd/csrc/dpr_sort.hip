@@ -1,9 +1,14 @@
-// dpr_sort_points_*: pose-independent spatial pre-sort of the model-frame points
-// (Morton / Z-order).  Not part of the reference; SURVEY.md 8(f) rank 3.  Every algorithm of
-// this library is faster on spatially coherent input (profiles/r01_summary.md), and the sort
-// depends on the points only, so a caller amortises it over poses and iterations.
+// dpr_sort_points_*: pose-independent spatial pre-sort of the model-frame points along a
+// HILBERT curve.  Not part of the reference; SURVEY.md 8(f) rank 3.  Every algorithm of this
+// library is faster on spatially coherent input, and the sort depends on the points only, so a
+// caller amortises it over poses and iterations.  Hilbert rather than Morton (Z-) order: the
+// Hilbert curve has no jumps, so ANY run of consecutive points is a compact blob (a Z-order run
+// that straddles a high octree boundary is two blobs far apart: 12 % of the 4096-point chunks
+// of DPR_ALGO_CHUNKED then had footprints too large for LDS).
 //
-//   keys   30-bit (3-D) / 32-bit (2-D) Morton code of the point quantised on [-1, 1)^n
+//   keys   30-bit (3-D) / 32-bit (2-D) Hilbert index of the point quantised on [-1, 1)^n
+//          (Skilling's transpose algorithm, "Programming the Hilbert curve", AIP Conf. Proc.
+//          707, 2004: axes -> transposed index by bit manipulation)
 //   sort   rocPRIM radix sort of (key, index) pairs
 //   gather points_sorted[i] = points[perm[i]]   (+ point weights)
 //
@@ -36,22 +41,54 @@ __device__ __forceinline__ uint32_t spread2(uint32_t v) {  // 16 bits -> every s
     return v;
 }
 
+// Skilling's AxesToTranspose: X[0..N) with BITS bits each -> the Hilbert index in "transposed"
+// form (its bits interleaved over X[0], X[1], .., most significant first)
+template <int N, int BITS> __device__ __forceinline__ void hilbert_transpose(uint32_t (&X)[N]) {
+    constexpr uint32_t M = 1u << (BITS - 1);
+#pragma unroll
+    for (uint32_t Q = M; Q > 1; Q >>= 1) {  // inverse undo
+        const uint32_t Pm = Q - 1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (X[i] & Q) {
+                X[0] ^= Pm;
+            } else {
+                const uint32_t t = (X[0] ^ X[i]) & Pm;
+                X[0] ^= t;
+                X[i] ^= t;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < N; ++i) X[i] ^= X[i - 1];  // Gray encode
+    uint32_t t = 0;
+#pragma unroll
+    for (uint32_t Q = M; Q > 1; Q >>= 1)
+        if (X[N - 1] & Q) t ^= Q - 1;
+#pragma unroll
+    for (int i = 0; i < N; ++i) X[i] ^= t;
+}
+
 template <typename T, int NI>
-__global__ __launch_bounds__(256) void k_morton_keys(int64_t P, const T* __restrict__ points,
-                                                     uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void k_hilbert_keys(int64_t P, const T* __restrict__ points,
+                                                      uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ idx) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     constexpr int BITS = NI == 3 ? 10 : 16;
-    uint32_t key = 0;
+    uint32_t X[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         T x = points[p * NI + j];
         // [-1, 1) -> [0, 2^BITS); NaN and out-of-range points go to the ends
         x = (x * T(0.5) + T(0.5)) * T(1u << BITS);
-        uint32_t q = !(x > T(0)) ? 0u : (x >= T((1u << BITS) - 1) ? (1u << BITS) - 1 : (uint32_t)x);
-        key |= (NI == 3 ? spread3(q) : spread2(q)) << j;
+        X[j] = !(x > T(0)) ? 0u : (x >= T((1u << BITS) - 1) ? (1u << BITS) - 1 : (uint32_t)x);
     }
+    hilbert_transpose<NI, BITS>(X);
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)  // X[0] carries the most significant bit of every level
+        key |= (NI == 3 ? spread3(X[j]) : spread2(X[j])) << (NI - 1 - j);
     keys[p] = key;
     idx[p] = (uint32_t)p;
 }
@@ -114,9 +151,9 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
     size_t temp_bytes = radix_temp_bytes(P);
     const dim3 grid((unsigned)((P + 255) / 256));
     if (n_in == 3)
-        hipLaunchKernelGGL((k_morton_keys<T, 3>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+        hipLaunchKernelGGL((k_hilbert_keys<T, 3>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
     else
-        hipLaunchKernelGGL((k_morton_keys<T, 2>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+        hipLaunchKernelGGL((k_hilbert_keys<T, 2>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm,
                                              (size_t)P, 0, n_in == 3 ? 30 : 32, st);
     if (e != hipSuccess)

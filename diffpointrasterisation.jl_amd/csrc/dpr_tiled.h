@@ -29,7 +29,20 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                    const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw,
                    void* ws, size_t ws_bytes, Residual<T> rs);
 
-// DPR_ALGO_CHUNKED (dpr_chunked.hip)
+// DPR_ALGO_CHUNKED on 2-D grids: chunk-owned LDS tiles, pose loop inside (dpr_chunkown.hip)
+size_t chunkown_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int64_t P,
+                                int64_t B);
+template <typename T, int NI>
+int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                    int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                    const T* ow, const T* pw, void* ws, size_t ws_bytes);
+template <typename T, int NI>
+int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                      int64_t B, const T* g, const T* points, const T* rot, const T* trans,
+                      const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                      T* d_pw, void* ws, size_t ws_bytes, Residual<T> rs);
+
+// DPR_ALGO_CHUNKED on 3-D grids (dpr_chunked.hip)
 bool chunked_supported(int n_out, const int64_t* grid);
 size_t chunked_workspace_bytes(int n_out, const int64_t* grid, int64_t P, int64_t B);
 

@@ -133,7 +133,8 @@ def _workspace(op, algo, suf, n_in, n_out, grid_arr, P, B, device, workspace, fl
 
 
 def workspace_bytes(op: str, grid_size, n_points: int, batch: int, n_in: int, dtype=torch.float32,
-                    algo: str = "auto", max_pose_group: int = 0) -> int:
+                    algo: str = "auto", max_pose_group: int = 0,
+                    coherent_points: bool = False) -> int:
     """dpr_workspace_bytes_ex_*: device bytes `op` needs.  `max_pose_group` (1..16, 0 = default)
     bounds how many poses of a batch the tiled path bins together -- the speed / memory trade of
     DPR_FLAG_MAX_POSE_GROUP (include/dpr.h)."""
@@ -142,7 +143,8 @@ def workspace_bytes(op: str, grid_size, n_points: int, batch: int, n_in: int, dt
     grid_arr = np.asarray(grid_size, dtype=np.int64)
     opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
     need = getattr(_lib.lib(), f"dpr_workspace_bytes_ex_{_SUFFIX[dtype]}")(
-        opc, _lib.ALGOS[algo], _lib.flag_max_pose_group(max_pose_group), n_in, len(grid_size),
+        opc, _lib.ALGOS[algo], _lib.flag_max_pose_group(max_pose_group)
+        | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0), n_in, len(grid_size),
         grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
     if need == ctypes.c_size_t(-1).value:
         raise _lib.DprError(_lib.ERR_INVALID_ARG, _lib.last_error())
@@ -219,7 +221,7 @@ def _canonicalise(points, rotation, translation, background, out_weight, point_w
 # --------------------------------------------------------------------------- forward
 def raster(grid_size, points, rotation, translation, background=None, out_weight=None,
            point_weight=None, *, algo: str = "auto", workspace=None,
-           max_pose_group: int = 0) -> torch.Tensor:
+           max_pose_group: int = 0, coherent_points: bool = False) -> torch.Tensor:
     """Allocating forward (src/interface.jl:62-77).  Returns `out[i_1..i_N]` for a single
     pose (rotation is a matrix) or `out[i_1..i_N, b]` for a batch."""
     device = _device_of(points)
@@ -229,12 +231,14 @@ def raster(grid_size, points, rotation, translation, background=None, out_weight
                                       else len(rotation))
     out = empty_grid(tuple(grid_size), batch, dtype, device)
     return raster_(out, points, rotation, translation, background, out_weight, point_weight,
-                   algo=algo, workspace=workspace, max_pose_group=max_pose_group)
+                   algo=algo, workspace=workspace, max_pose_group=max_pose_group,
+                   coherent_points=coherent_points)
 
 
 def raster_(out, points, rotation, translation, background=None, out_weight=None,
             point_weight=None, *, algo: str = "auto", workspace=None,
-            keep_binning: bool = False, max_pose_group: int = 0) -> torch.Tensor:
+            keep_binning: bool = False, max_pose_group: int = 0,
+            coherent_points: bool = False) -> torch.Tensor:
     """In-place forward, the reference's `raster!`.  `out` is fully overwritten and
     returned (same object).  Enqueued on torch's current stream; not synchronised.
     `keep_binning=True` (tiled algorithm, one pose, explicit `workspace`) leaves the binning
@@ -260,6 +264,7 @@ def raster_(out, points, rotation, translation, background=None, out_weight=None
     algo_c = _lib.ALGOS[algo]
     with torch.cuda.device(c["device"]):
         flags = _lib.flag_max_pose_group(max_pose_group)
+        flags |= _lib.FLAG_COHERENT_POINTS if coherent_points else 0  # dpr_sort_points output etc.
         ws, ws_bytes = _workspace(_lib.OP_RASTER, algo_c, suf, c["n_in"], c["n_out"], grid_arr,
                                   c["P"], c["B"], c["device"], workspace, flags)
         fn = getattr(_lib.lib(), f"dpr_raster_ex_{suf}")
@@ -278,7 +283,8 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
                      point_weight=None, *, ds_dpoints=None, ds_drotation=None,
                      ds_dtranslation=None, ds_dbackground=None, ds_dout_weight=None,
                      ds_dpoint_weight=None, algo: str = "auto", workspace=None,
-                     reuse_binning: bool = False, max_pose_group: int = 0) -> PullbackResult:
+                     reuse_binning: bool = False, max_pose_group: int = 0,
+                     coherent_points: bool = False) -> PullbackResult:
     """The reference's `raster_pullback!` (src/interface.jl:196-308).  Optional keyword
     arguments are pre-allocated outputs (the reference's `points=`, `rotation=`, ... kwargs,
     src/interface.jl:278-291); they are OVERWRITTEN and returned by identity.  Unlike the
@@ -291,7 +297,7 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
     return _pullback(ds_dout, None, points, rotation, translation, background, out_weight,
                      point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
                      ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning,
-                     max_pose_group)
+                     max_pose_group, coherent_points)
 
 
 def raster_residual_pullback_(out, target, points, rotation, translation, background=None,
@@ -319,7 +325,7 @@ def raster_residual_pullback_(out, target, points, rotation, translation, backgr
 def _pullback(ds_dout, residual, points, rotation, translation, background, out_weight,
               point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
               ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning,
-              max_pose_group=0):
+              max_pose_group=0, coherent_points=False):
     import numpy as np
 
     c = _canonicalise(points, rotation, translation, background, out_weight, point_weight,
@@ -384,6 +390,7 @@ def _pullback(ds_dout, residual, points, rotation, translation, background, out_
     algo_c = _lib.ALGOS[algo]
     with torch.cuda.device(dev):
         flags = _lib.flag_max_pose_group(max_pose_group)
+        flags |= _lib.FLAG_COHERENT_POINTS if coherent_points else 0
         ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
                                   workspace, flags)
         flags |= _lib.FLAG_REUSE_BINNING if reuse_binning else 0

@@ -70,11 +70,17 @@ extern "C" {
 #define DPR_ALGO_ATOMIC 1 /* thread per point, direct global float atomics / gathers */
 #define DPR_ALGO_TILED 2  /* per-pose binning of points into voxel tiles, LDS-resident
                              tile accumulation, plain-store flush (no global atomics) */
-#define DPR_ALGO_CHUNKED 3 /* for spatially coherent point order (e.g. Morton-sorted once in
-                              the model frame): chunks of 256 consecutive points are listed
-                              per voxel tile, tiles read the points in place; no per-point
-                              permutation.  Correct for any order (incoherent chunks are
-                              diverted to direct atomics) but only fast for coherent input. */
+#define DPR_ALGO_CHUNKED 3 /* chunks of consecutive points of a spatially coherent cloud.
+                              2-D grids (projections; what AUTO picks for >= 4 poses): a
+                              block owns a chunk of 4096 points and an LDS tile under its
+                              small projected footprint, and loops over the poses -- forward:
+                              LDS accumulation + row-shaped global atomic flush, pullback:
+                              LDS-staged ds_dout, gradients in registers across poses, no
+                              atomics.  The points are Morton-sorted into the workspace first
+                              unless DPR_FLAG_COHERENT_POINTS says they already are.
+                              3-D grids (experimental): chunks of 64 points are listed per
+                              voxel tile, tiles read the points in place.
+                              Correct for any point order; fast only for coherent input. */
 
 /* flags (the *_ex entry points), DPR_ALGO_TILED with B == 1 only:
  * KEEP_BINNING  (raster)   leave the per-tile binning of the points (incl. original
@@ -100,6 +106,11 @@ extern "C" {
  * grows n-fold: (20 | 36) bytes * P * n for fp32 | fp64 -- e.g. 10 M points, 512^2 grid:
  * 0.28 GB at n = 1, 1.66 GB at n = 8.  Pass the same flags to dpr_workspace_bytes_ex_*. */
 #define DPR_FLAG_MAX_POSE_GROUP(n) (((unsigned)(n) & 0xffu) << 8)
+/* DPR_FLAG_COHERENT_POINTS: the caller states that neighbouring points in memory are
+ * neighbours in space (e.g. the output of dpr_sort_points_*).  DPR_ALGO_CHUNKED on 2-D grids
+ * then skips its own Morton sort (and the workspace shrinks to the per-pose partial sums).
+ * A wrong claim costs speed, never correctness. */
+#define DPR_FLAG_COHERENT_POINTS 4u
 
 int dpr_version(void);
 
@@ -118,8 +129,10 @@ int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t *grid, int64_t P
  * Stage order -- DPR_ALGO_ATOMIC raster: fill, splat; pullback: zero+grid_sum, gather.
  * DPR_ALGO_TILED, per pose -- raster: count, scan, scatter, tile_splat, halo;
  * pullback: count, scan, scatter, tile_gather, unpermute, pose_reduce.
- * DPR_ALGO_CHUNKED -- raster: boxes, lists, chunk_splat, divert;
- * pullback: boxes, lists, chunk_gather, pose_reduce, divert. */
+ * DPR_ALGO_CHUNKED, 3-D grids -- raster: boxes, lists, chunk_splat, divert;
+ * pullback: boxes, lists, chunk_gather, pose_reduce, divert.
+ * DPR_ALGO_CHUNKED, 2-D grids -- raster: sort, fill, chunk_splat;
+ * pullback: sort, grid_sum, chunk_gather, reduce+unsort. */
 int dpr_stage_timing_begin(void **events, int capacity);
 int dpr_stage_timing_end(void);
 
@@ -240,9 +253,9 @@ int dpr_raster_residual_pullback_ex_f64(void *stream, int algo, unsigned flags, 
                                         double *ds_dout_weight, double *ds_dpoint_weight,
                                         void *workspace, size_t workspace_bytes);
 
-/* Pose-independent spatial pre-sort (Morton order) of the model-frame points -- not in the
- * reference; every algorithm here is faster on coherent input and the sort only depends on
- * the points.  points_sorted[i] = points[perm[i]] (and point weights likewise; pass NULL for
+/* Pose-independent spatial pre-sort of the model-frame points along a Hilbert curve (any run
+ * of consecutive sorted points is a compact blob) -- not in the reference; every algorithm here
+ * is faster on coherent input and the sort only depends on the points.  points_sorted[i] = points[perm[i]] (and point weights likewise; pass NULL for
  * both weight pointers when unused).  Gradients of the sorted cloud go back with
  * ds_dpoints[perm[i]] = ds_dpoints_sorted[i].  n_in = 2 or 3; P < 2^32. */
 size_t dpr_sort_points_workspace_bytes(int64_t P);

@@ -111,8 +111,11 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     # the direct pullback kernel stays ahead longer (profiles/r01_algo_sweep_batched.txt)
     assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 16, 3) == "tiled"
     assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 1, 3) == "atomic"
-    assert dpr_amd.resolve_algo("pullback", (512, 512), 200_000, 64, 3) == "atomic"
-    assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (512, 512), 100_000, 64, 3) == "atomic"
+    # many poses onto a 2-D grid: chunk-owned LDS tiles with the pose loop inside
+    assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 64, 3) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 1, 3) == "tiled"
     # more tiles than the tiled path supports -> direct kernels
     assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "atomic"
     assert dpr_amd.workspace_bytes("raster", (8, 8), 100, 1, 2, torch.float64, "atomic") == 0

@@ -740,12 +740,46 @@ def test_large_grid_fp64_properties(dev, algo):
     assert_close(pb.point_weight, np.full(P, 1.5), 1e-12)
 
 
+def _hilbert_keys(q, bits):
+    """Skilling's AxesToTranspose + interleave on integer coordinates q (P, n), numpy."""
+    X = [q[:, j].astype(np.int64).copy() for j in range(q.shape[1])]
+    n = len(X)
+    M = 1 << (bits - 1)
+    Q = M
+    while Q > 1:
+        Pm = Q - 1
+        for i in range(n):
+            hit = (X[i] & Q) != 0
+            X0_new = np.where(hit, X[0] ^ Pm, X[0])
+            t = (X[0] ^ X[i]) & Pm
+            X0_new = np.where(hit, X0_new, X[0] ^ t)
+            Xi_new = np.where(hit, X[i], X[i] ^ t)
+            if i == 0:  # t == 0 for i == 0: only the `hit` branch changes X[0]
+                X[0] = X0_new
+            else:
+                X[0], X[i] = X0_new, Xi_new
+        Q >>= 1
+    for i in range(1, n):
+        X[i] = X[i] ^ X[i - 1]
+    t = np.zeros_like(X[0])
+    Q = M
+    while Q > 1:
+        t = np.where((X[n - 1] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    X = [x ^ t for x in X]
+    key = np.zeros_like(X[0])
+    for bit in range(bits):
+        for j in range(n):
+            key |= ((X[j] >> bit) & 1) << (n * bit + (n - 1 - j))
+    return key
+
+
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
 @pytest.mark.parametrize("n_in", [2, 3])
 def test_sort_points_is_a_morton_permutation(oracle, dev, npdt, tdt, n_in):
-    """dpr_sort_points_*: a permutation, keys non-decreasing, weights follow, and the
-    rasterisation of the sorted cloud equals that of the original (order-independent up to
-    rounding); gradients map back through perm."""
+    """dpr_sort_points_*: a permutation, Hilbert keys non-decreasing, weights follow, runs of
+    consecutive points are compact, and the rasterisation of the sorted cloud equals that of
+    the original (order-independent up to rounding); gradients map back through perm."""
     rng = np.random.default_rng(9)
     P = 50_000
     pts = (0.45 * rng.normal(size=(P, n_in))).astype(npdt)
@@ -759,11 +793,14 @@ def test_sort_points_is_a_morton_permutation(oracle, dev, npdt, tdt, n_in):
     bits = 10 if n_in == 3 else 16
     x = (pts[perm_h].astype(npdt) * npdt(0.5) + npdt(0.5)) * npdt(1 << bits)
     q = np.where(~(x > 0), 0, np.where(x >= (1 << bits) - 1, (1 << bits) - 1, np.nan_to_num(x).astype(np.int64))).astype(np.int64)
-    key = np.zeros(P, dtype=np.int64)
-    for bit in range(bits):
-        for k in range(n_in):
-            key |= ((q[:, k] >> bit) & 1) << (n_in * bit + k)
+    key = _hilbert_keys(q, bits)
     assert (np.diff(key) >= 0).all()
+    # the point of a Hilbert order: every run of consecutive points is a compact blob (no jumps)
+    body = pts[perm_h][np.isfinite(pts[perm_h]).all(axis=1) & (np.abs(pts[perm_h]) < 1).all(axis=1)]
+    run = 512
+    ext = np.array([np.ptp(body[i:i + run], axis=0).max() for i in range(0, len(body) - run, 97)])
+    ideal = 2.0 * (run / len(body)) ** (1.0 / n_in)  # side of a cube holding `run` uniform points
+    assert np.median(ext) < 6 * ideal and ext.max() < 40 * ideal
     # same image, gradients map back through perm
     fin = np.isfinite(pts).all(axis=1)
     pts[~fin] = 7.0
