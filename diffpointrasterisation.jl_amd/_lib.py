@@ -48,6 +48,8 @@ EXPORTS = [
     "dpr_raster_pullback_ex_f32", "dpr_raster_pullback_ex_f64",
     "dpr_raster_residual_pullback_f32", "dpr_raster_residual_pullback_f64",
     "dpr_raster_residual_pullback_ex_f32", "dpr_raster_residual_pullback_ex_f64",
+    "dpr_comm_unique_id", "dpr_comm_init", "dpr_comm_destroy", "dpr_comm_world", "dpr_comm_rank",
+    "dpr_shard_range", "dpr_raster_pullback_sharded_f32", "dpr_raster_pullback_sharded_f64",
 ]
 
 _lib = None
@@ -129,6 +131,23 @@ def lib() -> ctypes.CDLL:
         f.restype = i
         f.argtypes = ([vp, i, ctypes.c_uint, i, i, vp, i64, i64, vp, vp, ctypes.c_double]
                       + [vp] * 12 + [vp, sz])
+    L.dpr_comm_unique_id.restype = i
+    L.dpr_comm_unique_id.argtypes = [vp, sz]
+    L.dpr_comm_init.restype = i
+    L.dpr_comm_init.argtypes = [ctypes.POINTER(vp), i, i, vp]
+    L.dpr_comm_destroy.restype = i
+    L.dpr_comm_destroy.argtypes = [vp]
+    L.dpr_comm_world.restype = i
+    L.dpr_comm_world.argtypes = [vp]
+    L.dpr_comm_rank.restype = i
+    L.dpr_comm_rank.argtypes = [vp]
+    L.dpr_shard_range.restype = None
+    L.dpr_shard_range.argtypes = [i64, i, i, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    for suf in ("f32", "f64"):
+        # comm, stream, n_in, n_out, grid, P, B_local, ds_dout, points, rot, trans, ow, pw, 6 outputs, ws, bytes
+        f = getattr(L, f"dpr_raster_pullback_sharded_{suf}")
+        f.restype = i
+        f.argtypes = [vp, vp, i, i, vp, i64, i64] + [vp] * 12 + [vp, sz]
     _lib = L
     return L
 

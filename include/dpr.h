@@ -266,6 +266,48 @@ int dpr_sort_points_f64(void *stream, int n_in, int64_t P, const double *points,
                         double *points_sorted, uint32_t *perm, const double *point_weight,
                         double *point_weight_sorted, void *workspace, size_t workspace_bytes);
 
+/* ---- multi-GPU: pose sharding over RCCL (one process or task per GPU) ------------------------
+ * The batched pullback shards over poses: rank r owns the contiguous pose block
+ * dpr_shard_range(B, r, world), the points are replicated, every per-pose output is disjoint and
+ * the point gradients sum over ranks with ONE all-reduce -- the multi-process form of the
+ * reference's per-thread slabs + sum (src/raster_pullback.jl:112-147).  The forward needs no
+ * exchange: call dpr_raster_* on the local pose block.
+ *
+ *   rank 0:  dpr_comm_unique_id(id, DPR_COMM_ID_BYTES); ship the 128 bytes to the other ranks by
+ *            the host's own means (MPI, a file, Julia Distributed); every rank, with its GPU
+ *            current: dpr_comm_init(&comm, world, rank, id); ... ; dpr_comm_destroy(comm).
+ * RCCL is loaded at run time (librccl.so.1); DPR_ERR_HIP if it is not available. */
+#define DPR_COMM_ID_BYTES 128
+typedef struct dpr_comm dpr_comm_t;
+int dpr_comm_unique_id(void *id_out, size_t id_bytes);
+int dpr_comm_init(dpr_comm_t **comm_out, int world, int rank, const void *id);
+int dpr_comm_destroy(dpr_comm_t *comm);
+int dpr_comm_world(const dpr_comm_t *comm);
+int dpr_comm_rank(const dpr_comm_t *comm);
+void dpr_shard_range(int64_t batch, int rank, int world, int64_t *lo, int64_t *hi);
+/* dpr_raster_pullback_<T> on this rank's B_local poses (all `_local` arguments are the rank's
+ * slices), then all-reduce(sum) of ds_dpoints / ds_dpoint_weight over the communicator on
+ * `stream`: after the call they hold the global sums on every rank.  One all-reduce when the two
+ * buffers are adjacent (ds_dpoint_weight == ds_dpoints + n_in * P), a grouped pair otherwise. */
+int dpr_raster_pullback_sharded_f32(dpr_comm_t *comm, void *stream, int n_in, int n_out,
+                                    const int64_t *grid, int64_t P, int64_t B_local,
+                                    const float *ds_dout_local, const float *points,
+                                    const float *rotation_local, const float *translation_local,
+                                    const float *out_weight_local, const float *point_weight,
+                                    float *ds_dpoints, float *ds_drotation_local,
+                                    float *ds_dtranslation_local, float *ds_dbackground_local,
+                                    float *ds_dout_weight_local, float *ds_dpoint_weight,
+                                    void *workspace, size_t workspace_bytes);
+int dpr_raster_pullback_sharded_f64(dpr_comm_t *comm, void *stream, int n_in, int n_out,
+                                    const int64_t *grid, int64_t P, int64_t B_local,
+                                    const double *ds_dout_local, const double *points,
+                                    const double *rotation_local, const double *translation_local,
+                                    const double *out_weight_local, const double *point_weight,
+                                    double *ds_dpoints, double *ds_drotation_local,
+                                    double *ds_dtranslation_local, double *ds_dbackground_local,
+                                    double *ds_dout_weight_local, double *ds_dpoint_weight,
+                                    void *workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

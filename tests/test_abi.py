@@ -77,6 +77,21 @@ def test_argument_errors_are_reported_without_a_device(suf):
     assert ws(7, 0, 3, 3, gp, 1000, 2) == ctypes.c_size_t(-1).value
 
 
+def test_comm_entry_points_validate_before_touching_rccl():
+    L = dpr_amd.lib()
+    small = (ctypes.c_char * 16)()
+    assert L.dpr_comm_unique_id(small, 16) == dpr_amd._lib.ERR_INVALID_ARG
+    comm = ctypes.c_void_p()
+    uid = (ctypes.c_char * 128)()
+    assert L.dpr_comm_init(ctypes.byref(comm), 2, 2, uid) == dpr_amd._lib.ERR_INVALID_ARG
+    assert L.dpr_comm_init(ctypes.byref(comm), 0, 0, uid) == dpr_amd._lib.ERR_INVALID_ARG
+    assert L.dpr_comm_destroy(None) == 0 and L.dpr_comm_world(None) == 0 and L.dpr_comm_rank(None) == -1
+    grid = np.array([8, 8, 8], dtype=np.int64)
+    rc = L.dpr_raster_pullback_sharded_f32(None, None, 3, 3, grid.ctypes.data_as(ctypes.c_void_p), 10, 1,
+                                           *([None] * 12), None, 0)
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "comm" in dpr_amd._lib.last_error()
+
+
 def test_host_api_refuses_cpu_tensors():
     """No CPU fallback: the product path must fail loudly off-device."""
     import torch
@@ -90,9 +105,14 @@ def test_host_api_refuses_cpu_tensors():
 
 
 def test_shard_range_is_a_partition():
+    L = dpr_amd.lib()
     for B in [0, 1, 5, 8, 9, 64, 513]:
         for world in [1, 2, 3, 8]:
             ranges = [dpr_amd.shard_range(B, r, world) for r in range(world)]
+            for r in range(world):  # the C entry point a non-Python host uses agrees
+                lo, hi = ctypes.c_int64(), ctypes.c_int64()
+                L.dpr_shard_range(B, r, world, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == ranges[r]
             assert ranges[0][0] == 0 and ranges[-1][1] == B
             for (a, b), (c, d) in zip(ranges, ranges[1:]):
                 assert b == c

@@ -305,6 +305,57 @@ def test_pose_and_point_sharded_drivers_with_hip_compute_over_nccl(oracle, dev, 
     _compare(ref, rpb, out2, res2, npdt)
 
 
+@pytest.mark.parametrize("suf,npdt,tdt", [("f32", np.float32, torch.float32),
+                                          ("f64", np.float64, torch.float64)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_c_abi_sharded_pullback_over_rccl(oracle, dev, suf, npdt, tdt, fused):
+    """dpr_comm_unique_id / dpr_comm_init / dpr_raster_pullback_sharded_<T> / dpr_comm_destroy
+    through raw ctypes (what a non-Python host binds): a one-rank RCCL
+    communicator on this GPU, the rank's pose block from dpr_shard_range, the all-reduce on the
+    caller's stream.  Results against the oracle."""
+    L = dpr_amd.lib()
+    uid = (ctypes.c_char * 128)()
+    assert L.dpr_comm_unique_id(uid, 128) == 0, dpr_amd._lib.last_error()
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        assert L.dpr_comm_init(ctypes.byref(comm), 1, 0, uid) == 0, dpr_amd._lib.last_error()
+    try:
+        assert L.dpr_comm_world(comm) == 1 and L.dpr_comm_rank(comm) == 0
+        P, n, B = 300_000, 64, 5
+        d = D.make(n_points=P, n_in=3, n_out=3, batch=B, grid_n=n, seed=13, dtype=npdt)
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        L.dpr_shard_range(B, 0, 1, ctypes.byref(lo), ctypes.byref(hi))
+        assert (lo.value, hi.value) == (0, B)
+        grid = np.array([n, n, n], dtype=np.int64)
+        gp = grid.ctypes.data_as(ctypes.c_void_p)
+        need = getattr(L, f"dpr_workspace_bytes_{suf}")(dpr_amd._lib.OP_PULLBACK, 0, 3, 3, gp, P, B)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        pts = T(d.points, dev)
+        rot_cm = T(np.ascontiguousarray(np.transpose(d.rotations, (0, 2, 1))), dev)
+        trans, ow, pw = T(d.translations, dev), T(d.weights, dev), T(d.point_weights, dev)
+        g = torch.as_tensor(np.ascontiguousarray(np.transpose(d.ds_dout, (3, 2, 1, 0))), device=dev)
+        buf = torch.full((P * 4 + 64,), float("nan"), dtype=tdt, device=dev)
+        d_pts = buf[: P * 3].view(P, 3)
+        d_pw = buf[P * 3: P * 4] if fused else buf[P * 3 + 64:]
+        outs = [torch.full(s, float("nan"), dtype=tdt, device=dev) for s in [(B, 3, 3), (B, 3), (B,), (B,)]]
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = getattr(L, f"dpr_raster_pullback_sharded_{suf}")(
+            comm, stream, 3, 3, gp, P, B, _vp(g), _vp(pts), _vp(rot_cm), _vp(trans), _vp(ow), _vp(pw),
+            _vp(d_pts), *[_vp(o) for o in outs], _vp(d_pw), _vp(ws), ws.numel())
+        assert rc == 0, dpr_amd._lib.last_error()
+        torch.cuda.synchronize()
+        rpb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                     d.point_weights, dtype=npdt)
+        assert_close(d_pts, rpb.points, tol(npdt, "points"), "ds_dpoints")
+        assert_close(d_pw, rpb.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+        assert_close(outs[0].transpose(1, 2), rpb.rotation, tol(npdt, "pose"), "ds_drotation")
+        assert_close(outs[1], rpb.translation, tol(npdt, "pose"), "ds_dtranslation")
+        assert_close(outs[2], rpb.background, tol(npdt, "pose"), "ds_dbackground")
+        assert_close(outs[3], rpb.out_weight, tol(npdt, "pose"), "ds_dout_weight")
+    finally:
+        assert L.dpr_comm_destroy(comm) == 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (one rank per GPU)")
 def test_bench_two_ranks_over_rccl(tmp_path):
     """bench.py --gpus 2 from a bare shell: its own launcher, one rank per GPU, RCCL exchange."""
