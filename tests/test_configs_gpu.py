@@ -123,8 +123,8 @@ def test_c5_share_8_poses(dev):
 @pytest.mark.parametrize("algo", ["auto", "tiled"])
 def test_512_cube_fp64_vs_oracle(oracle, dev, algo):
     """HIP vs oracle on the C5 grid (512^3 fp64: 16384 tiles) with 1e5 points, all optional
-    arguments given, two poses."""
-    d = D.make(n_points=100_000, n_in=3, n_out=3, batch=2, grid_n=512, seed=21, dtype=np.float64)
+    arguments given."""
+    d = D.make(n_points=100_000, n_in=3, n_out=3, batch=1, grid_n=512, seed=21, dtype=np.float64)
     opt = (d.backgrounds, d.weights, d.point_weights)
     ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, *opt)
     out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev),
