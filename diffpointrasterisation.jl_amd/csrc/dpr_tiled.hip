@@ -233,13 +233,28 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
     if (!GROUP) {
         const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0);
-        for (int64_t p = lo + threadIdx.x; p < hi; p += kBinThreads) {
-            T pt[NI];
-            load_point<T, NI>(points, p, pt);
-            int ref0[NO];
-            T dlo[NO];
-            if (ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo))
-                atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
+        // kCU points per thread are requested before the first one is used: with one load in
+        // flight per thread (768 B per wave) the 32 waves of a CU cover ~3 TB/s of the chip
+#ifndef DPR_COUNT_UNROLL
+#define DPR_COUNT_UNROLL 4
+#endif
+        constexpr int kCU = DPR_COUNT_UNROLL;
+        for (int64_t base = lo + threadIdx.x; base < hi; base += (int64_t)kCU * kBinThreads) {
+            T pt[kCU][NI];
+            bool live[kCU];
+#pragma unroll
+            for (int u = 0; u < kCU; ++u) {
+                const int64_t p = base + (int64_t)u * kBinThreads;
+                live[u] = p < hi;
+                load_point<T, NI>(points, live[u] ? p : hi - 1, pt[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kCU; ++u) {
+                int ref0[NO];
+                T dlo[NO];
+                if (ref_and_deltas<T, NI, NO>(pt[u], ps, gd, ref0, dlo) && live[u])
+                    atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
+            }
         }
     } else {
         // a pose group: each point is read once and classified for every pose of the group
@@ -700,17 +715,22 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
     constexpr int NVH = tile_voxels_halo<NO>();
     __shared__ double acc[NVH];
-    // the item and the item count are fetched together (the list is allocated for the whole
-    // grid): one memory latency, not two, before the block can start
+    // Everything the block needs from memory before it can touch its records is requested at
+    // once -- the item, the item count (the list is allocated for the whole grid, so reading
+    // past the count is safe) and the pose of the group's first image -- instead of one after
+    // the other (count -> item -> pose were three dependent round trips of 1-2 us each on a
+    // busy chip).  Only a pose group's later images need a second pose fetch.
+    const uint32_t n_it = *n_items;
     const WorkItem item = items[blockIdx.x];
-    if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
+    Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
+    if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
     // item.tile = (pose within the group) * NT + tile
     const int tile = (int)(item.tile % (uint32_t)tg.NT);
     const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+    if (b != b0) ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     // Record assignment: strided (lane-adjacent records, coalesced) or blocked (each thread
     // owns a contiguous run, so lanes are far apart in the list: with spatially sorted input
     // lane-adjacent records hit the same voxel and same-address LDS atomics serialise).
@@ -1080,8 +1100,11 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         if (blockIdx.x == 0 && threadIdx.x == 0) hdr->verdict = ok ? 1u : 0u;
         if (!ok) return;  // k_unpermute / k_pose_reduce turn the verdict into NaN outputs
     }
-    WorkItem item = items[blockIdx.x];  // fetched together with the item count
-    if (blockIdx.x >= *n_items) return;  // the grid is sized for the worst case
+    // item, item count and the first image's pose are requested together (see k_tile_splat)
+    const uint32_t n_it = *n_items;
+    WorkItem item = items[blockIdx.x];
+    Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
+    if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
     // record ranges never leave the record buffer, whatever the lists say
     if (item.end > (uint32_t)P) item.end = (uint32_t)P;
     if (item.begin > item.end) item.begin = item.end;
@@ -1172,8 +1195,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
             tile_g[row * (TX + 1) + TX] = val;
         }
     }
+    if (b != b0) ps = load_pose<T, NI, NO>(rot, trans, ow, b);  // later image of a pose group
     lds_barrier();  // LDS phases only: prefetched records stay in flight
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
     // per-thread sums of the per-pose scalars: T within the thread (few records each),
     // f64 across threads / tiles
     T vals[NVAL - 2];
