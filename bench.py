@@ -315,8 +315,10 @@ def run_rank(args):
     algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P_local, Bq, n_in)
     # The pullback reuses the tile binning its forward call built in the same step (what an
     # rrule caches between `raster` and its pullback closure); nothing is carried across steps.
-    # Single pose only (DPR_FLAG_KEEP_BINNING needs B == 1).
-    can_share = single_call and do_bwd and algo_f == algo_b and algo_f in ("tiled", "chunked")
+    # Batched calls share on the chunk-owner path (2-D grids): what is kept there is the sorted copy
+    # of the cloud, for any number of poses.
+    can_share = do_bwd and algo_f == algo_b and (
+        (single_call and algo_f in ("tiled", "chunked")) or (algo_f == "chunked" and n_out == 2))
     share = can_share and not args.no_share_binning
 
     def fwd(keep=None):

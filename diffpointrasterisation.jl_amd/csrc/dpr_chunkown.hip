@@ -41,7 +41,10 @@
 namespace dpr {
 
 constexpr int kCOThreads = 1024;
-constexpr int kCOPPT = 4;                        // points per thread
+#ifndef DPR_CO_PPT
+#define DPR_CO_PPT 4
+#endif
+constexpr int kCOPPT = DPR_CO_PPT;               // points per thread
 constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
 constexpr int kCOWaves = kCOThreads / kWave;
 constexpr int kCOCap = 9216;                     // LDS tile cells (8 bytes each): 72 KiB, 2 blocks / CU
@@ -175,6 +178,27 @@ __device__ __forceinline__ int64_t co_footprint(const T (&c)[NI], const T (&h)[N
     return cells;
 }
 
+// What a DPR_FLAG_KEEP_BINNING forward leaves at the start of the workspace: the identity of the
+// cloud whose sorted copy (+ permutation) follows.  A DPR_FLAG_REUSE_BINNING pullback skips its
+// own sort and checks this ON THE DEVICE; on a mismatch it reads nothing through the stale
+// permutation and returns NaN gradients (the host cannot see the mismatch without synchronising).
+// The CONTENT of `points` is not checked: like the tiled path's binning, the sorted copy belongs
+// to the raster call of the same call pair.
+constexpr uint32_t kSortMagic = 0x44505253u;
+struct alignas(16) SortHeader {
+    uint32_t magic, elem, n_in, has_pw;
+    int64_t P;
+    uint64_t points, pw;
+};
+__global__ void k_co_write_header(SortHeader h, SortHeader* dst) {
+    if (threadIdx.x == 0) *dst = h;
+}
+__device__ __forceinline__ bool sort_header_ok(const SortHeader* hdr, const SortHeader& want) {
+    return hdr->magic == kSortMagic && hdr->elem == want.elem && hdr->n_in == want.n_in &&
+           hdr->has_pw == want.has_pw && hdr->P == want.P && hdr->points == want.points &&
+           hdr->pw == want.pw;
+}
+
 // ------------------------------------------------------------------ forward
 template <typename T, int NI, bool HAS_PW>
 __global__ __launch_bounds__(kCOThreads) void k_co_splat(GridDesc<2> gd, int64_t P, int64_t B,
@@ -262,8 +286,19 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     GridDesc<2> gd, int64_t P, int64_t B, int poses_per_slice, const T* __restrict__ g,
     const T* __restrict__ points, const T* __restrict__ pw, const T* __restrict__ rot,
     const T* __restrict__ trans, const T* __restrict__ ow, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, double* __restrict__ partials, int accumulate_points, Residual<T> rs) {
+    T* __restrict__ ds_dpw, double* __restrict__ partials, int accumulate_points, Residual<T> rs,
+    SortHeader want, const SortHeader* hdr) {
     constexpr int NVAL = 2 * NI + 2 + 1;  // dR | dt | d out_weight
+    if (want.magic && !sort_header_ok(hdr, want)) {
+        // REUSE_BINNING without the matching KEEP_BINNING forward: NaN partials (k_co_unsort
+        // turns the point gradients into NaN as well), nothing read through stale pointers
+        const int64_t b_lo0 = (int64_t)blockIdx.y * poses_per_slice;
+        const int64_t b_hi0 = (b_lo0 + poses_per_slice < B) ? b_lo0 + poses_per_slice : B;
+        for (int i = threadIdx.x; i < (int)(b_hi0 - b_lo0) * NVAL; i += kCOThreads)
+            partials[((size_t)(i % NVAL) * B + (b_lo0 + i / NVAL)) * gridDim.x + blockIdx.x] =
+                __builtin_nan("");
+        return;
+    }
     __shared__ T tile[kCOCap];
     __shared__ T sbox[kCOWaves][6];
     __shared__ double pacc[kCOMaxSlice][NVAL];
@@ -417,10 +452,19 @@ __global__ __launch_bounds__(256) void k_co_unsort(int64_t P, const uint32_t* __
                                                    const T* __restrict__ dp_sorted,
                                                    const T* __restrict__ dpw_sorted,
                                                    T* __restrict__ ds_dpoints,
-                                                   T* __restrict__ ds_dpw) {
+                                                   T* __restrict__ ds_dpw, SortHeader want,
+                                                   const SortHeader* hdr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    if (want.magic && !sort_header_ok(hdr, want)) {
+        const T nan = T(__builtin_nanf(""));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ds_dpoints[i * NI + j] = nan;
+        ds_dpw[i] = nan;
+        return;
+    }
     const size_t p = perm[i];
+    if (p >= (size_t)P) return;  // never for a permutation this library wrote
 #pragma unroll
     for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp_sorted[i * NI + j];
     ds_dpw[p] = dpw_sorted[i];
@@ -432,7 +476,7 @@ static size_t co_align(size_t x) { return (x + 255) & ~(size_t)255; }
 struct COPlan {
     int64_t nblk;
     int slices, poses_per_slice;
-    size_t off_pts, off_pw, off_perm, off_grad, off_gradw, off_part, off_sort, total;
+    size_t off_hdr, off_pts, off_pw, off_perm, off_grad, off_gradw, off_part, off_sort, total;
 };
 
 size_t sort_workspace_bytes(int64_t P);
@@ -461,6 +505,8 @@ static COPlan co_plan(size_t elem, int op, unsigned flags, int n_in, int64_t P, 
     pl.poses_per_slice = (int)pps;
     const bool sort = !(flags & DPR_FLAG_COHERENT_POINTS);
     size_t o = 0;
+    pl.off_hdr = o;
+    o += co_align(sizeof(SortHeader));
     pl.off_pts = o;
     if (sort) o += co_align((size_t)P * n_in * elem);
     pl.off_pw = o;
@@ -519,6 +565,17 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
         pts = spts;
         pws = spw;
     }
+    {
+        SortHeader h{};
+        h.magic = (sort && (flags & DPR_FLAG_KEEP_BINNING)) ? kSortMagic : 0u;  // else: nothing to reuse
+        h.elem = (uint32_t)sizeof(T);
+        h.n_in = NI;
+        h.has_pw = pw ? 1u : 0u;
+        h.P = P;
+        h.points = (uint64_t)(uintptr_t)points;
+        h.pw = (uint64_t)(uintptr_t)pw;
+        hipLaunchKernelGGL(k_co_write_header, dim3(1), dim3(64), 0, st, h, (SortHeader*)(ws + pl.off_hdr));
+    }
     stage_mark(st);
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {
         const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
@@ -564,12 +621,28 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
     const T* pws = pw;
     T* gp = d_pts;
     T* gw = d_pw;
+    // DPR_FLAG_REUSE_BINNING: the sorted copy and the permutation of the preceding
+    // KEEP_BINNING raster call are still in the workspace (validated on the device)
+    const bool reuse = sort && (flags & DPR_FLAG_REUSE_BINNING);
+    SortHeader want{};
+    if (reuse) {
+        want.magic = kSortMagic;
+        want.elem = (uint32_t)sizeof(T);
+        want.n_in = NI;
+        want.has_pw = pw ? 1u : 0u;
+        want.P = P;
+        want.points = (uint64_t)(uintptr_t)points;
+        want.pw = (uint64_t)(uintptr_t)pw;
+    }
+    const SortHeader* hdr = (const SortHeader*)(ws + pl.off_hdr);
     if (sort && P > 0) {
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
-        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts, (uint32_t*)(ws + pl.off_perm),
-                                         pw, spw, ws + pl.off_sort, sort_workspace_bytes(P)))
-            return rc;
+        if (!reuse)
+            if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts,
+                                             (uint32_t*)(ws + pl.off_perm), pw, spw,
+                                             ws + pl.off_sort, sort_workspace_bytes(P)))
+                return rc;
         pts = spts;
         pws = spw;
         gp = (T*)(ws + pl.off_grad);
@@ -602,11 +675,11 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
         if (pws)
             hipLaunchKernelGGL((k_co_gather<T, NI, true>), gg, dim3(kCOThreads), 0, st, gd, P, B,
                                pl.poses_per_slice, g, pts, pws, rot, trans, ow, gp, gw, partials,
-                               accumulate, rs);
+                               accumulate, rs, want, hdr);
         else
             hipLaunchKernelGGL((k_co_gather<T, NI, false>), gg, dim3(kCOThreads), 0, st, gd, P, B,
                                pl.poses_per_slice, g, pts, pws, rot, trans, ow, gp, gw, partials,
-                               accumulate, rs);
+                               accumulate, rs, want, hdr);
     } else {
         DPR_HIP(hipMemsetAsync(partials, 0, (size_t)(2 * NI + 3) * (size_t)B * pl.nblk * 8, st));
     }
@@ -616,7 +689,7 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
     if (sort && P > 0)
         hipLaunchKernelGGL((k_co_unsort<T, NI>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
                            P, (const uint32_t*)(ws + pl.off_perm), (const T*)gp, (const T*)gw, d_pts,
-                           d_pw);
+                           d_pw, want, hdr);
     stage_mark(st);
     DPR_HIP(hipGetLastError());
     return DPR_OK;

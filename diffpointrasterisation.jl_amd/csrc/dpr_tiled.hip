@@ -1441,7 +1441,8 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // Experiment knobs: environment overrides of the compiled-in defaults, read ONCE per process
 // (function-local static: thread-safe, no getenv on the call path) and clamped to valid ranges.
 struct Knobs {
-    int cap3d_div, cap2d_div, pose_group, scatter_wc, bwd_unpermute, compact_records, splat_blocked;
+    int cap3d_div, cap2d_div, cap_min, pose_group, scatter_wc, bwd_unpermute, compact_records,
+        splat_blocked;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -1453,6 +1454,7 @@ static const Knobs& knobs() {
         Knobs q;
         q.cap3d_div = env_int("DPR_CAP3D_DIV", 256, 1, 1 << 20);
         q.cap2d_div = env_int("DPR_CAP2D_DIV", 2048, 0, 1 << 20);  // 0: use the 3-D rule
+        q.cap_min = env_int("DPR_CAP_MIN", 4096, 256, 1 << 24);
         q.pose_group = env_int("DPR_POSE_GROUP", 16, 1, 16);
         q.scatter_wc = env_int("DPR_SCATTER_WC", 1, 0, 1);
         q.bwd_unpermute = env_int("DPR_BWD_UNPERMUTE", 1, 0, 1);
@@ -1525,7 +1527,7 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     // one per CU, while the headline Gaussian cloud has no tile above it), at least 4096; a
     // split tile's parts hold more than cap/2 records each
     int64_t cap = P / knobs().cap3d_div;
-    if (cap < 4096) cap = 4096;
+    if (cap < knobs().cap_min) cap = knobs().cap_min;
     if (n_out == 2) {
         // 2-D grids have few tiles (256 at 512^2) with cheap LDS tiles (8.7 KB): split
         // earlier so that a dense projection still gives the chip ~2048 items

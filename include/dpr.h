@@ -82,7 +82,8 @@ extern "C" {
                               voxel tile, tiles read the points in place.
                               Correct for any point order; fast only for coherent input. */
 
-/* flags (the *_ex entry points), DPR_ALGO_TILED with B == 1 only:
+/* flags (the *_ex entry points); DPR_ALGO_TILED / 3-D DPR_ALGO_CHUNKED: B == 1 only; DPR_ALGO_CHUNKED
+ * on 2-D grids: any B (what is kept there is the sorted copy of the cloud and its permutation):
  * KEEP_BINNING  (raster)   leave the per-tile binning of the points (incl. original
  *                          indices) in the workspace for the pullback of the same call pair
  * REUSE_BINNING (pullback) the workspace still holds the binning written by the preceding

@@ -120,6 +120,49 @@ def test_c5_share_8_poses(dev):
     assert_close(pb.point_weight, np.full(P, 0.5 * float(ow.sum())), 1e-12)
 
 
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+@pytest.mark.parametrize("with_pw", [False, True])
+def test_chunk_owner_keeps_the_sorted_cloud_for_the_pullback(oracle, dev, npdt, tdt, with_pw):
+    """DPR_ALGO_CHUNKED on a 2-D grid, batch of poses: the forward (KEEP_BINNING) leaves the
+    Hilbert-sorted copy of the cloud in the workspace, the pullback (REUSE_BINNING) skips its own
+    sort; a pullback that finds no matching copy returns NaN; pre-sorted input with
+    coherent_points=True gives the same results."""
+    d = D.make(n_points=120_000, n_in=3, n_out=2, batch=9, grid_n=96, seed=4, dtype=npdt)
+    d.points[::11] *= 3.5  # some far outside
+    pw = d.point_weights if with_pw else None
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(pw, dev))
+    ws = torch.zeros(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, d.batch, 3, tdt, "chunked"),
+                     dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, d.batch, tdt, dev)
+    g = grid_to_dev(d.ds_dout, dev)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                            pw, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights, pw,
+                                    dtype=npdt)
+    stale = dpr_amd.raster_pullback_(g, *args, algo="chunked", workspace=ws, reuse_binning=True)
+    assert bool(torch.isnan(stale.points).all()) and bool(torch.isnan(stale.rotation).all())
+    dpr_amd.raster_(out, *args, algo="chunked", workspace=ws, keep_binning=True)
+    for _ in range(2):  # the sorted copy is not consumed
+        pb = dpr_amd.raster_pullback_(g, *args, algo="chunked", workspace=ws, reuse_binning=True)
+        _compare(ref_out, ref_pb, out, pb, npdt)
+    other = T(d.points, dev).clone()
+    wrong = dpr_amd.raster_pullback_(g, other, *args[1:], algo="chunked", workspace=ws, reuse_binning=True)
+    assert bool(torch.isnan(wrong.points).all())
+    # pre-sorted cloud + the coherence hint: no sort inside, same numbers
+    if with_pw:
+        sp, perm, spw = dpr_amd.sort_points(args[0], args[5])
+    else:
+        (sp, perm), spw = dpr_amd.sort_points(args[0]), None
+    out2 = dpr_amd.raster(d.grid, sp, *args[1:5], spw, algo="chunked", coherent_points=True)
+    assert_close(out2, ref_out, tol(npdt, "out"), "coherent forward")
+    pb2 = dpr_amd.raster_pullback_(g, sp, *args[1:5], spw, algo="chunked", coherent_points=True)
+    back = torch.empty_like(pb2.points)
+    back.index_copy_(0, perm.long(), pb2.points)
+    assert_close(back, ref_pb.points, tol(npdt, "points"), "coherent pullback through perm")
+    assert_close(pb2.rotation, ref_pb.rotation, tol(npdt, "pose"), "coherent ds_drotation")
+
+
 @pytest.mark.parametrize("algo", ["auto", "tiled"])
 def test_512_cube_fp64_vs_oracle(oracle, dev, algo):
     """HIP vs oracle on the C5 grid (512^3 fp64: 16384 tiles) with 1e5 points, all optional
