@@ -500,16 +500,20 @@ def run_rank(args):
         sorted_pts, _perm = dpr_amd.sort_points(points)  # dpr_sort_points_f32
         points_random = points
         points = sorted_pts
-        coherent_kw = {}
+        # the caller of dpr_sort_points may say so: DPR_FLAG_COHERENT_POINTS (local binning)
+        coherent_kw = dict(coherent_points=True)
+        ws_c = torch.empty(max(16, dpr_amd.workspace_bytes("pullback", grid, P, 1, n_in, tdt, algo_f,
+                                                           coherent_points=True)),
+                           dtype=torch.uint8, device=device)
 
         def fwd_c(keep=None):
-            dpr_amd.raster_(out, points, R, t, algo=algo_f, workspace=ws,
+            dpr_amd.raster_(out, points, R, t, algo=algo_f, workspace=ws_c,
                             keep_binning=share if keep is None else keep, **coherent_kw)
 
         def bwd_c():
             dpr_amd.raster_pullback_(g, points, R, t, ds_dpoints=fused[: P * n_in].view(P, n_in),
                                      ds_dpoint_weight=fused[P * n_in:], algo=algo_b,
-                                     workspace=ws, reuse_binning=share, **coherent_kw)
+                                     workspace=ws_c, reuse_binning=share, **coherent_kw)
 
         def step_c():
             fwd_c()
@@ -524,14 +528,16 @@ def run_rank(args):
             step_c()
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / args.steps
-        st_fm = dpr_amd.stage_times(fwd_c, "raster", algo_f, reps)
-        coh = {"point_order": "morton (dpr_sort_points once, not timed)",
+        names_c = "tiled_local" if algo_f == "tiled" else algo_f
+        st_fm = dpr_amd.stage_times(fwd_c, "raster", names_c, reps)
+        coh = {"point_order": "Hilbert-sorted (dpr_sort_points once, not timed) + DPR_FLAG_COHERENT_POINTS",
                "value": round(P / el / 1e6, 3), "unit": "M points/s",
                "ms_per_step": round(el * 1e3, 4), "raster_ms": round(st_fm["total"], 4),
                "raster_frac_of_hbm_peak": round(gbs(a_fwd, st_fm["total"]) / HBM_PEAK_GBS, 4),
                "raster_stages": {k: round(v, 4) for k, v in st_fm.items()}}
         if do_bwd:
-            st_bm = dpr_amd.stage_times(bwd_c, "pullback", algo_b, reps, prepare=fwd_c)
+            st_bm = dpr_amd.stage_times(bwd_c, "pullback", "tiled_local" if algo_b == "tiled" else algo_b,
+                                        reps, prepare=fwd_c)
             coh["pullback_ms"] = round(st_bm["total"], 4)
         line["coherent_input"] = coh
         points = points_random

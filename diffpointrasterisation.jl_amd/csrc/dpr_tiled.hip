@@ -376,6 +376,108 @@ struct alignas(16) WorkItem {
     uint32_t part_nparts;  // part | nparts << 16
 };
 
+// ---- LOCAL BINNING (DPR_FLAG_COHERENT_POINTS) ------------------------------------------------
+// For a spatially coherent cloud the per-pose permutation can stay LOCAL: a block orders one
+// sub-chunk of S consecutive points by tile in LDS and writes it out as ONE contiguous run of
+// records, plus a descriptor {tile, start, count} for every tile the sub-chunk touches (a
+// handful -- 13 of 2048 for a 4096-point sub-chunk of the Hilbert-sorted C3 cloud).  No count
+// pass over the points, no counts table, no column scan; the descriptors (3 % of the points'
+// bytes) are sorted by tile instead of the records, and the tile kernels walk the record runs
+// their descriptors name.  Correct for any order -- an incoherent cloud just yields about as
+// many descriptors as points and runs slowly, which is why the caller has to ask for it.
+struct alignas(8) RunDesc {
+    uint32_t start;       // first record of the run
+    uint32_t tile_count;  // tile | count << 16   (tile < 4096 on this path, count <= S <= 4096)
+    __host__ __device__ uint32_t tile() const { return tile_count & 0xffffu; }
+    __host__ __device__ uint32_t count() const { return tile_count >> 16; }
+};
+constexpr int kMaxRuns = 256;        // descriptors per round of a work item in k_tile_splat ...
+constexpr int kMaxRunsGather = 64;   // ... and in k_tile_gather (their tables live in LDS: 4
+                                     // gather blocks per CU leave room for 64 runs)
+
+// LDS tables of one work item's runs + a forward-only cursor: logical record i of the item ->
+// index into the record array.  A thread asks for non-decreasing i only.
+template <int N> struct RunTable {
+    uint32_t start[N];
+    uint32_t prefix[N + 1];
+};
+struct RunCursor {
+    int k;
+    uint32_t pos, left;  // next record of the current run, records left in it
+    // position the cursor on logical record i (binary search: largest k with prefix[k] <= i)
+    template <int N> __device__ __forceinline__ void seek(const RunTable<N>& rt, uint32_t i, int nruns) {
+        int lo = 0, hi = nruns - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rt.prefix[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        k = lo;
+        pos = rt.start[k] + (i - rt.prefix[k]);
+        left = rt.prefix[k + 1] - i;
+    }
+    // record index of the cursor's position, then advance by `step` logical records (the table
+    // is only read when a run is exhausted); `more` = there are records behind the new position
+    template <int N>
+    __device__ __forceinline__ uint32_t next(const RunTable<N>& rt, uint32_t step, int nruns, bool more) {
+        const uint32_t p = pos;
+        if (step < left) {
+            pos += step;
+            left -= step;
+        } else if (more) {
+            uint32_t skip = step - left;  // records to skip in the following runs
+            ++k;
+            while (k + 1 < nruns && skip >= rt.prefix[k + 1] - rt.prefix[k]) {
+                skip -= rt.prefix[k + 1] - rt.prefix[k];
+                ++k;
+            }
+            pos = rt.start[k] + skip;
+            left = rt.prefix[k + 1] - rt.prefix[k] - skip;
+        }
+        return p;
+    }
+};
+// all threads of the block: load the item's descriptors, build the prefix table; returns the
+// number of records of the item.  `nthreads` >= 64; ends with a barrier.
+template <int N>
+__device__ __forceinline__ uint32_t load_runs(RunTable<N>& rt, const RunDesc* __restrict__ runs,
+                                              uint32_t d0, uint32_t d1, uint32_t max_rec) {
+    const int nruns = (int)(d1 - d0);
+    if (threadIdx.x < kWave) {  // one wave, N / 64 descriptors per lane
+        constexpr int PER = N / kWave;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = threadIdx.x * PER + q;
+            c[q] = 0;
+            if (j < nruns) {
+                const RunDesc d = runs[d0 + j];
+                // record runs never leave the record buffer, whatever a stale list says
+                const uint32_t st = d.start < max_rec ? d.start : max_rec;
+                c[q] = d.count() < max_rec - st ? d.count() : max_rec - st;
+                rt.start[j] = st;
+            }
+            sum += c[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, kWave);
+            if ((int)threadIdx.x >= o) incl += v;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = threadIdx.x * PER + q;
+            if (j <= nruns) rt.prefix[j] = run;
+            run += c[q];
+        }
+        if (threadIdx.x == kWave - 1) rt.prefix[N] = incl;  // == total when nruns == N
+    }
+    __syncthreads();
+    return rt.prefix[nruns];
+}
+
 // exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768), and the
 // work list: items[] ordered by decreasing size (log2 buckets; the heaviest items are
 // dispatched first), n_items, and per tile the number of parts and its first overflow slab.
@@ -705,6 +807,286 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     }
 }
 
+// ------------------------------------------------------------------ local binning: K1
+// One block per sub-chunk of S consecutive points (see "LOCAL BINNING" above).
+//   LDS: lhist[NT] (dynamic) | recs[S]
+// Outputs: records rec[sub * S ...] in tile order (rejected points leave holes at the end of the
+// sub-chunk's slab), slot_of[p] for the pullback, the sub-chunk's descriptors appended to
+// `desc` (position from one global atomic per block) and the per-tile totals tile_ndesc /
+// tile_npts (global atomics, two per descriptor).
+template <typename T, int NI, int NO, bool HAS_PW, int S, bool W3>
+__global__ __launch_bounds__(kBinThreads) void k_bin_local(
+    GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
+    RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, RunDesc* __restrict__ desc,
+    uint32_t* __restrict__ n_desc, uint32_t* __restrict__ tile_ndesc,
+    uint32_t* __restrict__ tile_npts, uint32_t spare_slot, T* __restrict__ ds_dpoints,
+    T* __restrict__ ds_dpw, int zero_dropped) {
+    static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
+    constexpr int PPT = S / kBinThreads;
+    constexpr int kMaxBpt = 4096 / kBinThreads;
+    const int NT = tg.NT;
+    extern __shared__ uint32_t lhist[];  // [NT]
+    __shared__ RecT<T, W3> recs[S];
+    __shared__ uint32_t wsum[kBinThreads / kWave];
+    __shared__ uint32_t s_dbase;
+    for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
+    const int64_t base = (int64_t)blockIdx.x * S;
+    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
+    T pt[PPT][NI], w[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+        const int64_t pl = p < P ? p : P - 1;
+        load_point<T, NI>(points, pl, pt[k]);
+        w[k] = HAS_PW ? pw[pl] : T(1);
+    }
+    __syncthreads();
+    // a. classify; rank inside (sub-chunk, tile).  Neighbouring lanes of a coherent cloud fall
+    // into the same tile, and same-address returning LDS atomics serialise: each wave first
+    // ranks the lanes that share the tile of its first unranked lane (ballot), one atomic per
+    // distinct tile and wave.
+    int tile[PPT];
+    uint32_t lrank[PPT];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+        int ref0[NO];
+        T dlo[NO];
+        const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < P;
+        tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+        lrank[k] = 0;
+        unsigned long long todo = __ballot(valid);
+        int rounds = 0;
+        while (todo && rounds < 8) {  // a few distinct tiles per wave; the rest one by one
+            const int leader = __ffsll((long long)todo) - 1;
+            const int t = __shfl(tile[k], leader, kWave);
+            const unsigned long long same = __ballot(tile[k] == t) & todo;
+            uint32_t b0 = 0;
+            if (lane == leader) b0 = atomicAdd(&lhist[t], (uint32_t)__popcll(same));
+            b0 = __shfl(b0, leader, kWave);
+            if ((same >> lane) & 1ull) lrank[k] = b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+            ++rounds;
+        }
+        if ((todo >> lane) & 1ull) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
+    }
+    lds_barrier();
+    // b. exclusive scan of lhist (in place); the same pass counts the non-empty bins (packed
+    // into the upper half: at most 4096 of each)
+    const int bpt = (NT + kBinThreads - 1) / kBinThreads;
+    const int bin0 = threadIdx.x * bpt;
+    uint32_t cnt[kMaxBpt], packed = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxBpt; ++q) {
+        const int i = bin0 + q;
+        cnt[q] = (q < bpt && i < NT) ? lhist[i] : 0u;
+        packed += cnt[q] + (cnt[q] ? (1u << 16) : 0u);
+    }
+    uint32_t incl = packed;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += v;
+    }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    lds_barrier();
+    uint32_t run = incl - packed;
+    for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
+    uint32_t total = 0;
+#pragma unroll
+    for (int wv = 0; wv < kBinThreads / kWave; ++wv) total += wsum[wv];
+    const uint32_t n_valid = total & 0xffffu, n_runs = total >> 16;
+    if (threadIdx.x == 0) s_dbase = n_runs ? atomicAdd(n_desc, n_runs) : 0u;
+    {
+        uint32_t r2 = run;
+#pragma unroll
+        for (int q = 0; q < kMaxBpt; ++q) {
+            const int i = bin0 + q;
+            if (q < bpt && i < NT) lhist[i] = r2 & 0xffffu;  // exclusive offset inside the sub-chunk
+            r2 += cnt[q] + (cnt[q] ? (1u << 16) : 0u);
+        }
+    }
+    lds_barrier();
+    // descriptors of this sub-chunk + per-tile totals
+    {
+        uint32_t r2 = run;
+#pragma unroll
+        for (int q = 0; q < kMaxBpt; ++q) {
+            const int i = bin0 + q;
+            if (q < bpt && i < NT && cnt[q]) {
+                RunDesc d;
+                d.start = (uint32_t)base + (r2 & 0xffffu);
+                d.tile_count = (uint32_t)i | (cnt[q] << 16);
+                desc[s_dbase + (r2 >> 16)] = d;
+                atomicAdd(&tile_ndesc[i], 1u);
+                atomicAdd(&tile_npts[i], cnt[q]);
+            }
+            r2 += cnt[q] + (cnt[q] ? (1u << 16) : 0u);
+        }
+    }
+    // c. place into LDS in tile order
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+        if (tile[k] >= 0) {
+            const uint32_t sidx = lhist[tile[k]] + lrank[k];
+            RecT<T, W3> r;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
+            if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+            recs[sidx] = r;
+            if (slot_of) __builtin_nontemporal_store((uint32_t)base + sidx, &slot_of[p]);
+        } else if (p < P) {
+            if (slot_of) __builtin_nontemporal_store(spare_slot, &slot_of[p]);
+            if (zero_dropped) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
+                ds_dpw[p] = T(0);
+            }
+        }
+    }
+    lds_barrier();
+    // d. write-out: one contiguous, coalesced run
+    for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[base + i] = recs[i];
+}
+
+// local binning: K2 -- tile totals -> descriptor offsets, work list (a work item is a range of
+// a tile's descriptors holding about `cap` records at most), heaviest first.  Single block.
+// Also clears the cursors K3 uses.
+__global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ tile_ndesc,
+                                                  const uint32_t* __restrict__ tile_npts, int NT,
+                                                  uint32_t cap, uint32_t* __restrict__ tile_dstart,
+                                                  uint32_t* __restrict__ tile_cursor,
+                                                  WorkItem* __restrict__ items,
+                                                  uint32_t* __restrict__ n_items,
+                                                  uint32_t* __restrict__ tile_parts,
+                                                  uint32_t* __restrict__ tile_slab,
+                                                  uint32_t* __restrict__ split_list,
+                                                  uint32_t* __restrict__ n_split, int max_items,
+                                                  BinHeader hdr, BinHeader* __restrict__ hdr_out,
+                                                  const uint32_t* __restrict__ rot, int rot_words,
+                                                  const uint32_t* __restrict__ trans,
+                                                  int trans_words) {
+    if (threadIdx.x >= 1024 - 64) {  // binning header, as in k_tilescan
+        const int i = threadIdx.x - (1024 - 64);
+        uint32_t* pose = (uint32_t*)hdr_out->pose;
+        if (i < rot_words) pose[i] = rot[i];
+        else if (i < rot_words + trans_words) pose[i] = trans[i - rot_words];
+        if (i == 63) {
+            hdr_out->magic = hdr.magic;
+            hdr_out->state = hdr.state;
+            hdr_out->elem = hdr.elem;
+            hdr_out->n_in = hdr.n_in;
+            hdr_out->n_out = hdr.n_out;
+            hdr_out->has_pw = hdr.has_pw;
+            hdr_out->P = hdr.P;
+            hdr_out->grid[0] = hdr.grid[0];
+            hdr_out->grid[1] = hdr.grid[1];
+            hdr_out->grid[2] = hdr.grid[2];
+            hdr_out->verdict = 0;
+            hdr_out->points = hdr.points;
+            hdr_out->pw = hdr.pw;
+        }
+    }
+    __shared__ uint32_t wsum[16], wslab[16];
+    __shared__ uint32_t s_nsplit, s_nitems;
+    __shared__ uint32_t bcount[33], bstart[33];
+    if (threadIdx.x == 0) s_nsplit = 0;
+    if (threadIdx.x < 33) bcount[threadIdx.x] = 0;
+    __syncthreads();
+    const int per = (NT + 1023) / 1024;
+    const int i0 = threadIdx.x * per;
+    // parts of a heavy tile are ranges of its descriptors (a run is never cut)
+    auto parts_of = [&](uint32_t c, uint32_t nd) {
+        uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
+        if (k > nd && nd > 0) k = nd;
+        return k ? k : 1u;
+    };
+    uint32_t s = 0, slabs = 0;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
+        s += nd;
+        const uint32_t k = parts_of(c, nd);
+        const uint32_t sz = (c + k - 1) / k;  // records per part (estimate)
+        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
+        if (k > 1) slabs += k;
+    }
+    uint32_t incl = s, incl_slab = slabs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64), v2 = __shfl_up(incl_slab, o, 64);
+        if ((threadIdx.x & 63) >= o) {
+            incl += v;
+            incl_slab += v2;
+        }
+    }
+    if ((threadIdx.x & 63) == 63) {
+        wsum[threadIdx.x >> 6] = incl;
+        wslab[threadIdx.x >> 6] = incl_slab;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t start = 0;
+        for (int k = 32; k >= 0; --k) {
+            bstart[k] = start;
+            start += bcount[k];
+        }
+        s_nitems = start < (uint32_t)max_items ? start : (uint32_t)max_items;
+        *n_items = s_nitems;
+    }
+    uint32_t wbase = 0, sbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
+        wbase += wsum[w];
+        sbase += wslab[w];
+    }
+    __syncthreads();
+    uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
+        tile_dstart[i] = run;
+        tile_cursor[i] = 0;
+        const uint32_t k = parts_of(c, nd);
+        const uint32_t sz = (c + k - 1) / k;
+        const uint32_t dsz = (nd + k - 1) / k;  // descriptors per part
+        const int bucket = sz ? 32 - __clz(sz) : 0;
+        tile_parts[i] = k;
+        tile_slab[i] = slab_run;
+        for (uint32_t part = 0; part < k; ++part) {
+            WorkItem it;
+            it.tile = (uint32_t)i;
+            it.begin = run + part * dsz;
+            it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
+            if (it.begin > run + nd) it.begin = run + nd;
+            it.part_nparts = part | (k << 16);
+            const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
+            if (pos < (uint32_t)max_items) items[pos] = it;
+        }
+        if (k > 1) {
+            slab_run += k;
+            split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
+        }
+        run += nd;
+    }
+    if (threadIdx.x == 1023) tile_dstart[NT] = wbase + incl;
+    __syncthreads();
+    if (threadIdx.x == 0) *n_split = s_nsplit;
+}
+
+// local binning: K3 -- descriptors into tile order (any order inside a tile)
+__global__ __launch_bounds__(256) void k_place_desc(const RunDesc* __restrict__ desc,
+                                                    const uint32_t* __restrict__ n_desc,
+                                                    const uint32_t* __restrict__ tile_dstart,
+                                                    uint32_t* __restrict__ tile_cursor,
+                                                    RunDesc* __restrict__ sorted) {
+    const uint32_t n = *n_desc;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const RunDesc d = desc[i];
+        sorted[tile_dstart[d.tile()] + atomicAdd(&tile_cursor[d.tile()], 1u)] = d;
+    }
+}
+
 // ------------------------------------------------------------------ forward K4
 template <typename T, int NI, int NO, bool HAS_PW, bool W3>
 __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
@@ -821,6 +1203,183 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
                     atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
                 }
             }
+        }
+    }
+    lds_barrier();  // LDS phases only: prefetched records stay in flight
+    if ((item.part_nparts >> 16) > 1) {
+        // part of a split tile: the whole LDS tile goes to this part's overflow slab;
+        // k_halo_gather sums the parts
+        T* slab = ovf + (size_t)(tile_slab[item.tile] + (item.part_nparts & 0xffffu)) * NVH;
+        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)acc[i];
+        return;
+    }
+    // Flush, one LDS row (TX + 1 cells along x) at a time: the row's y/z coordinates, bounds
+    // and base offsets are computed once per row, a lane only adds its x.  Owned rows leave
+    // as out = background + acc (plain stores of TX contiguous values); the rows of the upper
+    // y / z halo and the x == TX column go to the compact per-tile halo buffer (always fully
+    // written, zeros included).
+    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+    constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
+    constexpr int ROWS = NVH / (TX + 1);   // (TY + 1) [* (TZ + 1)]
+    constexpr int RPW = kWave / TX;        // rows per wave pass (1 for TX = 64, 2 for TX = 32)
+    static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
+    const double bgv = bg ? (double)bg[b] : 0.0;
+    T* o = out + b * gd.G;
+    T* hb = halo + (size_t)item.tile * halo_count<NO>();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int x = lane % TX;
+    const bool x_ok = x0[0] + x < gd.n[0];
+    for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += (kSplatThreads / kWave) * RPW) {
+        int row = row0 + lane / TX;
+        if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+        if (row >= ROWS) continue;
+        const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+        const double a = acc[row * (TX + 1) + x];
+        const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
+        if (owned) {
+            const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+            const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+            if (in && x_ok)
+                __builtin_nontemporal_store(
+                    (T)(bgv + a),
+                    &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
+        } else {
+            int h[NO];
+            h[0] = x;
+            h[1] = l1;
+            if (NO == 3) h[NO - 1] = l2;
+            hb[halo_index<NO>(h)] = (T)a;
+        }
+    }
+    // x == TX column: the X-face of the halo buffer is indexed by the row number
+    for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
+        hb[row] = (T)acc[row * (TX + 1) + TX];
+}
+
+// ------------------------------------------------------------------ forward K4, local binning
+// (k_tile_splat with the record loop walking run descriptors; instantiated with RUNS = true)
+template <typename T, int NI, int NO, bool HAS_PW, bool W3, bool RUNS>
+__global__ __launch_bounds__(kSplatThreads, 8) void k_tile_splat_runs(  // 8 waves / SIMD = 2 blocks / CU
+    GridDesc<NO> gd, TileGeom<NO> tg, const RecT<T, W3>* __restrict__ rec,
+    const RunDesc* __restrict__ runs, uint32_t max_rec,
+    const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
+    const uint32_t* __restrict__ tile_slab, const T* __restrict__ rot,
+    const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
+    T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
+    constexpr int NVH = tile_voxels_halo<NO>();
+    __shared__ double acc[NVH];
+    // Everything the block needs from memory before it can touch its records is requested at
+    // once -- the item, the item count (the list is allocated for the whole grid, so reading
+    // past the count is safe) and the pose of the group's first image -- instead of one after
+    // the other (count -> item -> pose were three dependent round trips of 1-2 us each on a
+    // busy chip).  Only a pose group's later images need a second pose fetch.
+    const uint32_t n_it = *n_items;
+    const WorkItem item = items[blockIdx.x];
+    Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
+    for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
+    if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
+    // item.tile = (pose within the group) * NT + tile
+    const int tile = (int)(item.tile % (uint32_t)tg.NT);
+    const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
+    int x0[NO], tc[NO];
+    tile_origin<NO>(tile, tg, x0, tc);
+    if (b != b0) ps = load_pose<T, NI, NO>(rot, trans, ow, b);
+#ifndef DPR_PF
+#define DPR_PF 2
+#endif
+    constexpr int kPF = DPR_PF;
+    {
+        // LOCAL BINNING: the item is a range of run descriptors; the records of a run are
+        // contiguous.  Each thread takes a contiguous share of the item's records (as in the
+        // blocked assignment below: neighbouring records of a coherent cloud hit the same
+        // voxels) and walks it through the run table with a forward-only cursor.
+        __shared__ RunTable<kMaxRuns> rt;
+        for (uint32_t d0 = item.begin; d0 < item.end; d0 += kMaxRuns) {
+            const uint32_t d1 = (d0 + kMaxRuns < item.end) ? d0 + kMaxRuns : item.end;
+            const int nruns = (int)(d1 - d0);
+            const uint32_t n = load_runs(rt, runs, d0, d1, max_rec);  // barrier inside
+            const uint32_t per = (n + kSplatThreads - 1) / kSplatThreads;
+            uint32_t i = threadIdx.x * per;
+            const uint32_t i1 = (i + per < n) ? i + per : n;
+            if (i < i1) {
+                RunCursor cu;
+                cu.seek(rt, i, nruns);
+                uint32_t fetched = i;  // logical index of the next record to request
+                RecT<T, W3> nxt[kPF];
+#pragma unroll
+                for (int u = 0; u < kPF; ++u) {
+                    // past the end the last record is requested again (branch-free loop body)
+                    const bool adv = fetched + 1 < i1;
+                    nxt[u] = rec[cu.next(rt, adv ? 1u : 0u, nruns, adv)];
+                    fetched += adv ? 1u : 0u;
+                }
+                while (i < i1) {
+                    RecT<T, W3> cur[kPF];
+#pragma unroll
+                    for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
+                    const uint32_t i_cur = i;
+                    i += kPF;
+#pragma unroll
+                    for (int u = 0; u < kPF; ++u) {
+                        const bool adv = fetched + 1 < i1;
+                        nxt[u] = rec[cu.next(rt, adv ? 1u : 0u, nruns, adv)];
+                        fetched += adv ? 1u : 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kPF; ++u) {
+                        const RecT<T, W3> rc = cur[u];
+                        const bool active = i_cur + u < i1;
+                    T pt[NI];
+            #pragma unroll
+                    for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
+                    const T w = HAS_PW ? ps.ow * rc.v[HAS_PW ? 3 : 0] : ps.ow * T(1);  // src/raster.jl:52
+                    int ref0[NO];
+                    T dlo[NO];
+                    ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
+                    // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
+                    // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
+                    // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
+                    int lb[NO];
+                    bool low_ok[NO];
+            #pragma unroll
+                    for (int d = 0; d < NO; ++d) {
+                        lb[d] = ref0[d] - x0[d];
+                        // records of this tile have lb in [-1, T-1]; the clamp only matters if the
+                        // caller breaks the REUSE_BINNING contract (stale workspace): LDS indices
+                        // stay legal
+                        lb[d] = lb[d] < -1 ? -1
+                                           : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
+                        low_ok[d] = lb[d] >= 0;
+                    }
+                    bool interior = true;
+            #pragma unroll
+                    for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+                    if (active && interior) {
+                        // common case: one base address, the 2^N neighbours are compile-time offsets
+                        // (they fold into the ds_add offset field)
+                        double* base = &acc[lds_index<NO>(lb)];
+            #pragma unroll
+                        for (int s = 0; s < (1 << NO); ++s)
+                            atomicAdd(base + nbr_lds_offset<NO>(s), (double)voxel_weight<T, NO>(dlo, s, w));
+                    } else if (active) {  // a lower neighbour at -1: only at the low faces of the grid
+            #pragma unroll
+                        for (int s = 0; s < (1 << NO); ++s) {
+                            int l[NO];
+                            bool ok = true;
+            #pragma unroll
+                            for (int d = 0; d < NO; ++d) {
+                                const int sd = (s >> d) & 1;
+                                ok = ok && (sd || low_ok[d]);
+                                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+                            }
+                            const T v = voxel_weight<T, NO>(dlo, s, w);
+                            atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
+                        }
+                    }
+                    }
+                }
+            }
+            __syncthreads();  // the table is rebuilt by the next round
         }
     }
     lds_barrier();  // LDS phases only: prefetched records stay in flight
@@ -1323,6 +1882,294 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     }
 }
 
+// ------------------------------------------------------------------ pullback K4, local binning
+// (k_tile_gather with the record loop walking run descriptors; instantiated with RUNS = true)
+// UNPERM: the per-point gradient {d point, d point_weight} overwrites the point's record in
+// place (coalesced 16/32-byte stores in binned order); k_unpermute then brings it back to the
+// original order with one random read per point.  !UNPERM: the owner thread stores straight
+// to ds_dpoints[idx] / ds_dpoint_weight[idx] (good when the input order is spatially coherent).
+template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM, bool RUNS>
+__global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
+    GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, const RunDesc* __restrict__ runs, int64_t P,
+    const uint32_t* __restrict__ rec_idx, const WorkItem* __restrict__ items,
+    const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
+    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b0,
+    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials,
+    Residual<T> rs, BinHeader want, BinHeader* hdr) {
+    constexpr int NVH = tile_voxels_halo<NO>();
+    constexpr int NVAL = NO * NI + NO + 3;  // dR | dt | d out_weight | d background | loss
+    constexpr int NW = kGatherThreads / kWave;
+    __shared__ T tile_g[NVH];
+    __shared__ double red[NW][NVAL];
+    if (want.magic) {
+        // DPR_FLAG_REUSE_BINNING: trust the lists in the workspace only if a KEEP_BINNING forward
+        // with the same problem, buffers and pose wrote them and nobody has consumed them since
+        const bool ok = header_matches(hdr, want, (const uint32_t*)(rot + b0 * (NO * NI)),
+                                       NO * NI * (int)(sizeof(T) / 4),
+                                       (const uint32_t*)(trans + b0 * NO), NO * (int)(sizeof(T) / 4));
+        if (blockIdx.x == 0 && threadIdx.x == 0) hdr->verdict = ok ? 1u : 0u;
+        if (!ok) return;  // k_unpermute / k_pose_reduce turn the verdict into NaN outputs
+    }
+    // item, item count and the first image's pose are requested together (see k_tile_splat)
+    const uint32_t n_it = *n_items;
+    WorkItem item = items[blockIdx.x];
+    Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
+    if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
+    // record ranges never leave the record buffer, whatever the lists say (RUNS: load_runs)
+    if (!RUNS && item.end > (uint32_t)P) item.end = (uint32_t)P;
+    if (item.begin > item.end) item.begin = item.end;
+    const int tile = (int)(item.tile % (uint32_t)tg.NT);
+    const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
+    int x0[NO], tc[NO];
+    tile_origin<NO>(tile, tg, x0, tc);
+    const T* gb = g + b * gd.G;
+    const T* tb = rs.target ? rs.target + b * gd.G : nullptr;
+    // RUNS (local binning): the item is a range of run descriptors (see k_tile_splat); the first
+    // round's table is built here so that the first record is in flight during the staging.
+    __shared__ RunTable<RUNS ? kMaxRunsGather : 1> rt;
+    uint32_t d0 = RUNS ? item.begin : 0u, n_round = 0;
+    int nruns = 0;
+    RunCursor cu{0, 0, 0};
+    if constexpr (RUNS) {
+        const uint32_t d1 = (d0 + kMaxRunsGather < item.end) ? d0 + kMaxRunsGather : item.end;
+        nruns = (int)(d1 - d0);
+        n_round = load_runs(rt, runs, d0, d1, (uint32_t)P);
+    }
+    // threads stride over the records (RUNS: over the round's logical records, mapped through
+    // the run table by a forward-only cursor)
+    const uint32_t r1 = RUNS ? n_round : item.end;
+    uint32_t r = (RUNS ? 0u : item.begin) + threadIdx.x;
+    Rec4<T> nxt;
+    uint32_t nxt_idx = 0, nxt_phys = 0;
+    if (r < r1) {
+        if constexpr (RUNS) {
+            cu.seek(rt, r, nruns);
+            nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1);
+        } else {
+            nxt_phys = r;
+        }
+        nxt = rec[nxt_phys];
+        if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
+    }
+    if (UNPERM && blockIdx.x == 0 && threadIdx.x == 0) {
+        Rec4<T> z;
+        z.v[0] = z.v[1] = z.v[2] = z.v[3] = T(0);
+        rec[P] = z;  // spare slot: the gradient of every rejected point
+    }
+    // Stage the ds_dout tile + upper halo in LDS, one row (TX + 1 cells along x) at a time: the
+    // row's y / z coordinates, bounds and base offset are computed once per row, a lane only
+    // adds its x; kRB rows are in flight per wave.  Cells beyond the grid are staged as 0.
+    // Owned voxels are summed for ds_dbackground (residual mode: ds_dout = scale * (out -
+    // target) formed here, squared residuals summed for the loss).
+    double bg_sum = 0.0, sq_sum = 0.0;
+    {
+        constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+        constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
+        constexpr int ROWS = NVH / (TX + 1);
+        constexpr int RPW = kWave / TX;  // rows per wave pass (1 for TX = 64, 2 for TX = 32)
+        constexpr int kRB = 8;           // row passes in flight
+        static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
+        const bool first_part = (item.part_nparts & 0xffffu) == 0;
+        const int lane = threadIdx.x & (kWave - 1);
+        const int x = lane % TX;
+        const bool x_ok = x0[0] + x < gd.n[0];
+        constexpr int STEP = (kGatherThreads / kWave) * RPW;
+        // an unsplit tile's ds_dout cells are read by this block only (plus the neighbours' halo
+        // rows): streamed with non-temporal loads; the parts of a split tile re-read them
+        auto stage_rows = [&](auto nt_tag) {
+        constexpr bool NT = decltype(nt_tag)::value;
+        for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += STEP * kRB) {
+            T v[kRB], tv[kRB];
+            bool in[kRB], owned[kRB];
+            int lrow[kRB];
+#pragma unroll
+            for (int k = 0; k < kRB; ++k) {
+                int row = row0 + k * STEP + lane / TX;
+                if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+                const bool live = row < ROWS;
+                const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+                const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+                in[k] = live && x_ok && g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+                owned[k] = in[k] && l1 < TY && (NO == 2 || l2 < TZ);
+                lrow[k] = live ? row * (TX + 1) + x : -1;
+                const size_t off =
+                    ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x;
+                const size_t oc = in[k] ? off : 0;
+                v[k] = NT ? __builtin_nontemporal_load(&gb[oc]) : gb[oc];
+                tv[k] = tb ? (NT ? __builtin_nontemporal_load(&tb[oc]) : tb[oc]) : T(0);
+            }
+#pragma unroll
+            for (int k = 0; k < kRB; ++k) {
+                T val = in[k] ? v[k] : T(0);
+                if (tb) {
+                    const T d = val - (in[k] ? tv[k] : T(0));
+                    if (owned[k] && first_part) sq_sum += (double)d * (double)d;
+                    val = rs.scale * d;
+                }
+                if (lrow[k] >= 0) tile_g[lrow[k]] = val;
+                if (owned[k] && first_part) bg_sum += (double)val;
+            }
+        }
+        };
+        if ((item.part_nparts >> 16) > 1) stage_rows(std::false_type{});
+        else stage_rows(std::true_type{});
+        // the x == TX column (halo cells only): one cell per row
+        for (int row = threadIdx.x; row < ROWS; row += kGatherThreads) {
+            const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+            const int g0 = x0[0] + TX, g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+            const bool in = g0 < gd.n[0] && g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+            const size_t off = ((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + g0;
+            T val = in ? gb[off] : T(0);
+            if (tb) val = in ? rs.scale * (val - tb[off]) : T(0);
+            tile_g[row * (TX + 1) + TX] = val;
+        }
+    }
+    if (b != b0) ps = load_pose<T, NI, NO>(rot, trans, ow, b);  // later image of a pose group
+    lds_barrier();  // LDS phases only: prefetched records stay in flight
+    // per-thread sums of the per-pose scalars: T within the thread (few records each),
+    // f64 across threads / tiles
+    T vals[NVAL - 2];
+#pragma unroll
+    for (int k = 0; k < NVAL - 2; ++k) vals[k] = T(0);
+    {
+        uint32_t r1r = r1;
+        for (;;) {
+            while (r < r1r) {
+                const Rec4<T> rc = nxt;
+                const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
+                const uint32_t rcur = nxt_phys;
+                r += kGatherThreads;
+                if (r < r1r) {
+                    nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1r);
+                    nxt = rec[nxt_phys];
+                    if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
+                }
+                T pt[NI];
+        #pragma unroll
+                for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
+                const T pwi = HAS_PW ? rc.v[3] : T(1);
+                int ref0[NO];
+                T dlo[NO];
+                ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+                // Branch-free neighbour loop: cells beyond the grid were staged as 0 (they add
+                // nothing, which equals dropping them, src/raster_pullback.jl:51); a lower neighbour
+                // at -1 reads cell 0 and is zeroed.
+                int lb[NO];
+                bool low_ok[NO];
+        #pragma unroll
+                for (int d = 0; d < NO; ++d) {
+                    lb[d] = ref0[d] - x0[d];
+                    // records of this tile have lb in [-1, T-1]; the clamp only matters if the caller
+                    // breaks the REUSE_BINNING contract (stale workspace) and keeps LDS indices legal
+                    lb[d] = lb[d] < -1 ? -1 : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
+                    low_ok[d] = lb[d] >= 0;
+                }
+                T gv[1 << NO];
+                bool interior = true;
+        #pragma unroll
+                for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+                if (interior) {
+                    // common case: one base address, neighbours at compile-time offsets
+                    const T* base = &tile_g[lds_index<NO>(lb)];
+        #pragma unroll
+                    for (int s = 0; s < (1 << NO); ++s) gv[s] = base[nbr_lds_offset<NO>(s)];
+                } else {
+        #pragma unroll
+                    for (int s = 0; s < (1 << NO); ++s) {
+                        int l[NO];
+                        bool ok = true;
+        #pragma unroll
+                        for (int d = 0; d < NO; ++d) {
+                            const int sd = (s >> d) & 1;
+                            ok = ok && (sd || low_ok[d]);
+                            l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+                        }
+                        const T gi = tile_g[lds_index<NO>(l)];
+                        gv[s] = ok ? gi : T(0);
+                    }
+                }
+                T scaled[NO], dow_part = T(0), dpw_part = T(0);
+                {
+                    T dcoord[NO];
+        #pragma unroll
+                    for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
+        #pragma unroll
+                    for (int s = 0; s < (1 << NO); ++s) {
+                        const T gi = gv[s];
+                        const T dweight = voxel_weight<T, NO>(dlo, s, gi);  // :55
+                        dow_part += dweight * pwi;                          // :57
+                        dpw_part += dweight * ps.ow;                        // :58
+                        const T factor = gi * ps.ow * pwi;                  // :60
+        #pragma unroll
+                        for (int n = 0; n < NO; ++n) dcoord[n] += factor * interp_weight<T, NO>(n, dlo, s);
+                    }
+        #pragma unroll
+                    for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));  // :67
+                }
+        #pragma unroll
+                for (int n = 0; n < NO; ++n) {
+        #pragma unroll
+                    for (int j = 0; j < NI; ++j) vals[n + j * NO] += scaled[n] * pt[j];  // :69
+                    vals[NO * NI + n] += scaled[n];                                     // :68
+                }
+                vals[NO * NI + NO] += dow_part;
+                T dp[NI];
+        #pragma unroll
+                for (int j = 0; j < NI; ++j) {  // rotation' * scaled (:70)
+                    T v = ps.R[0 + j * NO] * scaled[0];
+        #pragma unroll
+                    for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
+                    dp[j] = v;
+                }
+                if (UNPERM) {
+                    Rec4<T> gr;
+        #pragma unroll
+                    for (int j = 0; j < 3; ++j) gr.v[j] = (j < NI) ? dp[(j < NI) ? j : 0] : T(0);
+                    gr.v[3] = dpw_part;
+                    rec[rcur] = gr;
+                } else if (FIRST_POSE) {  // this thread is the only writer of point p for this pose
+        #pragma unroll
+                    for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] = dp[j];
+                    ds_dpw[p] = dpw_part;
+                } else {
+        #pragma unroll
+                    for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] += dp[j];
+                    ds_dpw[p] += dpw_part;
+                }
+            }
+            d0 += kMaxRunsGather;
+            if (d0 >= item.end) break;  // uniform
+            __syncthreads();  // next round of descriptors: rebuild the table
+            const uint32_t d1 = (d0 + kMaxRunsGather < item.end) ? d0 + kMaxRunsGather : item.end;
+            nruns = (int)(d1 - d0);
+            r1r = load_runs(rt, runs, d0, d1, (uint32_t)P);
+            r = threadIdx.x;
+            if (r < r1r) {
+                cu.seek(rt, r, nruns);
+                nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1r);
+                nxt = rec[nxt_phys];
+                if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
+            }
+        }
+    }
+    // per-tile partial sums of the per-pose scalars (f64), reduced later by k_pose_reduce
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < NVAL; ++k) {
+        const double v = (k < NVAL - 2) ? (double)vals[k < NVAL - 2 ? k : 0]
+                                        : (k == NVAL - 2 ? bg_sum : sq_sum);
+        const double s = wave_sum<double>(v);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < (rs.target ? NVAL : NVAL - 1)) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
+        partials[(size_t)threadIdx.x * max_items + blockIdx.x] = s;
+    }
+}
+
 // ------------------------------------------------------------------ pullback un-permute
 // thread per ORIGINAL point: gradient record(s) of its slot(s) -> ds_dpoints /
 // ds_dpoint_weight (coalesced stores; accumulating over poses when !FIRST_POSE).  A pose
@@ -1477,6 +2324,12 @@ struct Plan {
     int max_slabs;   // overflow slabs (parts of split tiles)
     size_t off_hdr, off_counts, off_totals, off_tile_start, off_items, off_nitems, off_tparts, off_tslab,
         off_split, off_rec, off_idx, off_slot, off_aux, total;
+    // local binning (DPR_FLAG_COHERENT_POINTS, NT <= 4096)
+    bool local;
+    int sub;               // points per sub-chunk
+    int64_t nsub;          // sub-chunks = blocks of k_bin_local
+    int64_t max_desc;      // descriptors: worst case min(P, nsub * min(sub, NT))
+    size_t off_ltot, off_dstart, off_dcursor, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | n_desc
 };
 
 // Pose groups: with few tiles per pose (2-D projections, small 3-D grids) the bins become
@@ -1499,8 +2352,13 @@ static int pose_group(int NT, int64_t P, int64_t B, int max_group) {
     return bg;
 }
 
-static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group) {
+static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group,
+                      bool coherent = false) {
     Plan pl;
+    // (the direct-store pullback mode, an experiment knob, needs the index array only the plain
+    // scatter writes)
+    pl.local = coherent && NT1 <= 4096 && knobs().bwd_unpermute;
+    if (pl.local) max_group = 1;  // local binning is per pose
     pl.bg = pose_group(NT1, P1, B, max_group);
     const int NT = NT1 * pl.bg;          // bins
     const int64_t P = P1 * pl.bg;        // records
@@ -1547,12 +2405,34 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     o += align_up((size_t)NT * 4);
     pl.off_split = o;  // [0] = n_split, [1..] = split tile ids (at most max_slabs / 2)
     o += align_up((size_t)(pl.max_slabs / 2 + 2) * 4);
+    pl.sub = elem == 4 ? 4096 : 2048;
+    pl.nsub = (P1 + pl.sub - 1) / pl.sub;
+    if (pl.nsub < 1) pl.nsub = 1;
+    pl.max_desc = 0;
+    int64_t nrec = P;  // records (+ spare slot for rejected points)
+    if (pl.local) {
+        const int64_t per = pl.sub < NT1 ? pl.sub : NT1;
+        pl.max_desc = pl.nsub * per < P1 ? pl.nsub * per : P1;
+        if (pl.max_desc < 1) pl.max_desc = 1;
+        nrec = pl.nsub * pl.sub;  // every sub-chunk owns a slab of `sub` records
+        pl.off_ltot = o;
+        o += align_up((size_t)(2 * NT1 + 1) * 4);
+        pl.off_dstart = o;
+        o += align_up((size_t)(NT1 + 1) * 4);
+        pl.off_dcursor = o;
+        o += align_up((size_t)NT1 * 4);
+        pl.off_desc = o;
+        o += align_up((size_t)pl.max_desc * sizeof(RunDesc));
+        pl.off_sdesc = o;
+        o += align_up((size_t)pl.max_desc * sizeof(RunDesc));
+    }
     pl.off_rec = o;
-    o += align_up((size_t)(P + 1) * 4 * elem);  // + spare slot for rejected points
+    o += align_up((size_t)(nrec + 1) * 4 * elem);  // + spare slot for rejected points
     pl.off_idx = o;
     o += align_up((size_t)(P1 + 1) * 4);
     pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
+    (void)nrec;
     pl.off_aux = o;
     // aux: forward = halo buffer | overflow slabs ; pullback = per-item partials
     const size_t nvh = (n_out == 3) ? tile_voxels_halo<3>() : tile_voxels_halo<2>();
@@ -1613,7 +2493,8 @@ size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int 
         if (!make_geom<2>(grid, &tg)) return (size_t)-1;
         NT = tg.NT;
     }
-    return make_plan(elem, n_out, NT, P, B, (int)((flags >> 8) & 0xffu)).total;
+    return make_plan(elem, n_out, NT, P, B, (int)((flags >> 8) & 0xffu),
+                     (flags & DPR_FLAG_COHERENT_POINTS) != 0).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -1752,6 +2633,54 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     return rc;
 }
 
+// Local binning for one pose (DPR_FLAG_COHERENT_POINTS): clear the tile totals, k_bin_local,
+// k_runscan, k_place_desc.  Same stage marks as bin_points (count | scan | scatter become
+// clear | bin_local | runscan + place).
+template <typename T, int NI, int NO>
+static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
+                            const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
+                            const T* rot, const T* trans, int64_t b, bool want_idx, T* d_pts,
+                            T* d_pw, int zero_dropped, bool keep_valid) {
+    uint32_t* ltot = (uint32_t*)(ws + pl.off_ltot);  // ndesc[NT] | npts[NT] | n_desc
+    DPR_HIP(hipMemsetAsync(ltot, 0, (size_t)(2 * tg.NT + 1) * 4, st));
+    stage_mark(st);
+    const uint32_t spare = (uint32_t)(pl.nsub * pl.sub);
+    const size_t lds = (size_t)tg.NT * 4;
+    uint32_t* slot = want_idx ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr;
+#define DPR_LAUNCH_LOCAL(HAS_PW, W3)                                                              \
+    hipLaunchKernelGGL((k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3>),     \
+                       dim3((unsigned)pl.nsub), dim3(kBinThreads), lds, st, gd, tg, P, points,   \
+                       pw, rot, trans, b, (RecT<T, W3>*)(ws + pl.off_rec), slot,                 \
+                       (RunDesc*)(ws + pl.off_desc), ltot + 2 * tg.NT, ltot, ltot + tg.NT,       \
+                       spare, d_pts, d_pw, zero_dropped)
+    if (pw) DPR_LAUNCH_LOCAL(true, false);
+    else if (!want_idx && knobs().compact_records) DPR_LAUNCH_LOCAL(false, true);
+    else DPR_LAUNCH_LOCAL(false, false);
+#undef DPR_LAUNCH_LOCAL
+    stage_mark(st);
+    int64_t grid64[3] = {1, 1, 1};
+    for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
+    BinHeader hdr = make_header<T, NI, NO>(grid64, P, points, pw);
+    hdr.state = keep_valid ? kBinValid : 0u;
+    hipLaunchKernelGGL(k_runscan, dim3(1), dim3(1024), 0, st, (const uint32_t*)ltot,
+                       (const uint32_t*)(ltot + tg.NT), tg.NT, pl.cap,
+                       (uint32_t*)(ws + pl.off_dstart), (uint32_t*)(ws + pl.off_dcursor),
+                       (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
+                       (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
+                       (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split),
+                       pl.max_items, hdr, (BinHeader*)(ws + pl.off_hdr),
+                       (const uint32_t*)(rot + b * (NO * NI)), (int)(NO * NI * sizeof(T) / 4),
+                       (const uint32_t*)(trans + b * NO), (int)(NO * sizeof(T) / 4));
+    int64_t pblocks = (pl.max_desc + 255) / 256;
+    if (pblocks > 2048) pblocks = 2048;
+    hipLaunchKernelGGL(k_place_desc, dim3((unsigned)pblocks), dim3(256), 0, st,
+                       (const RunDesc*)(ws + pl.off_desc), (const uint32_t*)(ltot + 2 * tg.NT),
+                       (const uint32_t*)(ws + pl.off_dstart), (uint32_t*)(ws + pl.off_dcursor),
+                       (RunDesc*)(ws + pl.off_sdesc));
+    stage_mark(st);
+    return DPR_OK;
+}
+
 template <int NO> static GridDesc<NO> make_grid_desc(const int64_t* grid, int64_t G) {
     GridDesc<NO> gd;
     for (int d = 0; d < NO; ++d) gd.n[d] = (int)grid[d];
@@ -1773,7 +2702,8 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     if (keep && B != 1)
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
                     (long long)B);
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu));
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
@@ -1785,21 +2715,39 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     const int blocked = knobs().splat_blocked;
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
-        if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
-                                           (int)nb, keep, (T*)nullptr, (T*)nullptr, 0, keep))
+        if (pl.local) {
+            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans,
+                                                     b, keep, (T*)nullptr, (T*)nullptr, 0, keep))
+                return rc;
+        } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
+                                                  (int)nb, keep, (T*)nullptr, (T*)nullptr, 0, keep))
             return rc;
-#define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
-    hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
+#define DPR_LAUNCH_SPLAT_RUNS(HAS_PW, W3)                                                        \
+    hipLaunchKernelGGL((k_tile_splat_runs<T, NI, NO, HAS_PW, W3, true>), dim3(pl.max_items),    \
                        dim3(kSplatThreads), 0, st, gd, tg,                                      \
-                       (const RecT<T, W3>*)(ws + pl.off_rec),              \
+                       (const RecT<T, W3>*)(ws + pl.off_rec),                                   \
+                       (const RunDesc*)(ws + pl.off_sdesc), (uint32_t)(pl.nsub * pl.sub),       \
                        (const WorkItem*)(ws + pl.off_items),                                    \
                        (const uint32_t*)(ws + pl.off_nitems),                                   \
                        (const uint32_t*)(ws + pl.off_tslab), rot, trans, ow, bg, b, out, halo,  \
                        ovf, blocked)
-        if (pw) DPR_LAUNCH_SPLAT(true, false);
+#define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
+    hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
+                       dim3(kSplatThreads), 0, st, gd, tg,                                      \
+                       (const RecT<T, W3>*)(ws + pl.off_rec),                                   \
+                       (const WorkItem*)(ws + pl.off_items),                                    \
+                       (const uint32_t*)(ws + pl.off_nitems),                                   \
+                       (const uint32_t*)(ws + pl.off_tslab), rot, trans, ow, bg, b, out, halo,  \
+                       ovf, blocked)
+        if (pl.local) {
+            if (pw) DPR_LAUNCH_SPLAT_RUNS(true, false);
+            else if (!keep && knobs().compact_records) DPR_LAUNCH_SPLAT_RUNS(false, true);
+            else DPR_LAUNCH_SPLAT_RUNS(false, false);
+        } else if (pw) DPR_LAUNCH_SPLAT(true, false);
         else if (records_are_compact(tg.NT, (int)nb, false, keep)) DPR_LAUNCH_SPLAT(false, true);
         else DPR_LAUNCH_SPLAT(false, false);
 #undef DPR_LAUNCH_SPLAT
+#undef DPR_LAUNCH_SPLAT_RUNS
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>),
                            dim3(tg.NT * (int)nb + (pl.max_slabs / 2) * kSplitBlocks),
@@ -1829,7 +2777,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     if (reuse && B != 1)
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
                     (long long)B);
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu));
+    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -1858,16 +2807,34 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             stage_mark(st);
             stage_mark(st);
             stage_mark(st);
+        } else if (pl.local) {
+            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans,
+                                                     b, true, d_pts, d_pw,
+                                                     (b == 0 && !unperm) ? 1 : 0, false))
+                return rc;
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
                                                   (int)nb, true, d_pts, d_pw,
                                                   (b == 0 && !unperm) ? 1 : 0))
             return rc;
-#define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                                                   \
-    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(pl.max_items),             \
+#define DPR_LAUNCH_GATHER_RUNS(HAS_PW, FIRST, UNP)                                               \
+    hipLaunchKernelGGL((k_tile_gather_runs<T, NI, NO, HAS_PW, FIRST, UNP, true>),                \
+                       dim3(pl.max_items), dim3(kGatherThreads), 0, st, gd, tg,                  \
+                       (Rec4<T>*)(ws + pl.off_rec), (const RunDesc*)(ws + pl.off_sdesc),         \
+                       pl.nsub * pl.sub, (const uint32_t*)(ws + pl.off_idx),                     \
+                       (const WorkItem*)(ws + pl.off_items),                                     \
+                       (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,   \
+                       b, d_pts, d_pw, partials, rs, want, hdr)
+#define DPR_LAUNCH_GATHER_PLAIN(HAS_PW, FIRST, UNP)                                              \
+    hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(pl.max_items),       \
                        dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P * nb, \
                        (const uint32_t*)(ws + pl.off_idx), (const WorkItem*)(ws + pl.off_items), \
-                       (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,  \
+                       (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,   \
                        b, d_pts, d_pw, partials, rs, want, hdr)
+#define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                       \
+    do {                                                            \
+        if (pl.local) DPR_LAUNCH_GATHER_RUNS(HAS_PW, FIRST, UNP);   \
+        else DPR_LAUNCH_GATHER_PLAIN(HAS_PW, FIRST, UNP);           \
+    } while (0)
         if (unperm) {
             if (pw) DPR_LAUNCH_GATHER(true, true, true);
             else DPR_LAUNCH_GATHER(false, true, true);
@@ -1900,6 +2867,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             stage_mark(st);
         }
 #undef DPR_LAUNCH_GATHER
+#undef DPR_LAUNCH_GATHER_RUNS
+#undef DPR_LAUNCH_GATHER_PLAIN
         stage_mark(st);
         hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>),
                            dim3(rs.target ? NVAL + 1 : NVAL, (unsigned)nb), dim3(1024), 0, st,

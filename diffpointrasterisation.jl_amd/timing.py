@@ -15,6 +15,9 @@ STAGES = {
     ("raster", "chunked"): ["boxes", "lists", "chunk_splat", "divert"],
     ("pullback", "chunked"): ["boxes", "lists", "chunk_gather", "pose_reduce", "divert"],
     ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "unpermute", "pose_reduce"],
+    # DPR_ALGO_TILED with coherent_points=True (local binning): pass algo="tiled_local"
+    ("raster", "tiled_local"): ["clear", "bin_local", "runscan", "tile_splat", "halo"],
+    ("pullback", "tiled_local"): ["clear", "bin_local", "runscan", "tile_gather", "unpermute", "pose_reduce"],
     # DPR_ALGO_CHUNKED on 2-D grids (chunk-owned tiles): pass algo="chunked2d"
     ("raster", "chunked2d"): ["sort", "fill", "chunk_splat"],
     ("pullback", "chunked2d"): ["sort", "grid_sum", "chunk_gather", "reduce+unsort"],

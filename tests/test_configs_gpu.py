@@ -163,6 +163,62 @@ def test_chunk_owner_keeps_the_sorted_cloud_for_the_pullback(oracle, dev, npdt, 
     assert_close(pb2.rotation, ref_pb.rotation, tol(npdt, "pose"), "coherent ds_drotation")
 
 
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+@pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 70), (3, 2, 150), (2, 2, 100)])
+@pytest.mark.parametrize("order", ["sorted", "as generated"])
+@pytest.mark.parametrize("with_pw", [False, True])
+def test_local_binning_of_coherent_points(oracle, dev, npdt, tdt, n_in, n_out, grid_n, order, with_pw):
+    """DPR_ALGO_TILED + DPR_FLAG_COHERENT_POINTS: sub-chunks are ordered by tile locally and the
+    tile kernels walk run descriptors (no count pass, no global permutation).  Fast for sorted
+    clouds, but the result must be right for ANY order (here also the generated, incoherent one),
+    with points outside the grid, with the forward's binning kept for the pullback, and for a
+    cluster dense enough to split tiles."""
+    d = D.make(n_points=150_000, n_in=n_in, n_out=n_out, batch=2, grid_n=grid_n, seed=8, dtype=npdt)
+    d.points[::13] *= 3.0          # some far outside
+    d.points[1::5] *= 0.05         # a tight cluster: heavy tiles are split into parts
+    pts, pw = T(d.points, dev), (T(d.point_weights, dev) if with_pw else None)
+    perm = None
+    if order == "sorted":
+        if with_pw:
+            pts, perm, pw = dpr_amd.sort_points(pts, pw)
+        else:
+            pts, perm = dpr_amd.sort_points(pts)
+    pwn = d.point_weights if with_pw else None
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                            pwn, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights, pwn,
+                                    dtype=npdt)
+    pose = (T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev))
+    out = dpr_amd.raster(d.grid, pts, *pose, pw, algo="tiled", coherent_points=True)
+    assert_close(out, ref_out, tol(npdt, "out"), "out")
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), pts, *pose, pw, algo="tiled",
+                                  coherent_points=True)
+    def unsorted(x):
+        if perm is None:
+            return x
+        back = torch.empty_like(x)
+        back.index_copy_(0, perm.long(), x)
+        return back
+    assert_close(unsorted(pb.points), ref_pb.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(unsorted(pb.point_weight), ref_pb.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    assert_close(pb.rotation, ref_pb.rotation, tol(npdt, "pose"), "ds_drotation")
+    assert_close(pb.translation, ref_pb.translation, tol(npdt, "pose"), "ds_dtranslation")
+    assert_close(pb.out_weight, ref_pb.out_weight, tol(npdt, "pose"), "ds_dout_weight")
+    # single pose: the pullback reuses what the forward kept
+    ws = torch.empty(dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 1, n_in, tdt, "tiled",
+                                             coherent_points=True), dtype=torch.uint8, device=dev)
+    o1 = dpr_amd.empty_grid(d.grid, None, tdt, dev)
+    one = (pose[0][1], pose[1][1], float(d.backgrounds[1]), float(d.weights[1]))
+    dpr_amd.raster_(o1, pts, *one, pw, algo="tiled", workspace=ws, keep_binning=True, coherent_points=True)
+    assert_close(o1, ref_out[..., 1], tol(npdt, "out"), "kept forward")
+    pb1 = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout[..., 1], dev), pts, *one, pw, algo="tiled",
+                                   workspace=ws, reuse_binning=True, coherent_points=True)
+    ref1 = oracle.raster_pullback(d.ds_dout[..., 1:2], d.points, d.rotations[1:2], d.translations[1:2],
+                                  d.weights[1:2], pwn, dtype=npdt)
+    assert_close(unsorted(pb1.points), ref1.points, tol(npdt, "points"), "reused ds_dpoints")
+    assert_close(pb1.rotation, ref1.rotation[0], tol(npdt, "pose"), "reused ds_drotation")
+
+
 @pytest.mark.parametrize("algo", ["auto", "tiled"])
 def test_512_cube_fp64_vs_oracle(oracle, dev, algo):
     """HIP vs oracle on the C5 grid (512^3 fp64: 16384 tiles) with 1e5 points, all optional

@@ -1,6 +1,5 @@
-for c in 4096 8192 16384 32768 65536; do
-  echo "== cap_min $c"; DPR_CAP_MIN=$c python tools/stage_probe.py --P 1000000 --grid 128 128 128 2>&1 | grep -v amdgpu | tail -2
-done
-for c in 4096 16384 32768; do
-  echo "== cap_min $c (300k -> 96^3)"; DPR_CAP_MIN=$c python tools/stage_probe.py --P 300000 --grid 96 96 96 2>&1 | grep -v amdgpu | tail -2
-done
+for rep in 1 2; do
+for v in "" head; do
+  if [ -n "$v" ]; then export DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so; else unset DPR_LIB_OVERRIDE; fi
+  echo "== [$v]"; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['ms'], d['roofline']['pullback']['ms'], d['roofline']['stages'])"
+done; done
