@@ -2282,6 +2282,20 @@ __global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__
     }
 }
 
+// gradients of an internally sorted cloud back to the caller's order: dst[perm[i]] = src[i]
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void k_unsort(int64_t P, const uint32_t* __restrict__ perm,
+                                                const T* __restrict__ dp_sorted,
+                                                const T* __restrict__ dpw_sorted,
+                                                T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const size_t p = perm[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp_sorted[i * NI + j];
+    ds_dpw[p] = dpw_sorted[i];
+}
+
 // ------------------------------------------------------------------ host side
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -2324,6 +2338,11 @@ struct Plan {
     int max_slabs;   // overflow slabs (parts of split tiles)
     size_t off_hdr, off_counts, off_totals, off_tile_start, off_items, off_nitems, off_tparts, off_tslab,
         off_split, off_rec, off_idx, off_slot, off_aux, total;
+    // Hilbert sort of the cloud inside the call (batched poses on grids with more than 4096
+    // tiles, where the plain scatter runs 2.4x faster on coherent input: 50 M points -> 512^3,
+    // 1.64 -> 0.68 ms per pose against 2.7 ms for the sort, once per call)
+    bool sort_inside;
+    size_t off_spts, off_spw, off_perm, off_sgrad, off_sgradw, off_sorttmp;
     // local binning (DPR_FLAG_COHERENT_POINTS, NT <= 4096)
     bool local;
     int sub;               // points per sub-chunk
@@ -2352,9 +2371,15 @@ static int pose_group(int NT, int64_t P, int64_t B, int max_group) {
     return bg;
 }
 
+size_t sort_workspace_bytes(int64_t P);
+template <typename T>
+int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
+                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes);
+
 static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group,
-                      bool coherent = false) {
+                      bool coherent = false, int n_in = 3) {
     Plan pl;
+    pl.sort_inside = !coherent && NT1 > 4096 && B >= 4 && P1 >= 200000;
     // (the direct-store pullback mode, an experiment knob, needs the index array only the plain
     // scatter writes)
     pl.local = coherent && NT1 <= 4096 && knobs().bwd_unpermute;
@@ -2433,6 +2458,21 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
     (void)nrec;
+    pl.off_spts = pl.off_spw = pl.off_perm = pl.off_sgrad = pl.off_sgradw = pl.off_sorttmp = o;
+    if (pl.sort_inside) {
+        pl.off_spts = o;
+        o += align_up((size_t)P1 * n_in * elem);
+        pl.off_spw = o;
+        o += align_up((size_t)P1 * elem);
+        pl.off_perm = o;
+        o += align_up((size_t)P1 * 4);
+        pl.off_sgrad = o;
+        o += align_up((size_t)P1 * n_in * elem);
+        pl.off_sgradw = o;
+        o += align_up((size_t)P1 * elem);
+        pl.off_sorttmp = o;
+        o += align_up(sort_workspace_bytes(P1));
+    }
     pl.off_aux = o;
     // aux: forward = halo buffer | overflow slabs ; pullback = per-item partials
     const size_t nvh = (n_out == 3) ? tile_voxels_halo<3>() : tile_voxels_halo<2>();
@@ -2481,7 +2521,6 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
 size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int n_out,
                              const int64_t* grid, int64_t P, int64_t B) {
     (void)op;
-    (void)n_in;
     if (P >= (int64_t)1 << 32) return (size_t)-1;  // refused by raster_tiled / pullback_tiled
     int NT;
     if (n_out == 3) {
@@ -2494,7 +2533,7 @@ size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int 
         NT = tg.NT;
     }
     return make_plan(elem, n_out, NT, P, B, (int)((flags >> 8) & 0xffu),
-                     (flags & DPR_FLAG_COHERENT_POINTS) != 0).total;
+                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -2703,12 +2742,21 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
                     (long long)B);
     const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
-                              (flags & DPR_FLAG_COHERENT_POINTS) != 0);
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
+    if (pl.sort_inside) {
+        T* spw = pw ? (T*)(ws + pl.off_spw) : (T*)nullptr;
+        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
+                                         (uint32_t*)(ws + pl.off_perm), pw, spw,
+                                         ws + pl.off_sorttmp, sort_workspace_bytes(P)))
+            return rc;
+        points = (const T*)(ws + pl.off_spts);
+        pw = spw;
+    }
     T* halo = (T*)(ws + pl.off_aux);
     T* ovf = (T*)(ws + pl.off_aux +
                   align_up((size_t)tg.NT * pl.bg * halo_count<NO>() * sizeof(T)));
@@ -2778,13 +2826,26 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
                     (long long)B);
     const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
-                              (flags & DPR_FLAG_COHERENT_POINTS) != 0);
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
                     ws_ ? ws_bytes : (size_t)0);
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
+    T* d_pts_user = d_pts;
+    T* d_pw_user = d_pw;
+    if (pl.sort_inside) {
+        T* spw = pw ? (T*)(ws + pl.off_spw) : (T*)nullptr;
+        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
+                                         (uint32_t*)(ws + pl.off_perm), pw, spw,
+                                         ws + pl.off_sorttmp, sort_workspace_bytes(P)))
+            return rc;
+        points = (const T*)(ws + pl.off_spts);
+        pw = spw;
+        d_pts = (T*)(ws + pl.off_sgrad);   // gradients in sorted order, scattered back at the end
+        d_pw = (T*)(ws + pl.off_sgradw);
+    }
     double* partials = (double*)(ws + pl.off_aux);
     constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
     const bool unperm1 = knobs().bwd_unpermute != 0;
@@ -2877,6 +2938,10 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                            d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr, hdr);
         stage_mark(st);
     }
+    if (pl.sort_inside && P > 0)
+        hipLaunchKernelGGL((k_unsort<T, NI>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, P,
+                           (const uint32_t*)(ws + pl.off_perm), (const T*)d_pts, (const T*)d_pw,
+                           d_pts_user, d_pw_user);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

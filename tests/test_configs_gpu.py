@@ -219,6 +219,33 @@ def test_local_binning_of_coherent_points(oracle, dev, npdt, tdt, n_in, n_out, g
     assert_close(pb1.rotation, ref1.rotation[0], tol(npdt, "pose"), "reused ds_drotation")
 
 
+def test_batched_large_grid_sorts_the_cloud_inside(oracle, dev, with_pw=True):
+    """Batched poses on a grid with more than 4096 tiles: the tiled path Hilbert-sorts the cloud
+    into the workspace once per call and scatters the point gradients back through the
+    permutation.  250 k points -> 384 x 384 x 256 (4608 tiles), 4 poses, against the oracle."""
+    npdt = np.float32
+    d = D.make(n_points=250_000, n_in=3, n_out=3, batch=4, grid_n=384, seed=6, dtype=npdt)
+    d.grid = (384, 384, 256)
+    d.ds_dout = np.asfortranarray(d.ds_dout[:, :, :256, :])
+    pw = d.point_weights if with_pw else None
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(pw, dev))
+    few = dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 2, 3, torch.float32, "tiled")
+    many = dpr_amd.workspace_bytes("raster", d.grid, d.n_points, 4, 3, torch.float32, "tiled")
+    assert many > few + d.n_points * 12  # room for the sorted copy
+    out = dpr_amd.raster(d.grid, *args, algo="tiled")
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                            pw, dtype=npdt)
+    assert_close(out, ref_out, tol(npdt, "out"), "out")
+    del out, ref_out
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), *args, algo="tiled")
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights, pw,
+                                    dtype=npdt)
+    for name in ("points", "rotation", "translation", "background", "out_weight", "point_weight"):
+        assert_close(getattr(pb, name), getattr(ref_pb, name),
+                     tol(npdt, "points" if name.startswith("point") else "pose"), name)
+
+
 @pytest.mark.parametrize("algo", ["auto", "tiled"])
 def test_512_cube_fp64_vs_oracle(oracle, dev, algo):
     """HIP vs oracle on the C5 grid (512^3 fp64: 16384 tiles) with 1e5 points, all optional
