@@ -295,6 +295,9 @@ def run_rank(args):
     B_local = hi - lo
     to = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
     points = to(np_pts)
+    if args.order == "hilbert":
+        points = dpr_amd.sort_points(points)[0]
+    co = dict(coherent_points=True) if args.coherent else {}
     single_call = not batched  # single-pose signature (rotation is a matrix)
     R = to(np_R[0] if single_call else np_R)
     t = to(np_t[0] if single_call else np_t)
@@ -308,8 +311,8 @@ def run_rank(args):
     out = dpr_amd.empty_grid(grid, None if single_call else B_local, tdt, device)
     fused = torch.empty(P_local * (n_in + 1), dtype=tdt, device=device)
     Bq = max(B_local, 1)
-    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P_local, Bq, n_in, tdt, args.algo),
-                   dpr_amd.workspace_bytes("pullback", grid, P_local, Bq, n_in, tdt, args.algo))
+    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P_local, Bq, n_in, tdt, args.algo, **co),
+                   dpr_amd.workspace_bytes("pullback", grid, P_local, Bq, n_in, tdt, args.algo, **co))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
     algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P_local, Bq, n_in)
     algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P_local, Bq, n_in)
@@ -324,7 +327,7 @@ def run_rank(args):
     def fwd(keep=None):
         if B_local > 0:
             dpr_amd.raster_(out, points, R, t, algo=algo_f, workspace=ws,
-                            keep_binning=share if keep is None else keep)
+                            keep_binning=share if keep is None else keep, **co)
 
     def bwd(buf=fused, reuse=None):
         if B_local == 0:
@@ -332,7 +335,7 @@ def run_rank(args):
             return None
         return dpr_amd.raster_pullback_(g, points, R, t, ds_dpoints=buf[: P_local * n_in].view(P_local, n_in),
                                  ds_dpoint_weight=buf[P_local * n_in:], algo=algo_b, workspace=ws,
-                                 reuse_binning=share if reuse is None else reuse)
+                                 reuse_binning=share if reuse is None else reuse, **co)
 
     # ---- exchange.  Pose sharding: all-reduce(sum) of the fused point-gradient buffer; by
     # default step k's all-reduce runs on RCCL's stream under step k+1's kernels (double buffer;
@@ -439,10 +442,13 @@ def run_rank(args):
         roof["note"] = ("batched poses re-read the points per pose (group): the per-call "
                         "algorithmic bytes count them once, BASELINE.md section 3")
     if single_call and B_local == 1:
-        st_f = dpr_amd.stage_times(fwd, "raster", algo_f, reps)
+        local = args.coherent and algo_f == "tiled" and n_out == 3 or (args.coherent and algo_f == "tiled")
+        sname = lambda a: ("tiled_local" if (local and a == "tiled") else
+                           ("chunked2d" if (a == "chunked" and n_out == 2) else a))
+        st_f = dpr_amd.stage_times(fwd, "raster", sname(algo_f), reps)
         stages = {"raster": {"algo": algo_f, **{k: round(v, 4) for k, v in st_f.items()}}}
         if do_bwd:
-            st_b = dpr_amd.stage_times(bwd, "pullback", algo_b, reps, prepare=fwd)
+            st_b = dpr_amd.stage_times(bwd, "pullback", sname(algo_b), reps, prepare=fwd)
             stages["pullback"] = {"algo": algo_b, **{k: round(v, 4) for k, v in st_b.items()}}
         roof["stages"] = stages
         dom = max((k for k in st_f if k != "total"), key=lambda k: st_f[k])
@@ -481,6 +487,7 @@ def run_rank(args):
             "pullback_reuses_forward_binning": bool(share), "poses_global": B_global,
             "poses_per_rank": B_local if world == 1 else f"{B_global // world}..{-(-B_global // world)}",
             "sharding": shard if world > 1 else "none", "point_order": args.order,
+            "coherent_points_flag": bool(args.coherent),
             "exchange": exchange},
         "roofline": roof,
     }
@@ -494,7 +501,8 @@ def run_rank(args):
                             "unit": "M points/s",
                             "what": "pullback re-bins (plain dpr_raster_* / dpr_raster_pullback_* "
                                     "entry points, no DPR_FLAG_KEEP/REUSE_BINNING)"}
-    if world == 1 and args.order == "random" and not args.no_secondary and cfg in ("C2", "C3"):
+    if (world == 1 and args.order == "random" and not args.coherent and not args.no_secondary
+            and cfg in ("C2", "C3")):
         # secondary line: the same cloud pre-sorted once in the model frame (Morton order; the
         # sort is pose-independent, so a user amortises it over poses and iterations)
         sorted_pts, _perm = dpr_amd.sort_points(points)  # dpr_sort_points_f32
@@ -565,8 +573,11 @@ def main():
     ap.add_argument("--poses", type=int, default=None,
                     help="batched configs: global number of poses (default: the config's)")
     ap.add_argument("--algo", default="auto", choices=["auto", "atomic", "tiled", "chunked"])
-    ap.add_argument("--order", default="random", choices=["random", "morton"],
-                    help="point order in memory: as generated, or pre-sorted (pose-independent)")
+    ap.add_argument("--order", default="random", choices=["random", "morton", "hilbert"],
+                    help="point order in memory: as generated, Morton-sorted on the host, or "
+                         "Hilbert-sorted with dpr_sort_points (both pose-independent, not timed)")
+    ap.add_argument("--coherent", action="store_true",
+                    help="pass DPR_FLAG_COHERENT_POINTS (the caller vouches for a sorted cloud)")
     ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform", "tight"])
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: finish each step's all-reduce before the next step starts")

@@ -33,10 +33,14 @@ int fail(int code, const char* fmt, ...) {
             return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
 
-// AUTO picks DPR_ALGO_CHUNKED (2-D grids) from these sizes on (profiles/r02_chunkown_sweep.txt:
-// the forward wins from ~2e5 points at 8+ poses, the pullback from ~2e6 points)
-constexpr int64_t kChunkOwnMinPoses = 8, kChunkOwnMinPointsFwd = 200000,
-                  kChunkOwnMinPointsBwd = 2000000;
+// AUTO picks DPR_ALGO_CHUNKED (2-D grids) from these sizes on (profiles/r02_chunkown_sweep.txt):
+// the forward wins with 32+ poses from small clouds on (200 k points, 64 poses onto 128^2: 0.21
+// vs 0.88 ms) and with 8+ poses from ~4e6 points; the pullback from 8 poses and ~4e6 points.
+static bool chunkown_preferred(int op, int64_t P, int64_t B) {
+    if (P >= ((int64_t)1 << 32)) return false;
+    if (op == DPR_OP_RASTER) return (B >= 32 && P >= 50000) || (B >= 8 && P >= 4000000);
+    return B >= 8 && P >= 4000000;
+}
 
 static bool dims_supported(int n_in, int n_out) {
     return (n_in == 2 && n_out == 2) || (n_in == 3 && n_out == 3) || (n_in == 3 && n_out == 2);
@@ -76,9 +80,7 @@ static int resolve_algo(int algo, int op, int n_out, const int64_t* grid, int64_
     if (algo != DPR_ALGO_AUTO) return algo;
     // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside (the Morton sort
     // of the points, 0.65 ms per 10 M, is repaid from a few poses on)
-    if (n_out == 2 && B >= kChunkOwnMinPoses && P < ((int64_t)1 << 32) &&
-        P >= (op == DPR_OP_RASTER ? kChunkOwnMinPointsFwd : kChunkOwnMinPointsBwd))
-        return DPR_ALGO_CHUNKED;
+    if (n_out == 2 && chunkown_preferred(op, P, B)) return DPR_ALGO_CHUNKED;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
 
