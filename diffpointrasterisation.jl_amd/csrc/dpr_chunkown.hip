@@ -41,9 +41,13 @@
 namespace dpr {
 
 constexpr int kCOThreads = 1024;
+#ifndef DPR_CO_SPLAT_OCC
+#define DPR_CO_SPLAT_OCC 8  // waves per SIMD the fp32 forward kernel is compiled for
+#endif
 #ifndef DPR_CO_PPT
 #define DPR_CO_PPT 4
 #endif
+constexpr int kCOWideBlocks = 512;                // grid of k_co_splat_wide (walks a work list)
 constexpr int kCOPPT = DPR_CO_PPT;               // points per thread
 constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
 constexpr int kCOWaves = kCOThreads / kWave;
@@ -190,8 +194,11 @@ struct alignas(16) SortHeader {
     int64_t P;
     uint64_t points, pw;
 };
-__global__ void k_co_write_header(SortHeader h, SortHeader* dst) {
-    if (threadIdx.x == 0) *dst = h;
+__global__ void k_co_write_header(SortHeader h, SortHeader* dst, uint32_t* wide_count) {
+    if (threadIdx.x == 0) {
+        *dst = h;
+        *wide_count = 0;
+    }
 }
 __device__ __forceinline__ bool sort_header_ok(const SortHeader* hdr, const SortHeader& want) {
     return hdr->magic == kSortMagic && hdr->elem == want.elem && hdr->n_in == want.n_in &&
@@ -200,15 +207,21 @@ __device__ __forceinline__ bool sort_header_ok(const SortHeader* hdr, const Sort
 }
 
 // ------------------------------------------------------------------ forward
+// Two kernels.  k_co_splat covers every (chunk, pose) whose footprint fits the LDS tile in one
+// pass -- nearly all of them on a sorted cloud -- with a short inner loop (at most 64 VGPRs for
+// fp32: two workgroups per CU).  What does not fit (sparse tails of the cloud, incoherent input,
+// grids much larger than the cloud's resolution) is only FLAGGED per block, and k_co_splat_wide,
+// launched after it over the same grid, handles those poses of the flagged blocks in row bands.
+template <typename T> struct COSplatOcc {
+    static constexpr int value = sizeof(T) == 4 ? DPR_CO_SPLAT_OCC : 4;
+};
+
 template <typename T, int NI, bool HAS_PW>
-__global__ __launch_bounds__(kCOThreads) void k_co_splat(GridDesc<2> gd, int64_t P, int64_t B,
-                                                         int poses_per_slice,
-                                                         const T* __restrict__ points,
-                                                         const T* __restrict__ pw,
-                                                         const T* __restrict__ rot,
-                                                         const T* __restrict__ trans,
-                                                         const T* __restrict__ ow,
-                                                         T* __restrict__ out) {
+__global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
+    GridDesc<2> gd, int64_t P, int64_t B, int poses_per_slice, const T* __restrict__ points,
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans,
+    const T* __restrict__ ow, T* __restrict__ out, uint32_t* __restrict__ wide_count,
+    uint2* __restrict__ wide_items) {
     __shared__ double acc[kCOCap];
     __shared__ T sbox[kCOWaves][6];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -217,26 +230,96 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat(GridDesc<2> gd, int64_t
     bool live[kCOPPT];
     const bool any = co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P,
                                           (int64_t)blockIdx.x * kCOChunk, pt, w, live, c, h, sbox);
-    if (!any) return;  // uniform: no finite point in this chunk
     const int64_t b_lo = (int64_t)blockIdx.y * poses_per_slice;
     const int64_t b_hi = (b_lo + poses_per_slice < B) ? b_lo + poses_per_slice : B;
-    const int nbs = (int)(b_hi - b_lo);
+    const int nbs = any ? (int)(b_hi - b_lo) : 0;  // no finite point in this chunk: nothing to do
     // Blocks start at different poses: chunks along one viewing ray project onto the same
     // pixels, and float atomics of many workgroups into the same rows at the same time run an
     // order of magnitude slower than spread ones.
-    const int rot0 = (int)(blockIdx.x % (unsigned)nbs);
+    const int rot0 = nbs > 0 ? (int)(blockIdx.x % (unsigned)nbs) : 0;
     for (int jb = 0; jb < nbs; ++jb) {
         const int64_t b = b_lo + (jb + rot0) % nbs;
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
         if (cells == 0) continue;  // uniform
-        // A footprint larger than the LDS tile (sparse tails of the cloud, incoherent input) is
-        // covered in several passes over bands of rows; only a footprint WIDER than the whole
-        // tile goes to global memory directly.
+        if (cells > kCOCap) {  // uniform: left to k_co_splat_wide
+            if (threadIdx.x == 0)
+                wide_items[atomicAdd(wide_count, 1u)] = make_uint2(blockIdx.x, (unsigned)b);
+            continue;
+        }
+        // the footprint is clipped to the grid, so a neighbour inside it is in the grid: two
+        // unsigned compares per neighbour; whatever falls outside the bound takes the cold path
+        const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
+        T* o = out + b * gd.G;
+#pragma unroll
+        for (int k = 0; k < kCOPPT; ++k) {
+            int ref0[2];
+            T dlo[2];
+            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+            const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
+            const int lx0 = ref0[0] - lo[0], ly0 = ref0[1] - lo[1];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int lx = lx0 + (s & 1), ly = ly0 + (s >> 1);
+                const T v = voxel_weight<T, 2>(dlo, s, wk);
+                if (ok && (unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)H) {
+                    atomicAdd(&acc[ly * W + lx], (double)v);
+                } else if (ok) {  // outside the bound (rounding): straight to the image
+                    int ix = lx + lo[0], iy = ly + lo[1];
+                    asm volatile("" : "+v"(ix), "+v"(iy));  // keep the address math in here
+                    if (ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1])
+                        atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
+                }
+            }
+        }
+        lds_barrier();
+        // flush + re-zero: one wave per image row segment, contiguous x across the lanes
+        for (int r = wave; r < H; r += kCOWaves) {
+            T* orow = o + (size_t)(lo[1] + r) * gd.n[0] + lo[0];
+            for (int x = lane; x < W; x += kWave) {
+                const double a = acc[r * W + x];
+                if (a != 0.0) {
+                    atomic_add<T>(orow + x, (T)a);
+                    acc[r * W + x] = 0.0;
+                }
+            }
+        }
+        lds_barrier();  // LDS only: the flush's atomics stay in flight
+    }
+}
+
+template <typename T, int NI, bool HAS_PW>
+__global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
+    GridDesc<2> gd, int64_t P, const T* __restrict__ points, const T* __restrict__ pw,
+    const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
+    T* __restrict__ out, const uint32_t* __restrict__ wide_count,
+    const uint2* __restrict__ wide_items) {
+    __shared__ double acc[kCOCap];
+    __shared__ T sbox[kCOWaves][6];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t n_items = *wide_count;  // 0 in the usual case
+    if (blockIdx.x >= n_items) return;
+    for (int i = threadIdx.x; i < kCOCap; i += kCOThreads) acc[i] = 0.0;
+    // one (chunk, pose) pair at a time, so that a few sparse chunks with every pose wide still
+    // spread over the whole chip
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint2 item = wide_items[it];
+        __syncthreads();  // sbox of the previous item has been read
+        T pt[kCOPPT][NI], w[kCOPPT], c[NI], h[NI];
+        bool live[kCOPPT];
+        co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P, (int64_t)item.x * kCOChunk, pt, w,
+                             live, c, h, sbox);
+        const int64_t b = item.y;
+        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
+        int lo[2], hi[2];
+        const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+        if (cells <= kCOCap) continue;  // never: k_co_splat made the same decision
+        // several passes over bands of rows; only a footprint WIDER than the whole tile goes to
+        // global memory directly
         const int W = hi[0] - lo[0] + 1;
         const bool direct = W > kCOCap;
-        const int band = direct ? (1 << 30) : ((cells <= kCOCap) ? (hi[1] - lo[1] + 1) : kCOCap / W);
+        const int band = direct ? (1 << 30) : kCOCap / W;
         T* o = out + b * gd.G;
         for (int y0 = lo[1]; y0 <= hi[1]; y0 += band) {
             const int y1 = (y0 + band - 1 < hi[1]) ? y0 + band - 1 : hi[1];
@@ -263,7 +346,6 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat(GridDesc<2> gd, int64_t
             }
             if (direct) break;  // uniform
             lds_barrier();
-            // flush + re-zero: one wave per image row segment, contiguous x across the lanes
             for (int r = wave; r <= y1 - y0; r += kCOWaves) {
                 T* orow = o + (size_t)(y0 + r) * gd.n[0] + lo[0];
                 for (int x = lane; x < W; x += kWave) {
@@ -302,6 +384,8 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     __shared__ T tile[kCOCap];
     __shared__ T sbox[kCOWaves][6];
     __shared__ double pacc[kCOMaxSlice][NVAL];
+    __shared__ T red[NVAL][kCOThreads];
+    static_assert(NVAL <= kCOWaves, "one wave per per-pose sum");
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     for (int i = threadIdx.x; i < kCOMaxSlice * NVAL; i += kCOThreads) (&pacc[0][0])[i] = 0.0;
     T pt[kCOPPT][NI], w[kCOPPT], c[NI], h[NI];
@@ -321,7 +405,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
-        if (cells == 0) continue;  // uniform: no neighbour of the chunk is in the grid
+        if (cells == 0) continue;  // uniform: no neighbour of the chunk is in the grid (sums stay 0)
         // A footprint that does not fit the LDS tile (sparse tails of the cloud, incoherent
         // input) is gathered from global memory directly (L2-resident image; unlike the
         // forward's atomics these are plain loads).
@@ -340,6 +424,8 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
                 }
             }
             __syncthreads();
+        } else {
+            lds_barrier();  // `red` of the previous pose has been read
         }
         T vals[NVAL];
 #pragma unroll
@@ -388,12 +474,19 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
                 dp[k][j] += ps.R[0 + j * 2] * scaled[0] + ps.R[1 + j * 2] * scaled[1];
             dpw[k] += dpw_part;
         }
-        if (fits) lds_barrier();  // the tile is re-staged for the next pose (LDS phases only)
-        // per-pose sums: T within the thread (kCOPPT points), f64 across lanes / waves / blocks
+        // per-pose sums: T within the thread (kCOPPT points), f64 across the block.  Every thread
+        // parks its NVAL sums in LDS; after the barrier (which also releases the tile for the next
+        // pose) wave q adds up value q -- it is done before it arrives at the next barrier, and
+        // `red` is next written after that one.
 #pragma unroll
-        for (int q = 0; q < NVAL; ++q) {
-            const double sum = wave_sum<double>((double)vals[q]);
-            if (lane == 0 && sum != 0.0) atomicAdd(&pacc[b - b_lo][q], sum);
+        for (int q = 0; q < NVAL; ++q) red[q][threadIdx.x] = vals[q];
+        lds_barrier();
+        if (wave < NVAL) {
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < kCOThreads / kWave; ++i) sum += (double)red[wave][i * kWave + lane];
+            sum = wave_sum<double>(sum);
+            if (lane == 0) pacc[b - b_lo][wave] = sum;
         }
     }
     __syncthreads();
@@ -556,6 +649,10 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
     gd.G = G;
     const T* pts = points;
     const T* pws = pw;
+    // list of the (chunk, pose) pairs left to k_co_splat_wide: a counter + at most nblk * B
+    // entries, in the (forward-unused) region of the pullback's partial sums
+    uint32_t* wide_count = (uint32_t*)(ws + pl.off_part);
+    uint2* wide_items = (uint2*)(ws + pl.off_part + 16);
     if (sort && P > 0) {
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
@@ -574,7 +671,8 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
         h.P = P;
         h.points = (uint64_t)(uintptr_t)points;
         h.pw = (uint64_t)(uintptr_t)pw;
-        hipLaunchKernelGGL(k_co_write_header, dim3(1), dim3(64), 0, st, h, (SortHeader*)(ws + pl.off_hdr));
+        hipLaunchKernelGGL(k_co_write_header, dim3(1), dim3(64), 0, st, h,
+                           (SortHeader*)(ws + pl.off_hdr), wide_count);
     }
     stage_mark(st);
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {
@@ -587,12 +685,21 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
     stage_mark(st);
     if (P > 0) {
         dim3 gg((unsigned)pl.nblk, (unsigned)pl.slices);
-        if (pws)
+        if (pws) {
             hipLaunchKernelGGL((k_co_splat<T, NI, true>), gg, dim3(kCOThreads), 0, st, gd, P, B,
-                               pl.poses_per_slice, pts, pws, rot, trans, ow, out);
-        else
+                               pl.poses_per_slice, pts, pws, rot, trans, ow, out, wide_count,
+                               wide_items);
+            hipLaunchKernelGGL((k_co_splat_wide<T, NI, true>), dim3(kCOWideBlocks),
+                               dim3(kCOThreads), 0, st, gd, P, pts, pws, rot, trans, ow, out,
+                               wide_count, wide_items);
+        } else {
             hipLaunchKernelGGL((k_co_splat<T, NI, false>), gg, dim3(kCOThreads), 0, st, gd, P, B,
-                               pl.poses_per_slice, pts, pws, rot, trans, ow, out);
+                               pl.poses_per_slice, pts, pws, rot, trans, ow, out, wide_count,
+                               wide_items);
+            hipLaunchKernelGGL((k_co_splat_wide<T, NI, false>), dim3(kCOWideBlocks),
+                               dim3(kCOThreads), 0, st, gd, P, pts, pws, rot, trans, ow, out,
+                               wide_count, wide_items);
+        }
     }
     stage_mark(st);
     DPR_HIP(hipGetLastError());
