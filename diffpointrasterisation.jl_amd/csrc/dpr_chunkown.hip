@@ -52,6 +52,7 @@ constexpr int kCOPPT = DPR_CO_PPT;               // points per thread
 constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
 constexpr int kCOWaves = kCOThreads / kWave;
 constexpr int kCOCap = 9216;                     // LDS tile cells (8 bytes each): 72 KiB, 2 blocks / CU
+constexpr int kCOWideCap = 2 * kCOCap;            // tile of k_co_splat_wide (one workgroup per CU)
 constexpr int kCOMaxSlice = 64;                  // poses per block (per-pose sums live in LDS)
 static_assert(kCOChunk / kWave == kCOWaves * kCOPPT, "spread assignment covers the chunk");
 
@@ -295,12 +296,13 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
     T* __restrict__ out, const uint32_t* __restrict__ wide_count,
     const uint2* __restrict__ wide_items) {
-    __shared__ double acc[kCOCap];
+    // one workgroup per CU here (the register budget of the general path): twice the tile
+    __shared__ double acc[kCOWideCap];
     __shared__ T sbox[kCOWaves][6];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t n_items = *wide_count;  // 0 in the usual case
     if (blockIdx.x >= n_items) return;
-    for (int i = threadIdx.x; i < kCOCap; i += kCOThreads) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < kCOWideCap; i += kCOThreads) acc[i] = 0.0;
     // one (chunk, pose) pair at a time, so that a few sparse chunks with every pose wide still
     // spread over the whole chip
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -315,39 +317,53 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
         int lo[2], hi[2];
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
         if (cells <= kCOCap) continue;  // never: k_co_splat made the same decision
-        // several passes over bands of rows; only a footprint WIDER than the whole tile goes to
-        // global memory directly
-        const int W = hi[0] - lo[0] + 1;
-        const bool direct = W > kCOCap;
-        const int band = direct ? (1 << 30) : kCOCap / W;
+        // Passes over bands of rows (one pass when the footprint fits the larger tile); a footprint
+        // WIDER than the whole tile goes to global memory directly.  The neighbours and their
+        // weights are computed once and kept across the passes.
+        const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
+        const bool direct = W > kCOWideCap;
+        const int band = direct ? H : kCOWideCap / W;
         T* o = out + b * gd.G;
-        for (int y0 = lo[1]; y0 <= hi[1]; y0 += band) {
-            const int y1 = (y0 + band - 1 < hi[1]) ? y0 + band - 1 : hi[1];
-            const bool first = y0 == lo[1];
+        int lx0[kCOPPT], ly0[kCOPPT];
+        T v[kCOPPT][4];
 #pragma unroll
-            for (int k = 0; k < kCOPPT; ++k) {
-                int ref0[2];
-                T dlo[2];
-                const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
-                const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
+        for (int k = 0; k < kCOPPT; ++k) {
+            int ref0[2];
+            T dlo[2];
+            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+            const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
+            lx0[k] = ref0[0] - lo[0];
+            ly0[k] = ok ? ref0[1] - lo[1] : (1 << 29);  // no point: outside every band, and the grid
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int ix = ref0[0] + (s & 1), iy = ref0[1] + (s >> 1);
-                    const bool in = ok && ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1];
-                    const T v = voxel_weight<T, 2>(dlo, s, wk);
-                    const bool in_foot = !direct && ix >= lo[0] && ix <= hi[0] && iy >= lo[1] && iy <= hi[1];
-                    if (in && in_foot) {
-                        if (iy >= y0 && iy <= y1)
-                            atomicAdd(&acc[(iy - y0) * W + (ix - lo[0])], (double)v);
-                    } else if (in && first) {  // outside the bound (rounding), or no LDS tile at all
-                        atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
-                    }
+            for (int s = 0; s < 4; ++s) {
+                v[k][s] = voxel_weight<T, 2>(dlo, s, wk);
+                // outside the bound (rounding), or no LDS tile at all: straight to the image
+                const int lx = lx0[k] + (s & 1), ly = ly0[k] + (s >> 1);
+                const bool in_foot = !direct && (unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)H;
+                if (ok && !in_foot) {
+                    int ix = lx + lo[0], iy = ly + lo[1];
+                    asm volatile("" : "+v"(ix), "+v"(iy));  // keep the address math in here
+                    if (ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1])
+                        atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v[k][s]);
                 }
             }
-            if (direct) break;  // uniform
+        }
+        if (direct) continue;  // uniform
+        for (int y0 = 0; y0 < H; y0 += band) {
+            const int rows = (H - y0 < band) ? H - y0 : band;
+#pragma unroll
+            for (int k = 0; k < kCOPPT; ++k) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int lx = lx0[k] + (s & 1), ly = ly0[k] + (s >> 1) - y0;
+                    if ((unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)rows)
+                        atomicAdd(&acc[ly * W + lx], (double)v[k][s]);
+                }
+            }
             lds_barrier();
-            for (int r = wave; r <= y1 - y0; r += kCOWaves) {
-                T* orow = o + (size_t)(y0 + r) * gd.n[0] + lo[0];
+            // flush + re-zero: one wave per image row segment, contiguous x across the lanes
+            for (int r = wave; r < rows; r += kCOWaves) {
+                T* orow = o + (size_t)(lo[1] + y0 + r) * gd.n[0] + lo[0];
                 for (int x = lane; x < W; x += kWave) {
                     const double a = acc[r * W + x];
                     if (a != 0.0) {
@@ -381,10 +397,13 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
                 __builtin_nan("");
         return;
     }
-    __shared__ T tile[kCOCap];
+    // tile: footprint of ds_dout | red: per-thread per-pose sums.  The epilogue reuses both as
+    // one buffer to turn the chunk's point gradients into coalesced rows.
+    __shared__ T smem[kCOCap + NVAL * kCOThreads];
+    T* const tile = smem;
+    T(*const red)[kCOThreads] = reinterpret_cast<T(*)[kCOThreads]>(smem + kCOCap);
     __shared__ T sbox[kCOWaves][6];
     __shared__ double pacc[kCOMaxSlice][NVAL];
-    __shared__ T red[NVAL][kCOThreads];
     static_assert(NVAL <= kCOWaves, "one wave per per-pose sum");
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     for (int i = threadIdx.x; i < kCOMaxSlice * NVAL; i += kCOThreads) (&pacc[0][0])[i] = 0.0;
@@ -496,19 +515,39 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
         const int j = i / NVAL, q = i % NVAL;
         partials[((size_t)q * B + (b_lo + j)) * nblk + blockIdx.x] = pacc[j][q];
     }
+    // Point gradients: a thread's points are 64 apart from its neighbour lane's (co_point), so
+    // writing them from the registers would touch 64 cache lines per instruction (and, with the
+    // poses split over blockIdx.y, run at the one-lane-per-line atomic rate).  Through LDS
+    // instead: element i of the chunk's [kCOChunk][NI] block sits at i + i / 64 (the padding
+    // keeps the strided writes off one bank), the weights behind it.
+    constexpr int kPwBase = kCOChunk * NI + kCOChunk * NI / 64;
+    static_assert(kPwBase + kCOChunk + kCOChunk / 64 <= kCOCap + NVAL * kCOThreads, "epilogue fits");
 #pragma unroll
     for (int k = 0; k < kCOPPT; ++k) {
-        const int64_t p = (int64_t)blockIdx.x * kCOChunk + co_point(lane, wave, k);
-        if (p >= P) continue;
-        if (accumulate_points) {
+        const int q = co_point(lane, wave, k);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) atomic_add<T>(ds_dpoints + p * NI + j, dp[k][j]);
-            atomic_add<T>(ds_dpw + p, dpw[k]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp[k][j];
-            ds_dpw[p] = dpw[k];
+        for (int j = 0; j < NI; ++j) {
+            const int i = q * NI + j;
+            smem[i + (i >> 6)] = dp[k][j];
         }
+        smem[kPwBase + q + (q >> 6)] = dpw[k];
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kCOChunk;
+    const int n_here = (int)((P - base < kCOChunk) ? P - base : kCOChunk);
+    for (int i = threadIdx.x; i < n_here * NI; i += kCOThreads) {
+        const T v = smem[i + (i >> 6)];
+        if (accumulate_points)
+            atomic_add<T>(ds_dpoints + base * NI + i, v);
+        else
+            ds_dpoints[base * NI + i] = v;
+    }
+    for (int q = threadIdx.x; q < n_here; q += kCOThreads) {
+        const T v = smem[kPwBase + q + (q >> 6)];
+        if (accumulate_points)
+            atomic_add<T>(ds_dpw + base + q, v);
+        else
+            ds_dpw[base + q] = v;
     }
 }
 

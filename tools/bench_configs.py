@@ -43,6 +43,11 @@ def run(name, P, grid, B, dt, order, algo="auto"):
     del out, g, ws, tp
     torch.cuda.empty_cache()
 
+only = sys.argv[1:]  # e.g. "C5" "C4": run only the lines whose name starts with one of these
+_run = run
+def run(name, *a, **k):
+    if not only or any(name.startswith(o) for o in only):
+        _run(name, *a, **k)
 for order in ("random", "sorted"):
     run("C2 1M -> 128^3 f32, B=1", 1_000_000, (128,) * 3, 1, torch.float32, order)
     run("C3 10M -> 256^3 f32, B=1", 10_000_000, (256,) * 3, 1, torch.float32, order)
