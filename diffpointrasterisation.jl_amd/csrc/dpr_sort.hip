@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void k_hilbert_keys(int64_t P, const T* __rest
                                                       uint32_t* __restrict__ idx) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
-    constexpr int BITS = NI == 3 ? 10 : 16;
+    // 24-bit keys (three radix passes): 256^3 / 4096^2 cells order a cloud finely enough for
+    // chunks of thousands of points and for tiles of tens of voxels
+    constexpr int BITS = NI == 3 ? 8 : 12;
     uint32_t X[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -155,7 +157,7 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
     else
         hipLaunchKernelGGL((k_hilbert_keys<T, 2>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm,
-                                             (size_t)P, 0, n_in == 3 ? 30 : 32, st);
+                                             (size_t)P, 0, 24, st);
     if (e != hipSuccess)
         return fail(DPR_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
     if (n_in == 3)
