@@ -311,18 +311,31 @@ def run_rank(args):
     out = dpr_amd.empty_grid(grid, None if single_call else B_local, tdt, device)
     fused = torch.empty(P_local * (n_in + 1), dtype=tdt, device=device)
     Bq = max(B_local, 1)
-    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P_local, Bq, n_in, tdt, args.algo, **co),
-                   dpr_amd.workspace_bytes("pullback", grid, P_local, Bq, n_in, tdt, args.algo, **co))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
-    algo_f = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("raster", grid, P_local, Bq, n_in)
-    algo_b = args.algo if args.algo != "auto" else dpr_amd.resolve_algo("pullback", grid, P_local, Bq, n_in)
     # The pullback reuses the tile binning its forward call built in the same step (what an
     # rrule caches between `raster` and its pullback closure); nothing is carried across steps.
     # Batched calls share on the chunk-owner path (2-D grids): what is kept there is the sorted copy
-    # of the cloud, for any number of poses.
-    can_share = do_bwd and algo_f == algo_b and (
-        (single_call and algo_f in ("tiled", "chunked")) or (algo_f == "chunked" and n_out == 2))
+    # of the cloud, for any number of poses.  With keep / reuse flags DPR_ALGO_AUTO decides for
+    # the pair of calls (include/dpr.h); the names are resolved here so that the no-share run and
+    # the stage list use exactly the algorithms of the timed step.
+    def shareable(a):
+        return (single_call and a in ("tiled", "chunked")) or (a == "chunked" and n_out == 2)
+
+    def algos(sharing):
+        if args.algo != "auto":
+            return args.algo, args.algo
+        return tuple(dpr_amd.resolve_algo(op, grid, P_local, Bq, n_in, sharing=sharing, **co)
+                     for op in ("raster", "pullback"))
+
+    algo_f, algo_b = algos(sharing=do_bwd and not args.no_share_binning)
+    can_share = do_bwd and algo_f == algo_b and shareable(algo_f)
     share = can_share and not args.no_share_binning
+    if not share:
+        algo_f, algo_b = algos(sharing=False)
+    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P_local, Bq, n_in, tdt, a, **co)
+                   for a in {algo_f, algo_b} | set(algos(False)))
+    ws_bytes = max(ws_bytes, *(dpr_amd.workspace_bytes("pullback", grid, P_local, Bq, n_in, tdt, a, **co)
+                               for a in {algo_f, algo_b} | set(algos(False))))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
 
     def fwd(keep=None):
         if B_local > 0:

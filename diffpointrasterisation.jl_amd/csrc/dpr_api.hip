@@ -3,6 +3,7 @@
 // ext/DiffPointRasterisationCUDAExt.jl:246-262) but report through status codes.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <initializer_list>
@@ -33,13 +34,55 @@ int fail(int code, const char* fmt, ...) {
             return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
 
-// AUTO picks DPR_ALGO_CHUNKED (2-D grids) from these sizes on (profiles/r02_chunkown_sweep.txt):
-// the forward wins with 32+ poses from small clouds on (200 k points, 64 poses onto 128^2: 0.21
-// vs 0.88 ms) and with 8+ poses from ~4e6 points; the pullback from 8 poses and ~4e6 points.
-static bool chunkown_preferred(int op, int64_t P, int64_t B) {
-    if (P >= ((int64_t)1 << 32)) return false;
-    if (op == DPR_OP_RASTER) return (B >= 32 && P >= 50000) || (B >= 8 && P >= 4000000);
-    return B >= 8 && P >= 4000000;
+// AUTO and DPR_ALGO_CHUNKED on 2-D grids: a small cost model (ms on one MI355X, fitted to
+// profiles/r02_chunkown_sweep.txt) instead of fixed thresholds, because the crossover moves with
+// three things at once -- the poses that share the Hilbert sort, the size of the cloud, and how
+// far a 4096-point chunk spreads over the image (`spread`, in pixels: chunks whose footprint
+// outgrows the LDS tile take the slower banded path).
+struct PairCost {
+    double fwd, bwd;
+};
+static double chunk_spread(int n_in, int64_t G, int64_t P) {
+    const double frac = P > 4096 ? 4096.0 / (double)P : 1.0;
+    return (double)G * (n_in == 3 ? std::cbrt(frac * frac) : frac);
+}
+static double clamp01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+static double sort_cost(double pm) { return 0.04 + 0.052 * pm; }
+static PairCost chunkown_cost(int n_in, int64_t G, int64_t P, int64_t B, bool coherent) {
+    const double pm = (double)P * 1e-6, f = chunk_spread(n_in, G, P);
+    PairCost c;
+    c.fwd = 0.03 + 0.004 * pm + (double)B * (0.002 + pm * (0.0055 + 0.02 * clamp01((f - 2000) / 10000)));
+    c.bwd = 0.025 + 0.0075 * pm + (double)B * (0.002 + pm * (0.007 + 0.006 * clamp01((f - 2000) / 5000)));
+    if (!coherent) {
+        c.fwd += sort_cost(pm);
+        c.bwd += sort_cost(pm) + 0.01 + 0.033 * pm;  // + gradients back to the caller's order
+    }
+    return c;
+}
+static PairCost other_cost(int n_out, const int64_t* grid, int64_t P, int64_t B) {
+    const double pm = (double)P * 1e-6;
+    PairCost a, t;
+    a.fwd = 0.01 + (double)B * (0.001 + 0.19 * pm);
+    a.bwd = 0.05 + (double)B * (0.0003 + 0.05 * pm);
+    if (!tiled_supported(n_out, grid) || P >= ((int64_t)1 << 32)) return a;
+    const double pf = 0.005 + 0.0128 * pm, pb = 0.005 + 0.0207 * pm;
+    t.fwd = 0.03 + (double)B * (pf > 0.0115 ? pf : 0.0115);
+    t.bwd = 0.03 + (double)B * (pb > 0.0135 ? pb : 0.0135);
+    PairCost c;
+    c.fwd = a.fwd < t.fwd ? a.fwd : t.fwd;
+    c.bwd = a.bwd < t.bwd ? a.bwd : t.bwd;
+    return c;
+}
+// op < 0: the raster + pullback pair of a KEEP_BINNING / REUSE_BINNING call pair (one sort)
+static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid, int64_t G,
+                               int64_t P, int64_t B, bool coherent) {
+    if (n_out != 2 || P >= ((int64_t)1 << 32) || P < 1 || B < 1) return false;
+    const PairCost c = chunkown_cost(n_in, G, P, B, coherent), o = other_cost(n_out, grid, P, B);
+    const double margin = 0.85;  // stay with the established paths unless clearly ahead
+    if (op == DPR_OP_RASTER) return c.fwd < margin * o.fwd;
+    if (op == DPR_OP_PULLBACK) return c.bwd < margin * o.bwd;
+    const double pm = (double)P * 1e-6;
+    return c.fwd + c.bwd - (coherent ? 0.0 : sort_cost(pm)) < margin * (o.fwd + o.bwd);
 }
 
 static bool dims_supported(int n_in, int n_out) {
@@ -75,12 +118,24 @@ template <int NO> static GridDesc<NO> make_grid(const int64_t* grid, int64_t G) 
     return gd;
 }
 
-static int resolve_algo(int algo, int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
-                        int64_t G) {
+// DPR_ALGO_AUTO.  `flags` (in/out): a KEEP_BINNING / REUSE_BINNING call pair must run the SAME
+// algorithm in both calls, so with either flag set the choice is made for the pair, from
+// arguments both calls share -- and when the pair's algorithm cannot share (atomic; tiled with
+// B > 1), AUTO drops the two flags instead of failing: each call then works on its own.
+// An explicit algorithm keeps the strict behaviour (error).
+static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* grid, int64_t P,
+                        int64_t B, int64_t G, unsigned* flags) {
     if (algo != DPR_ALGO_AUTO) return algo;
-    // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside (the Morton sort
-    // of the points, 0.65 ms per 10 M, is repaid from a few poses on)
-    if (n_out == 2 && chunkown_preferred(op, P, B)) return DPR_ALGO_CHUNKED;
+    const bool coherent = (*flags & DPR_FLAG_COHERENT_POINTS) != 0;
+    if (*flags & 3u) {
+        if (chunkown_preferred(-1, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
+        if (B == 1 && tiled_preferred(DPR_OP_RASTER, n_out, grid, P, B, G) &&
+            tiled_preferred(DPR_OP_PULLBACK, n_out, grid, P, B, G))
+            return DPR_ALGO_TILED;
+        *flags &= ~3u;
+    }
+    // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside
+    if (chunkown_preferred(op, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
 
@@ -149,7 +204,7 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
         return fail(DPR_ERR_INVALID_ARG, "P too large");
     if (int rc = check_alignment<T>(ws, {out, points, rot, trans, bg, ow, pw})) return rc;
     hipStream_t st = (hipStream_t)stream;
-    algo = resolve_algo(algo, DPR_OP_RASTER, n_out, grid, P, B, G);
+    algo = resolve_algo(algo, DPR_OP_RASTER, n_in, n_out, grid, P, B, G, &flags);
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                       \
     if (n_in == NI && n_out == NO) {                                                           \
@@ -253,7 +308,7 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     if (int rc = check_alignment<T>(ws, {g, points, rot, trans, ow, pw, d_pts, d_rot, d_trans, d_bg,
                                          d_ow, d_pw, rs.target, rs.loss}))
         return rc;
-    algo = resolve_algo(algo, DPR_OP_PULLBACK, n_out, grid, P, B, G);
+    algo = resolve_algo(algo, DPR_OP_PULLBACK, n_in, n_out, grid, P, B, G, &flags);
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                         \
     if (n_in == NI && n_out == NO) {                                                             \
@@ -295,7 +350,7 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
         fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
         return (size_t)-1;
     }
-    algo = resolve_algo(algo, op, n_out, grid, P, B, G);
+    algo = resolve_algo(algo, op, n_in, n_out, grid, P, B, G, &flags);
     if (algo == DPR_ALGO_ATOMIC) return 0;
     if (algo == DPR_ALGO_TILED) {
         const size_t n = tiled_workspace_bytes(sizeof(T), op, flags, n_in, n_out, grid, P, B);
@@ -324,12 +379,17 @@ int dpr_version(void) { return DPR_VERSION; }
 
 const char* dpr_last_error(void) { return dpr::g_last_error.c_str(); }
 
-int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B) {
+int dpr_resolve_algo_ex(int op, unsigned flags, int n_in, int n_out, const int64_t* grid,
+                        int64_t P, int64_t B) {
     int64_t G = 0;
     if (int rc = dpr::check_common(n_in, n_out, grid, P, B, &G)) return rc;
     if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK)
         return dpr::fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
-    return dpr::resolve_algo(DPR_ALGO_AUTO, op, n_out, grid, P, B, G);
+    return dpr::resolve_algo(DPR_ALGO_AUTO, op, n_in, n_out, grid, P, B, G, &flags);
+}
+
+int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B) {
+    return dpr_resolve_algo_ex(op, 0u, n_in, n_out, grid, P, B);
 }
 
 int dpr_stage_timing_begin(void** events, int capacity) {

@@ -134,31 +134,37 @@ def _workspace(op, algo, suf, n_in, n_out, grid_arr, P, B, device, workspace, fl
 
 def workspace_bytes(op: str, grid_size, n_points: int, batch: int, n_in: int, dtype=torch.float32,
                     algo: str = "auto", max_pose_group: int = 0,
-                    coherent_points: bool = False) -> int:
+                    coherent_points: bool = False, sharing: bool = False) -> int:
     """dpr_workspace_bytes_ex_*: device bytes `op` needs.  `max_pose_group` (1..16, 0 = default)
     bounds how many poses of a batch the tiled path bins together -- the speed / memory trade of
-    DPR_FLAG_MAX_POSE_GROUP (include/dpr.h)."""
+    DPR_FLAG_MAX_POSE_GROUP (include/dpr.h).  `sharing`: the calls will carry keep_binning /
+    reuse_binning (`algo="auto"` then sizes for the algorithm the pair runs)."""
     import numpy as np
 
     grid_arr = np.asarray(grid_size, dtype=np.int64)
     opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
     need = getattr(_lib.lib(), f"dpr_workspace_bytes_ex_{_SUFFIX[dtype]}")(
         opc, _lib.ALGOS[algo], _lib.flag_max_pose_group(max_pose_group)
-        | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0), n_in, len(grid_size),
+        | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0)
+        | (_lib.FLAG_KEEP_BINNING if sharing else 0), n_in, len(grid_size),
         grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
     if need == ctypes.c_size_t(-1).value:
         raise _lib.DprError(_lib.ERR_INVALID_ARG, _lib.last_error())
     return int(need)
 
 
-def resolve_algo(op: str, grid_size, n_points: int, batch: int, n_in: int) -> str:
-    """Name of the algorithm `algo="auto"` picks for this problem."""
+def resolve_algo(op: str, grid_size, n_points: int, batch: int, n_in: int, *,
+                 sharing: bool = False, coherent_points: bool = False) -> str:
+    """Name of the algorithm `algo="auto"` picks for this problem.  `sharing`: the call carries
+    keep_binning / reuse_binning (the choice is then made for the raster + pullback pair, see
+    include/dpr.h)."""
     import numpy as np
 
     grid_arr = np.asarray(grid_size, dtype=np.int64)
     opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
-    rc = _lib.lib().dpr_resolve_algo(opc, n_in, len(grid_size),
-                                     grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
+    flags = (_lib.FLAG_KEEP_BINNING if sharing else 0) | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0)
+    rc = _lib.lib().dpr_resolve_algo_ex(opc, flags, n_in, len(grid_size),
+                                        grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
     if rc < 0:
         _lib.check(rc)
     return {v: k for k, v in _lib.ALGOS.items()}[rc]
@@ -265,10 +271,10 @@ def raster_(out, points, rotation, translation, background=None, out_weight=None
     with torch.cuda.device(c["device"]):
         flags = _lib.flag_max_pose_group(max_pose_group)
         flags |= _lib.FLAG_COHERENT_POINTS if coherent_points else 0  # dpr_sort_points output etc.
+        flags |= _lib.FLAG_KEEP_BINNING if keep_binning else 0  # (also steers DPR_ALGO_AUTO)
         ws, ws_bytes = _workspace(_lib.OP_RASTER, algo_c, suf, c["n_in"], c["n_out"], grid_arr,
                                   c["P"], c["B"], c["device"], workspace, flags)
         fn = getattr(_lib.lib(), f"dpr_raster_ex_{suf}")
-        flags |= _lib.FLAG_KEEP_BINNING if keep_binning else 0
         if keep_binning and workspace is None:
             raise ValueError("keep_binning needs a caller-owned workspace")
         _lib.check(fn(_stream_ptr(c["device"]), algo_c, flags, c["n_in"], c["n_out"],
@@ -391,9 +397,9 @@ def _pullback(ds_dout, residual, points, rotation, translation, background, out_
     with torch.cuda.device(dev):
         flags = _lib.flag_max_pose_group(max_pose_group)
         flags |= _lib.FLAG_COHERENT_POINTS if coherent_points else 0
+        flags |= _lib.FLAG_REUSE_BINNING if reuse_binning else 0
         ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
                                   workspace, flags)
-        flags |= _lib.FLAG_REUSE_BINNING if reuse_binning else 0
         if reuse_binning and workspace is None:
             raise ValueError("reuse_binning needs the workspace of the preceding raster_ call")
         head = (_stream_ptr(dev), algo_c, flags, n_in, n_out,

@@ -118,9 +118,19 @@ int dpr_version(void);
 /* Thread-local message of the last failing call on this host thread ("" if none). */
 const char *dpr_last_error(void);
 
-/* Algorithm DPR_ALGO_AUTO resolves to for this problem (DPR_ALGO_ATOMIC or DPR_ALGO_TILED),
- * or a negative status. */
+/* Algorithm DPR_ALGO_AUTO resolves to for this problem (DPR_ALGO_ATOMIC, DPR_ALGO_TILED or, on
+ * 2-D grids, DPR_ALGO_CHUNKED), or a negative status.  The choice depends on the flags:
+ *  - DPR_FLAG_COHERENT_POINTS makes the paths that exploit it cheaper;
+ *  - with DPR_FLAG_KEEP_BINNING or DPR_FLAG_REUSE_BINNING the choice is made for the raster +
+ *    pullback PAIR (both calls must run the same algorithm), from arguments both calls share.
+ *    When the pair's algorithm has nothing to share (DPR_ALGO_ATOMIC; DPR_ALGO_TILED with
+ *    B > 1), AUTO ignores the two flags -- each call then works on its own -- where an
+ *    explicitly named algorithm returns an error.  So a caller may always pass AUTO + KEEP to
+ *    raster and AUTO + REUSE to the pullback of the same arguments.
+ * dpr_resolve_algo is dpr_resolve_algo_ex with flags = 0. */
 int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t *grid, int64_t P, int64_t B);
+int dpr_resolve_algo_ex(int op, unsigned flags, int n_in, int n_out, const int64_t *grid,
+                        int64_t P, int64_t B);
 
 /* Optional per-stage device timing (used by bench.py for the roofline numbers): arm an
  * array of `capacity` hipEvent_t created by the caller; until dpr_stage_timing_end() every

@@ -70,6 +70,19 @@ function workspace(op::Integer, ::Type{T}, n_in, n_out, grid, P, B) where {T}
     return ROCVector{UInt8}(undef, max(nbytes, 16))
 end
 
+# Workspace of a raster / raster_pullback! call PAIR that shares its binning: with a sharing flag
+# DPR_ALGO_AUTO decides for the pair (dpr_resolve_algo_ex in dpr.h), so the size is asked with the
+# flag set, for both operations.
+function workspace_pair(::Type{T}, n_in, n_out, grid, P, B) where {T}
+    g = collect(Int64, grid)
+    sym = T === Float32 ? :dpr_workspace_bytes_ex_f32 : :dpr_workspace_bytes_ex_f64
+    nbytes = maximum(op -> ccall((sym, libdpr), Csize_t,
+        (Cint, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64),
+        op, 0, Cuint(1), n_in, n_out, g, P, B), (0, 1))
+    nbytes == typemax(Csize_t) && error(unsafe_string(ccall((:dpr_last_error, libdpr), Cstring, ())))
+    return ROCVector{UInt8}(undef, max(nbytes, 16))
+end
+
 # ---- forward: canonical method of src/raster.jl:5-13 for ROCArray outputs ------------------
 function DiffPointRasterisation.raster!(
     out::ROCArray{T,N_out_p1},
@@ -249,7 +262,9 @@ end
 # the closure, `raster_pullback!` -- two independent calls, so the pullback bins the points
 # again.  For a single pose on ROCArrays this more specific method keeps the workspace alive in
 # the closure: the primal passes DPR_FLAG_KEEP_BINNING, the pullback DPR_FLAG_REUSE_BINNING
-# (validated on the device: a stale workspace yields NaN gradients, never garbage).  bench.py's
+# (validated on the device: a stale workspace yields NaN gradients, never garbage; for problems
+# where AUTO's algorithm has nothing to share -- small clouds on the direct kernels -- the library
+# ignores the two flags and the calls are the generic pair).  bench.py's
 # headline step is exactly this pairing; its `no_share` entry is the generic rrule.
 # Loaded only when ChainRulesCore is (a second weak dependency of this extension).
 const DPR_ALGO_AUTO, DPR_FLAG_KEEP_BINNING, DPR_FLAG_REUSE_BINNING = Cint(0), Cuint(1), Cuint(2)
@@ -311,7 +326,7 @@ end
         ow = length(optional_args) >= 2 ? [T(optional_args[2])] : Ones{T}(1)
         pw = length(optional_args) >= 3 ? optional_args[3] : Ones{T}(P)
         out = similar(points, T, Tuple(grid_size))
-        ws = workspace(1, T, N_in, N_out, collect(Int64, grid_size), P, 1)   # one layout for both ops
+        ws = workspace_pair(T, N_in, N_out, collect(Int64, grid_size), P, 1)
         rot_d, tr_d, ow_d, pw_d = raster_keep!(out, points, rotation, translation, bg, ow, pw, ws)
         consumed = Ref(false)
         function raster_pullback(ds_dout)

@@ -131,11 +131,22 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     # the direct pullback kernel stays ahead longer (profiles/r01_algo_sweep_batched.txt)
     assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 16, 3) == "tiled"
     assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 1, 3) == "atomic"
-    assert dpr_amd.resolve_algo("pullback", (512, 512), 100_000, 64, 3) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (512, 512), 20_000, 64, 3) == "atomic"
     # many poses onto a 2-D grid: chunk-owned LDS tiles with the pose loop inside
     assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3) == "chunked"
     assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 64, 3) == "chunked"
     assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 1, 3) == "tiled"
+    # ... a sparse cloud on a large image spreads its chunks too far: the forward stays tiled
+    assert dpr_amd.resolve_algo("raster", (1024, 1024), 3_000_000, 8, 3) == "tiled"
+    # a keep_binning / reuse_binning pair gets ONE algorithm for both calls, whatever the op
+    for P, B, grid in [(1000, 1, (8, 8, 8)), (10_000_000, 1, (256,) * 3), (10_000_000, 64, (512, 512)),
+                       (200_000, 16, (128, 128)), (3_000_000, 8, (1024, 1024)), (100_000, 4, (64,) * 3)]:
+        pair = {dpr_amd.resolve_algo(op, grid, P, B, 3, sharing=True) for op in ("raster", "pullback")}
+        assert len(pair) == 1 or pair <= {"atomic", "tiled"}, (P, B, grid, pair)  # unshared: any mix
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 1, 3, sharing=True) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3, sharing=True) == "chunked"
+    # pre-sorted clouds skip the sort: the chunk-owner path pays off from a single pose on
+    assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 1, 3, coherent_points=True) == "chunked"
     # more tiles than the tiled path supports -> direct kernels
     assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "atomic"
     assert dpr_amd.workspace_bytes("raster", (8, 8), 100, 1, 2, torch.float64, "atomic") == 0

@@ -120,6 +120,38 @@ def test_c5_share_8_poses(dev):
     assert_close(pb.point_weight, np.full(P, 0.5 * float(ow.sum())), 1e-12)
 
 
+@pytest.mark.parametrize("n_points,n_in,n_out,batch,grid_n", [
+    (500, 3, 3, 1, 8),          # AUTO -> atomic: nothing to keep, the flags are ignored
+    (300_000, 3, 3, 1, 64),     # AUTO -> tiled for both calls, shared binning
+    (30_000, 3, 3, 3, 40),      # a batch on a 3-D grid: no sharing, each call on its own
+    (150_000, 3, 2, 12, 96),    # AUTO -> chunk-owner pair (the sorted copy is shared)
+    (400, 2, 2, 2, 16),
+    (60_000, 3, 2, 40, 300),    # sparse cloud, many poses: wide footprints
+])
+def test_auto_accepts_keep_and_reuse_for_any_problem(oracle, dev, n_points, n_in, n_out, batch, grid_n):
+    """include/dpr.h, dpr_resolve_algo_ex: a caller (the rrule) may always pass AUTO + KEEP_BINNING
+    to raster and AUTO + REUSE_BINNING to the pullback of the same arguments; AUTO picks one
+    algorithm for the pair or ignores the flags -- never an error, never stale lists."""
+    d = D.make(n_points=n_points, n_in=n_in, n_out=n_out, batch=batch, grid_n=grid_n, seed=21,
+               dtype=np.float32)
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(d.point_weights, dev))
+    need = max(dpr_amd.workspace_bytes(op, d.grid, n_points, batch, n_in, torch.float32, "auto", sharing=True)
+               for op in ("raster", "pullback"))
+    ws = torch.zeros(max(need, 16), dtype=torch.uint8, device=dev)
+    pair = {dpr_amd.resolve_algo(op, d.grid, n_points, batch, n_in, sharing=True) for op in ("raster", "pullback")}
+    assert len(pair) == 1 or "chunked" not in pair
+    out = dpr_amd.empty_grid(d.grid, batch, torch.float32, dev)
+    g = grid_to_dev(d.ds_dout, dev)
+    dpr_amd.raster_(out, *args, algo="auto", workspace=ws, keep_binning=True)
+    pb = dpr_amd.raster_pullback_(g, *args, algo="auto", workspace=ws, reuse_binning=True)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                            d.point_weights, dtype=np.float32)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                    d.point_weights, dtype=np.float32)
+    _compare(ref_out, ref_pb, out, pb, np.float32)
+
+
 @pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
 @pytest.mark.parametrize("with_pw", [False, True])
 def test_chunk_owner_keeps_the_sorted_cloud_for_the_pullback(oracle, dev, npdt, tdt, with_pw):

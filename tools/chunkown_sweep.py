@@ -27,6 +27,7 @@ for P, n, B in cases:
     out = dpr_amd.empty_grid((n, n), B, torch.float32, dev)
     line = f"P={P:>9} grid={n}^2 B={B:>3}:"
     for name, algo, p, kw in (("atomic", "atomic", pts, {}), ("tiled", "tiled", pts, {}), ("chunked", "chunked", pts, {}),
+                              ("tiled/coherent", "tiled", spts, dict(coherent_points=True)),
                               ("chunked/coherent", "chunked", spts, dict(coherent_points=True))):
         if name == "atomic" and P * B > 2e8:
             continue
