@@ -221,10 +221,14 @@ def test_local_binning_of_coherent_points(oracle, dev, npdt, tdt, n_in, n_out, g
     ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights, pwn,
                                     dtype=npdt)
     pose = (T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev))
-    out = dpr_amd.raster(d.grid, pts, *pose, pw, algo="tiled", coherent_points=True)
+    # (a batch that can form pose groups stays on the grouped pipeline; one pose per group selects
+    # the local bins for every pose of the batch)
+    out = dpr_amd.raster(d.grid, pts, *pose, pw, algo="tiled", coherent_points=True, max_pose_group=1)
     assert_close(out, ref_out, tol(npdt, "out"), "out")
+    out_g = dpr_amd.raster(d.grid, pts, *pose, pw, algo="tiled", coherent_points=True)
+    assert_close(out_g, ref_out, tol(npdt, "out"), "out (grouped)")
     pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), pts, *pose, pw, algo="tiled",
-                                  coherent_points=True)
+                                  coherent_points=True, max_pose_group=1)
     def unsorted(x):
         if perm is None:
             return x
