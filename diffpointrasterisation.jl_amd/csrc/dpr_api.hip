@@ -245,9 +245,7 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
     DPR_HIP(hipMemsetAsync(d_bg, 0, sizeof(T) * (size_t)B, st));
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {
         const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
-        int64_t want = (G + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
-        if (want * nb > 8192) want = (8192 + nb - 1) / nb;
-        if (want < 1) want = 1;
+        const int64_t want = grid_sum_blocks(G, nb);
         dim3 gg((unsigned)want, (unsigned)nb);
         Residual<T> rb = rs;
         if (rb.target) rb.target += b0 * G;
