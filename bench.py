@@ -501,7 +501,12 @@ def run_rank(args):
             "poses_per_rank": B_local if world == 1 else f"{B_global // world}..{-(-B_global // world)}",
             "sharding": shard if world > 1 else "none", "point_order": args.order,
             "coherent_points_flag": bool(args.coherent),
-            "exchange": exchange},
+            "exchange": exchange,
+            "value_counts": "points x poses of the whole job per second (a point counts once per pose)",
+            **({"same_job_on_one_gpu": f"python bench.py --config {cfg} --gpus 1"
+                                        + (f" --poses {B_global}" if args.poses else "")
+                                        + "  (the default --gpus 1 run is the metric's config C3, a different job)"}
+               if world > 1 else {})},
         "roofline": roof,
     }
     if can_share and not args.no_share_binning and world == 1:
