@@ -3,13 +3,14 @@
 // (/root/reference/README.md:189-192, ext/DiffPointRasterisationCUDAExt.jl:19-210 keeps one point
 // and a block of poses per thread block; here a block keeps a CHUNK of points and walks the poses).
 //
-// A chunk is kChunk consecutive points of a spatially coherent (Morton-sorted) cloud: a compact
+// A chunk is kChunk consecutive points of a spatially coherent (Hilbert-sorted) cloud: a compact
 // blob in the model frame, so under any pose its projection covers a small pixel rectangle
 // (~35 x 35 pixels for a 4096-point chunk of the 10 M-point cloud on 512^2), bounded WITHOUT
 // looking at the points again: footprint = projected centre +- sum_j |R[d,j]| h_j of the chunk's
 // 3-D bounding box.  Per block, with the chunk's points held in registers for ALL poses:
 //
-//   forward   per pose: 4 ds_add_f64 per point into the footprint tile in LDS, then the tile is
+//   forward   (k_co_splat; footprints larger than the tile: work list + k_co_splat_wide)
+//             per pose: 4 ds_add_f64 per point into the footprint tile in LDS, then the tile is
 //             flushed with global atomic adds, one image row segment (contiguous x) per wave
 //             instruction -- the 256-byte shape float atomics run at full rate in; `out` was
 //             pre-filled with the background.  A pixel of a projection collects ~40 points, so
@@ -24,8 +25,8 @@
 // neighbours project onto the same pixels, and same-address LDS atomics serialise (26 -> 190
 // cycles per wave instruction, profiles/r02_microbench_lds_conflicts.txt).
 //
-// Input that is not known to be coherent (no DPR_FLAG_COHERENT_POINTS) is Morton-sorted into the
-// workspace first (rocPRIM radix sort, 0.65 ms for 10 M points: amortised over the poses of the
+// Input that is not known to be coherent (no DPR_FLAG_COHERENT_POINTS) is Hilbert-sorted into the
+// workspace first (rocPRIM radix sort, 0.55 ms for 10 M points: amortised over the poses of the
 // call) and the point gradients are scattered back through the permutation.  Whatever the order,
 // the result is correct: a (chunk, pose) whose footprint does not fit the LDS tile, and any
 // neighbour outside the footprint bound, goes to / comes from global memory directly.

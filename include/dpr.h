@@ -71,12 +71,13 @@ extern "C" {
 #define DPR_ALGO_TILED 2  /* per-pose binning of points into voxel tiles, LDS-resident
                              tile accumulation, plain-store flush (no global atomics) */
 #define DPR_ALGO_CHUNKED 3 /* chunks of consecutive points of a spatially coherent cloud.
-                              2-D grids (projections; what AUTO picks for >= 4 poses): a
+                              2-D grids (projections; what AUTO picks for several poses of a
+                              cloud, by a cost model -- dpr_resolve_algo_ex): a
                               block owns a chunk of 4096 points and an LDS tile under its
                               small projected footprint, and loops over the poses -- forward:
                               LDS accumulation + row-shaped global atomic flush, pullback:
                               LDS-staged ds_dout, gradients in registers across poses, no
-                              atomics.  The points are Morton-sorted into the workspace first
+                              atomics.  The points are Hilbert-sorted into the workspace first
                               unless DPR_FLAG_COHERENT_POINTS says they already are.
                               3-D grids (experimental): chunks of 64 points are listed per
                               voxel tile, tiles read the points in place.
@@ -109,7 +110,7 @@ extern "C" {
 #define DPR_FLAG_MAX_POSE_GROUP(n) (((unsigned)(n) & 0xffu) << 8)
 /* DPR_FLAG_COHERENT_POINTS: the caller states that neighbouring points in memory are
  * neighbours in space (e.g. the output of dpr_sort_points_*).  DPR_ALGO_CHUNKED on 2-D grids
- * then skips its own Morton sort (and the workspace shrinks to the per-pose partial sums).
+ * then skips its own Hilbert sort (and the workspace shrinks to the per-pose partial sums).
  * A wrong claim costs speed, never correctness. */
 #define DPR_FLAG_COHERENT_POINTS 4u
 
