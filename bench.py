@@ -248,16 +248,55 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --force-exchange: a one-rank RCCL group, no launcher needed
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
     cfg = args.config or ("C3" if world == 1 else "C4")
+    if args.force_exchange and not CONFIGS[cfg]["B"] > 1:
+        raise SystemExit("--force-exchange drives the pose-sharded exchange: use a batched config (C4, C5)")
+    line = run_job(args, cfg, rank, world, device, dist, backend)
+    if world == 1 and args.config is None and not args.no_scaling_reference and not args.force_exchange:
+        # The N > 1 runs of this script time another job than the metric's C3 (C4: 512 poses,
+        # strong scaling).  Its one-GPU point, measured here in the same process, is what
+        # value(N) of an N-GPU line has to be divided by for same-job scaling.
+        ref_args = argparse.Namespace(**vars(args))
+        ref_args.config, ref_args.poses, ref_args.order, ref_args.coherent = "C4", None, "random", False
+        ref_args.dist, ref_args.algo, ref_args.shard = "gauss", "auto", None
+        ref_args.steps, ref_args.warmup = max(2, min(args.steps, 5)), 1
+        torch.cuda.empty_cache()
+        ref = run_job(ref_args, "C4", rank, world, device, dist, backend, lean=True)
+        line["scaling_reference"] = {
+            "what": "the job of the --gpus N > 1 runs (C4: 10M points -> 512^2, 512 poses, fwd+bwd, "
+                    "AUTO) on ONE GPU, same process: value(N) / this value = same-job strong scaling",
+            "command": "python bench.py --config C4 --gpus 1",
+            "value": ref["value"], "unit": ref["unit"], "ms_per_step": ref["ms_per_step"],
+            "steps": ref["steps"], "warmup": ref["warmup"], "poses_global": ref["config"]["poses_global"],
+            "algo": ref["config"]["algo"],
+            "pullback_reuses_forward_binning": ref["config"]["pullback_reuses_forward_binning"],
+        }
+    if rank == 0:
+        print(json.dumps(line, ensure_ascii=False), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
+    """One measured job on this rank; returns the JSON line (rank 0 prints it).  `lean`: only
+    the timed steps (no stage split, no no-share / coherent / CPU secondary measurements)."""
+    import torch
+
+    import dpr_amd
+
     c = CONFIGS[cfg]
     P, n_in, grid, dt = c["P"], c["n_in"], c["grid"], c["dt"]
     n_out = len(grid)
@@ -354,7 +393,10 @@ def run_rank(args):
     # default step k's all-reduce runs on RCCL's stream under step k+1's kernels (double buffer;
     # every all-reduce completes inside the timed region).  Point sharding: the forward
     # all-reduces the grid, the pullback the per-pose scalars (13 values), inside the step.
-    pose_exchange = world > 1 and shard == "poses" and do_bwd
+    # --force-exchange: the N-rank exchange step (double buffer, async all-reduce, wait before
+    # the buffer is written again) over a ONE-rank RCCL group -- the code path of every N > 1 run,
+    # executable on a one-GPU box
+    pose_exchange = (world > 1 or args.force_exchange) and shard == "poses" and do_bwd
     overlap = pose_exchange and backend == "nccl" and not args.no_overlap_exchange
     fused_alt = torch.empty_like(fused) if overlap else None
     pending = [None, None]
@@ -454,7 +496,7 @@ def run_rank(args):
     if batched:
         roof["note"] = ("batched poses re-read the points per pose (group): the per-call "
                         "algorithmic bytes count them once, BASELINE.md section 3")
-    if single_call and B_local == 1:
+    if single_call and B_local == 1 and not lean:
         local = args.coherent and algo_f == "tiled" and n_out == 3 or (args.coherent and algo_f == "tiled")
         sname = lambda a: ("tiled_local" if (local and a == "tiled") else
                            ("chunked2d" if (a == "chunked" and n_out == 2) else a))
@@ -481,7 +523,7 @@ def run_rank(args):
                                            "frac": round(gbs(a_fwd, ms_alone) / HBM_PEAK_GBS, 4)}
 
     exchange = "none"
-    if world > 1 and shard == "poses" and do_bwd:
+    if pose_exchange:
         exchange = (f"all-reduce(sum) of [ds_dpoints|ds_dpoint_weight] ({backend})"
                     + (", overlapped with the next step's kernels (double buffer)" if overlap
                        else ", inside the step"))
@@ -509,7 +551,7 @@ def run_rank(args):
                if world > 1 else {})},
         "roofline": roof,
     }
-    if can_share and not args.no_share_binning and world == 1:
+    if can_share and not args.no_share_binning and world == 1 and not lean:
         # the drop-in number: plain entry points (no KEEP/REUSE flags), the pullback re-bins
         for _ in range(max(1, args.warmup)):
             step(False)
@@ -520,7 +562,7 @@ def run_rank(args):
                             "what": "pullback re-bins (plain dpr_raster_* / dpr_raster_pullback_* "
                                     "entry points, no DPR_FLAG_KEEP/REUSE_BINNING)"}
     if (world == 1 and args.order == "random" and not args.coherent and not args.no_secondary
-            and cfg in ("C2", "C3")):
+            and cfg in ("C2", "C3") and not lean):
         # secondary line: the same cloud pre-sorted once in the model frame (Morton order; the
         # sort is pose-independent, so a user amortises it over poses and iterations)
         sorted_pts, _perm = dpr_amd.sort_points(points)  # dpr_sort_points_f32
@@ -567,15 +609,12 @@ def run_rank(args):
             coh["pullback_ms"] = round(st_bm["total"], 4)
         line["coherent_input"] = coh
         points = points_random
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not lean:
         np_g = None
         if do_bwd:
             np_g = (g[..., :2] if batched else g).cpu().numpy()
         line["cpu_baseline"] = cpu_baseline(cfg, np_pts, np_R, np_t, np_g, args.cpu_budget)
-    if rank == 0:
-        print(json.dumps(line, ensure_ascii=False), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -597,6 +636,11 @@ def main():
     ap.add_argument("--coherent", action="store_true",
                     help="pass DPR_FLAG_COHERENT_POINTS (the caller vouches for a sorted cloud)")
     ap.add_argument("--dist", default="gauss", choices=["gauss", "uniform", "tight"])
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="--gpus 1 with a batched config: run the pose-sharded exchange step of the "
+                         "N > 1 runs (double-buffered async all-reduce) over a one-rank RCCL group")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="--gpus 1 default run: skip the one-GPU point of the N > 1 job (C4, 512 poses)")
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: finish each step's all-reduce before the next step starts")
     ap.add_argument("--no-share-binning", action="store_true",

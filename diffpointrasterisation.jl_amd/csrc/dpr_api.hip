@@ -77,6 +77,7 @@ static PairCost other_cost(int n_out, const int64_t* grid, int64_t P, int64_t B)
 static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid, int64_t G,
                                int64_t P, int64_t B, bool coherent) {
     if (n_out != 2 || P >= ((int64_t)1 << 32) || P < 1 || B < 1) return false;
+    if (B > 65535 * 64) return false;  // the chunk-owner kernels' grid.y (pose slices of <= 64)
     const PairCost c = chunkown_cost(n_in, G, P, B, coherent), o = other_cost(n_out, grid, P, B);
     const double margin = 0.85;  // stay with the established paths unless clearly ahead
     if (op == DPR_OP_RASTER) return c.fwd < margin * o.fwd;

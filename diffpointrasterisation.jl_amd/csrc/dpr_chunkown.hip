@@ -556,12 +556,12 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
 // (scalar, pose).
 template <typename T, int NI>
 __global__ __launch_bounds__(256) void k_co_reduce(const double* __restrict__ partials, int64_t B,
-                                                   int64_t nblk, T* __restrict__ d_rot,
+                                                   int64_t b0, int64_t nblk, T* __restrict__ d_rot,
                                                    T* __restrict__ d_trans,
                                                    T* __restrict__ d_ow) {
     __shared__ double wsum[4];
     const int q = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    const int64_t b = b0 + blockIdx.y;  // grid.y holds at most 65535 poses per launch
     const double* src = partials + ((size_t)q * B + b) * nblk;
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < nblk; i += 256) s += src[i];
@@ -629,6 +629,7 @@ static COPlan co_plan(size_t elem, int op, unsigned flags, int n_in, int64_t P, 
     int64_t slices = 1;
     if (pl.nblk < 1024 && B > 1) slices = (1024 + pl.nblk - 1) / pl.nblk;
     if (slices > B) slices = B;
+    if (slices < 1) slices = 1;  // B == 0 (accepted by check_common): no division by zero
     int64_t pps = (B + slices - 1) / slices;
     if (pps > kCOMaxSlice) pps = kCOMaxSlice;
     if (pps < 1) pps = 1;
@@ -678,6 +679,9 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
     const COPlan pl = co_plan(sizeof(T), DPR_OP_RASTER, flags, NI, P, B);
+    if (pl.slices > 65535)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: at most %d poses per call",
+                    65535 * kCOMaxSlice);
     const bool sort = !(flags & DPR_FLAG_COHERENT_POINTS);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED raster needs %zu workspace bytes, got %zu",
@@ -754,6 +758,9 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
     const COPlan pl = co_plan(sizeof(T), DPR_OP_PULLBACK, flags, NI, P, B);
+    if (pl.slices > 65535)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: at most %d poses per call",
+                    65535 * kCOMaxSlice);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_CHUNKED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -829,8 +836,11 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
         DPR_HIP(hipMemsetAsync(partials, 0, (size_t)(2 * NI + 3) * (size_t)B * pl.nblk * 8, st));
     }
     stage_mark(st);
-    hipLaunchKernelGGL((k_co_reduce<T, NI>), dim3(2 * NI + 3, (unsigned)B), dim3(256), 0, st,
-                       (const double*)partials, B, pl.nblk, d_rot, d_trans, d_ow);
+    for (int64_t b0 = 0; b0 < B; b0 += 65535) {
+        const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
+        hipLaunchKernelGGL((k_co_reduce<T, NI>), dim3(2 * NI + 3, (unsigned)nb), dim3(256), 0, st,
+                           (const double*)partials, B, b0, pl.nblk, d_rot, d_trans, d_ow);
+    }
     if (sort && P > 0)
         hipLaunchKernelGGL((k_co_unsort<T, NI>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
                            P, (const uint32_t*)(ws + pl.off_perm), (const T*)gp, (const T*)gw, d_pts,

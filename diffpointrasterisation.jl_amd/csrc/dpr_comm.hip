@@ -14,13 +14,20 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include <rccl/rccl.h>
 
 #include "../../include/dpr.h"
 #include "dpr_tiled.h"
+
+struct dpr_comm {
+    ncclComm_t comm;
+    int world, rank;
+};
 
 namespace dpr {
 
@@ -34,6 +41,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)();
     const char* (*GetErrorString)(ncclResult_t);
     bool ok;
+    char why[256];  // why the binding failed (dlopen's message, captured once)
 };
 
 static const RcclApi& rccl() {
@@ -44,7 +52,11 @@ static const RcclApi& rccl() {
             h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (h) break;
         }
-        if (!h) return a;
+        if (!h) {
+            const char* e = dlerror();  // one call: it clears the message
+            snprintf(a.why, sizeof(a.why), "%s", e ? e : "dlopen failed");
+            return a;
+        }
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
@@ -54,6 +66,7 @@ static const RcclApi& rccl() {
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GroupStart &&
                a.GroupEnd && a.GetErrorString;
+        if (!a.ok) snprintf(a.why, sizeof(a.why), "a required nccl* symbol is missing");
         return a;
     }();
     return api;
@@ -61,8 +74,7 @@ static const RcclApi& rccl() {
 
 static int need_rccl() {
     if (!rccl().ok)
-        return fail(DPR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s",
-                    dlerror() ? dlerror() : "symbols missing");
+        return fail(DPR_ERR_HIP, "RCCL (librccl.so.1) could not be loaded: %s", rccl().why);
     return DPR_OK;
 }
 
@@ -74,12 +86,60 @@ static int need_rccl() {
                              dpr::rccl().GetErrorString(r_));                              \
     } while (0)
 
+
+// The exchange step of dpr_raster_pullback_sharded_*: ONE all-reduce(sum) when the caller fused
+// [ds_dpoints | ds_dpoint_weight] into one buffer, else a group of two.
+//
+// A rank whose LOCAL pullback failed (rc_local != 0: e.g. a workspace sized for another rank's
+// B_local) must not simply return: its peers are already inside -- or on their way into -- the
+// collective and would block forever.  Defined behaviour: when the rank's two gradient buffers
+// are usable (non-NULL, P > 0) it fills them with NaN (all-ones bytes), JOINS the all-reduce --
+// every rank then sees NaN point gradients, loud instead of silently short of one rank's poses --
+// and returns its own error code afterwards.  Only when the buffers themselves are unusable
+// (NULL) can the rank not take part; the error text then says that the communicator has to be
+// torn down (dpr_comm_destroy on every rank) because the peers are blocked.
+template <typename T>
+static int sharded_exchange(dpr_comm_t* comm, hipStream_t st, int rc_local, int n_in, int64_t P,
+                            T* ds_dpoints, T* ds_dpoint_weight, ncclDataType_t dt) {
+    if (P <= 0) return rc_local;  // nothing to exchange (every rank sees the same P)
+    std::string local_msg;
+    if (rc_local != DPR_OK) {
+        local_msg = dpr_last_error();
+        if (!ds_dpoints || !ds_dpoint_weight)
+            return fail(rc_local,
+                        "%s -- this rank cannot join the all-reduce (gradient buffers are NULL): "
+                        "the other ranks block in it; destroy the communicator on every rank",
+                        local_msg.c_str());
+        (void)hipMemsetAsync(ds_dpoints, 0xff, sizeof(T) * (size_t)P * n_in, st);
+        (void)hipMemsetAsync(ds_dpoint_weight, 0xff, sizeof(T) * (size_t)P, st);
+    }
+    ncclResult_t r = ncclSuccess;
+    if (ds_dpoint_weight == ds_dpoints + (size_t)P * n_in) {
+        r = rccl().AllReduce(ds_dpoints, ds_dpoints, (size_t)P * (n_in + 1), dt, ncclSum,
+                             comm->comm, st);
+    } else {
+        r = rccl().GroupStart();
+        if (r == ncclSuccess) {
+            // an open group is always closed, whatever the calls inside return
+            const ncclResult_t r1 = rccl().AllReduce(ds_dpoints, ds_dpoints, (size_t)P * n_in, dt,
+                                                     ncclSum, comm->comm, st);
+            const ncclResult_t r2 = rccl().AllReduce(ds_dpoint_weight, ds_dpoint_weight, (size_t)P,
+                                                     dt, ncclSum, comm->comm, st);
+            const ncclResult_t r3 = rccl().GroupEnd();
+            r = r1 != ncclSuccess ? r1 : (r2 != ncclSuccess ? r2 : r3);
+        }
+    }
+    if (rc_local != DPR_OK)
+        return fail(rc_local, "%s (this rank joined the all-reduce with NaN gradients)",
+                    local_msg.c_str());
+    if (r != ncclSuccess)
+        return fail(DPR_ERR_HIP, "all-reduce of the point gradients failed: %s",
+                    rccl().GetErrorString(r));
+    return DPR_OK;
+}
+
 }  // namespace dpr
 
-struct dpr_comm {
-    ncclComm_t comm;
-    int world, rank;
-};
 
 extern "C" {
 
@@ -122,6 +182,11 @@ int dpr_comm_rank(const dpr_comm_t* comm) { return comm ? comm->rank : -1; }
 void dpr_shard_range(int64_t batch, int rank, int world, int64_t* lo, int64_t* hi) {
     // contiguous pose blocks whose sizes differ by at most one (ChunkSplitters.chunks,
     // src/raster_pullback.jl:117)
+    if (world < 1 || rank < 0 || rank >= world || batch < 0) {  // no valid block: an empty range
+        if (lo) *lo = 0;
+        if (hi) *hi = 0;
+        return;
+    }
     const int64_t base = batch / world, rem = batch % world;
     const int64_t l = rank * base + (rank < rem ? rank : rem);
     if (lo) *lo = l;
@@ -137,29 +202,13 @@ void dpr_shard_range(int64_t batch, int rank, int world, int64_t* lo, int64_t* h
         T* ds_dout_weight_local, T* ds_dpoint_weight, void* workspace, size_t workspace_bytes) {  \
         if (!comm) return dpr::fail(DPR_ERR_INVALID_ARG, "dpr_raster_pullback_sharded: comm is NULL"); \
         if (int rc = dpr::need_rccl()) return rc;                                                 \
-        if (int rc = dpr_raster_pullback_##SUF(stream, n_in, n_out, grid, P, B_local,             \
-                                               ds_dout_local, points, rotation_local,             \
-                                               translation_local, out_weight_local, point_weight, \
-                                               ds_dpoints, ds_drotation_local,                    \
-                                               ds_dtranslation_local, ds_dbackground_local,       \
-                                               ds_dout_weight_local, ds_dpoint_weight, workspace, \
-                                               workspace_bytes))                                  \
-            return rc;                                                                            \
-        if (P == 0) return DPR_OK;                                                                \
-        hipStream_t st = (hipStream_t)stream;                                                     \
-        /* one all-reduce when the caller fused [ds_dpoints | ds_dpoint_weight], else a group */  \
-        if (ds_dpoint_weight == ds_dpoints + (size_t)P * n_in) {                                  \
-            DPR_NCCL(dpr::rccl().AllReduce(ds_dpoints, ds_dpoints, (size_t)P * (n_in + 1), NCCLT, \
-                                           ncclSum, comm->comm, st));                             \
-        } else {                                                                                  \
-            DPR_NCCL(dpr::rccl().GroupStart());                                                   \
-            DPR_NCCL(dpr::rccl().AllReduce(ds_dpoints, ds_dpoints, (size_t)P * n_in, NCCLT,       \
-                                           ncclSum, comm->comm, st));                             \
-            DPR_NCCL(dpr::rccl().AllReduce(ds_dpoint_weight, ds_dpoint_weight, (size_t)P, NCCLT,  \
-                                           ncclSum, comm->comm, st));                             \
-            DPR_NCCL(dpr::rccl().GroupEnd());                                                     \
-        }                                                                                         \
-        return DPR_OK;                                                                            \
+        const int rc_local = dpr_raster_pullback_##SUF(                                           \
+            stream, n_in, n_out, grid, P, B_local, ds_dout_local, points, rotation_local,         \
+            translation_local, out_weight_local, point_weight, ds_dpoints, ds_drotation_local,    \
+            ds_dtranslation_local, ds_dbackground_local, ds_dout_weight_local, ds_dpoint_weight,  \
+            workspace, workspace_bytes);                                                          \
+        return dpr::sharded_exchange<T>(comm, (hipStream_t)stream, rc_local, n_in, P, ds_dpoints, \
+                                        ds_dpoint_weight, NCCLT);                                 \
     }
 DPR_DEFINE_SHARDED(f32, float, ncclFloat)
 DPR_DEFINE_SHARDED(f64, double, ncclDouble)

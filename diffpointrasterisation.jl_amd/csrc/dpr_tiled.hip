@@ -336,6 +336,7 @@ struct alignas(16) BinHeader {
     int32_t grid[3];
     uint32_t verdict;  // written by the consuming pullback's first kernel: 1 = header matched
     uint64_t points, pw;
+    uint32_t layout, pad_[3];  // plan_layout_id() of the workspace layout the binning was written in
     unsigned char pose[96];  // rotation | translation bytes of pose 0 (<= 9 + 3 doubles)
 };
 template <typename T, int NI, int NO>
@@ -360,7 +361,8 @@ __device__ __forceinline__ bool header_matches(const BinHeader* hdr, const BinHe
     bool ok = hdr->magic == kBinMagic && hdr->state == kBinValid && hdr->elem == want.elem &&
               hdr->n_in == want.n_in && hdr->n_out == want.n_out && hdr->has_pw == want.has_pw &&
               hdr->P == want.P && hdr->grid[0] == want.grid[0] && hdr->grid[1] == want.grid[1] &&
-              hdr->grid[2] == want.grid[2] && hdr->points == want.points && hdr->pw == want.pw;
+              hdr->grid[2] == want.grid[2] && hdr->points == want.points && hdr->pw == want.pw &&
+              hdr->layout == want.layout;
     const uint32_t* pose = (const uint32_t*)hdr->pose;
     for (int i = 0; i < rot_words; ++i) ok = ok && pose[i] == rot[i];
     for (int i = 0; i < trans_words; ++i) ok = ok && pose[rot_words + i] == trans[i];
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
             hdr_out->verdict = 0;
             hdr_out->points = hdr.points;
             hdr_out->pw = hdr.pw;
+            hdr_out->layout = hdr.layout;
         }
     }
     __shared__ uint32_t wsum[16], wslab[16];
@@ -988,6 +991,7 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
             hdr_out->verdict = 0;
             hdr_out->points = hdr.points;
             hdr_out->pw = hdr.pw;
+            hdr_out->layout = hdr.layout;
         }
     }
     __shared__ uint32_t wsum[16], wslab[16];
@@ -2486,6 +2490,33 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     return pl;
 }
 
+// Identity of a workspace layout: a REUSE_BINNING pullback must read the lists where -- and in
+// the form in which -- the KEEP_BINNING forward wrote them.  The two calls compute their plans
+// independently (DPR_FLAG_COHERENT_POINTS, DPR_FLAG_MAX_POSE_GROUP and the environment knobs all
+// move regions), so the forward stores this id in the header and the pullback's kernels compare
+// it on the device like the rest of the header.
+static uint32_t plan_layout_id(const Plan& pl) {
+    uint64_t h = 1469598103934665603ull;  // FNV-1a over the fields that place or shape the lists
+    auto mix = [&](uint64_t v) {
+        for (int i = 0; i < 8; ++i) {
+            h ^= (v >> (8 * i)) & 0xffu;
+            h *= 1099511628211ull;
+        }
+    };
+    mix(pl.local ? 1 : 0);
+    mix((uint64_t)pl.bg);
+    mix((uint64_t)pl.sub);
+    mix((uint64_t)pl.cap);
+    mix(pl.off_items);
+    mix(pl.off_rec);
+    mix(pl.off_idx);
+    mix(pl.off_slot);
+    mix(pl.off_aux);
+    mix(pl.local ? pl.off_sdesc : 0);
+    const uint32_t id = (uint32_t)(h ^ (h >> 32));
+    return id ? id : 1u;
+}
+
 bool tiled_supported(int n_out, const int64_t* grid) {
     if (n_out == 3) {
         TileGeom<3> tg;
@@ -2644,6 +2675,7 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
     BinHeader hdr = make_header<T, NI, NO>(grid64, P, points, pw);
     hdr.state = keep_valid ? kBinValid : 0u;  // only a KEEP_BINNING forward may be reused
+    hdr.layout = plan_layout_id(pl);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, NTe, pl.cap, tile_start,
                        (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
                        (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
@@ -2703,6 +2735,7 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
     BinHeader hdr = make_header<T, NI, NO>(grid64, P, points, pw);
     hdr.state = keep_valid ? kBinValid : 0u;
+    hdr.layout = plan_layout_id(pl);
     hipLaunchKernelGGL(k_runscan, dim3(1), dim3(1024), 0, st, (const uint32_t*)ltot,
                        (const uint32_t*)(ltot + tg.NT), tg.NT, pl.cap,
                        (uint32_t*)(ws + pl.off_dstart), (uint32_t*)(ws + pl.off_dcursor),
@@ -2852,6 +2885,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
     const bool unperm1 = knobs().bwd_unpermute != 0;
     BinHeader want = make_header<T, NI, NO>(grid, P, points, pw);
+    want.layout = plan_layout_id(pl);
     if (!reuse) want.magic = 0;  // own binning: nothing to validate
     BinHeader* hdr = reuse ? (BinHeader*)(ws + pl.off_hdr) : (BinHeader*)nullptr;
     for (int64_t b = 0, nb = 1; b < B; b += nb) {

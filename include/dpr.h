@@ -98,9 +98,13 @@ extern "C" {
 /* A REUSE_BINNING pullback validates ON THE DEVICE that the workspace holds the binning of a
  * KEEP_BINNING forward with the same P, grid, element type, points / point_weight buffers and
  * pose values, and that no pullback has consumed it yet (the gradient records overwrite the
- * point records).  If not, nothing is read through the stale lists and all six outputs (and
- * `loss`) come back as NaN; the status is still 0 because the host cannot see the mismatch
- * without synchronising.
+ * point records), and that it was written in the workspace LAYOUT of this call (same
+ * DPR_FLAG_COHERENT_POINTS / DPR_FLAG_MAX_POSE_GROUP on both calls of the pair).  If not, nothing
+ * is read through the stale lists and the outputs come back as NaN; the status is still 0
+ * because the host cannot see the mismatch without synchronising.  Which outputs: DPR_ALGO_TILED
+ * -- all six and `loss`; DPR_ALGO_CHUNKED on 2-D grids (what is reused there is the sorted copy of
+ * the cloud) -- ds_dpoints, ds_dpoint_weight, ds_drotation, ds_dtranslation and ds_dout_weight,
+ * while ds_dbackground and `loss` do not depend on the points and stay valid.
  *
  * DPR_FLAG_MAX_POSE_GROUP(n), n in 1..16 (0 = library default 16): DPR_ALGO_TILED bins up to n
  * poses of a batch together when the grid has few tiles (n * tiles <= 4096).  Larger groups are
@@ -158,7 +162,11 @@ size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int6
                                int64_t P, int64_t B);
 size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B);
-/* The same for a call that will pass `flags` (only DPR_FLAG_MAX_POSE_GROUP changes the size). */
+/* The same for a call that will pass `flags`: query with EXACTLY the flags of the call.
+ * DPR_FLAG_MAX_POSE_GROUP and DPR_FLAG_COHERENT_POINTS change the layout (and the size) of the
+ * tiled and the chunk-owner workspaces, and with DPR_ALGO_AUTO the KEEP / REUSE flags take part
+ * in choosing the algorithm (see dpr_resolve_algo_ex).  A workspace that serves a KEEP raster
+ * and its REUSE pullback is the larger of the two queries. */
 size_t dpr_workspace_bytes_ex_f32(int op, int algo, unsigned flags, int n_in, int n_out,
                                   const int64_t *grid, int64_t P, int64_t B);
 size_t dpr_workspace_bytes_ex_f64(int op, int algo, unsigned flags, int n_in, int n_out,
@@ -300,7 +308,15 @@ void dpr_shard_range(int64_t batch, int rank, int world, int64_t *lo, int64_t *h
 /* dpr_raster_pullback_<T> on this rank's B_local poses (all `_local` arguments are the rank's
  * slices), then all-reduce(sum) of ds_dpoints / ds_dpoint_weight over the communicator on
  * `stream`: after the call they hold the global sums on every rank.  One all-reduce when the two
- * buffers are adjacent (ds_dpoint_weight == ds_dpoints + n_in * P), a grouped pair otherwise. */
+ * buffers are adjacent (ds_dpoint_weight == ds_dpoints + n_in * P), a grouped pair otherwise.
+ *
+ * When the LOCAL pullback of a rank fails (non-zero status, e.g. a workspace sized for another
+ * rank's B_local) the rank still JOINS the all-reduce, with its two gradient buffers filled with
+ * NaN, and returns its own error afterwards: no peer is left blocked in the collective, and every
+ * rank sees NaN point gradients instead of sums that silently miss one rank's poses.  Only a rank
+ * whose gradient buffers are NULL cannot take part; its error text says so, and the communicator
+ * must then be destroyed on every rank (the peers are blocked).  dpr_shard_range with an invalid
+ * (rank, world) yields the empty range [0, 0). */
 int dpr_raster_pullback_sharded_f32(dpr_comm_t *comm, void *stream, int n_in, int n_out,
                                     const int64_t *grid, int64_t P, int64_t B_local,
                                     const float *ds_dout_local, const float *points,

@@ -310,42 +310,11 @@ function raster_pullback_reuse!(ds_dout::ROCArray{T,N_out}, points::ROCVector{<:
             point_weight=o_pw)
 end
 
-@static if isdefined(Base, :get_extension) && Base.find_package("ChainRulesCore") !== nothing
-    import ChainRulesCore
-    function ChainRulesCore.rrule(
-        ::typeof(DiffPointRasterisation.raster),
-        grid_size,
-        points::ROCVector{<:StaticVector{N_in,T}},
-        rotation::AbstractMatrix{<:Number},
-        translation::AbstractVector{<:Number},
-        optional_args...,
-    ) where {N_in,T<:Union{Float32,Float64}}
-        N_out = length(grid_size)
-        P = length(points)
-        bg = length(optional_args) >= 1 ? [T(optional_args[1])] : Zeros{T}(1)
-        ow = length(optional_args) >= 2 ? [T(optional_args[2])] : Ones{T}(1)
-        pw = length(optional_args) >= 3 ? optional_args[3] : Ones{T}(P)
-        out = similar(points, T, Tuple(grid_size))
-        ws = workspace_pair(T, N_in, N_out, collect(Int64, grid_size), P, 1)
-        rot_d, tr_d, ow_d, pw_d = raster_keep!(out, points, rotation, translation, bg, ow, pw, ws)
-        consumed = Ref(false)
-        function raster_pullback(ds_dout)
-            g = devbuf(ChainRulesCore.unthunk(ds_dout), T)
-            pb = if consumed[]   # a second call through the same closure re-bins (generic path)
-                DiffPointRasterisation.raster_pullback!(g, points, rotation, translation, optional_args...)
-            else
-                consumed[] = true
-                raster_pullback_reuse!(g, points, rot_d, tr_d, ow_d, pw_d, ws)
-            end
-            ds_dpoints = reinterpret(reshape, SVector{N_in,T}, pb.points)
-            single = (dropdims(pb.rotation; dims=3), vec(pb.translation),
-                      sum(pb.background), sum(pb.out_weight), pb.point_weight)
-            return ChainRulesCore.NoTangent(), ChainRulesCore.NoTangent(), ds_dpoints,
-                   single[1:(2 + length(optional_args))]...
-        end
-        return out, raster_pullback
-    end
-end
+# The ChainRules `rrule` for ROCArray points (forward keeps the binning, the pullback closure
+# reuses it: `raster_keep!` / `raster_pullback_reuse!` above) needs BOTH AMDGPU and ChainRulesCore
+# and therefore lives in its own two-trigger extension,
+# ext/DiffPointRasterisationAMDGPUChainRulesCoreExt.jl -- the same mechanism the reference uses
+# for its single-trigger ones (/root/reference/Project.toml:16-22).
 
 # ---- multi-GPU: pose sharding over RCCL (one Julia process or task per GPU) -------------------
 # `comm = dpr_comm(world, rank, id)` with `id = dpr_comm_unique_id()` created on rank 0 and shipped
@@ -355,12 +324,22 @@ end
 mutable struct DprComm
     handle::Ptr{Cvoid}
 end
+# Collective teardown belongs at a point of the program every rank reaches: call `close(comm)`
+# explicitly.  The finalizer is a last resort only (the garbage collector runs it at an arbitrary
+# time, possibly while a peer is inside a collective); it does nothing after `close`.
+function Base.close(c::DprComm)
+    h = c.handle
+    c.handle = C_NULL
+    h == C_NULL || check(ccall((:dpr_comm_destroy, libdpr), Cint, (Ptr{Cvoid},), h))
+    return nothing
+end
+Base.isopen(c::DprComm) = c.handle != C_NULL
 dpr_comm_unique_id() = (id = zeros(UInt8, 128); check(ccall((:dpr_comm_unique_id, libdpr), Cint, (Ptr{UInt8}, Csize_t), id, 128)); id)
 function dpr_comm(world::Integer, rank::Integer, id::Vector{UInt8})
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:dpr_comm_init, libdpr), Cint, (Ptr{Ptr{Cvoid}}, Cint, Cint, Ptr{UInt8}), h, world, rank, id))
     c = DprComm(h[])
-    finalizer(x -> ccall((:dpr_comm_destroy, libdpr), Cint, (Ptr{Cvoid},), x.handle), c)
+    finalizer(x -> (x.handle == C_NULL || ccall((:dpr_comm_destroy, libdpr), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), c)
     return c
 end
 function shard_range(batch::Integer, rank::Integer, world::Integer)   # 1-based, inclusive

@@ -118,6 +118,21 @@ def test_shard_range_is_a_partition():
                 assert b == c
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+    # an invalid (rank, world) is an empty range, not a division by zero
+    for rank, world in [(0, 0), (0, -1), (3, 2), (-1, 4)]:
+        lo, hi = ctypes.c_int64(7), ctypes.c_int64(7)
+        L.dpr_shard_range(10, rank, world, ctypes.byref(lo), ctypes.byref(hi))
+        assert (lo.value, hi.value) == (0, 0)
+
+
+def test_chunk_owner_workspace_query_with_no_poses():
+    """B == 0 is a valid (empty) batch: the chunk-owner plan must not divide by it."""
+    L = dpr_amd.lib()
+    grid = (ctypes.c_int64 * 2)(64, 64)
+    for op in (0, 1):
+        for flags in (0, 4):
+            n = L.dpr_workspace_bytes_ex_f32(op, 3, flags, 3, 2, grid, 100_000, 0)
+            assert n != ctypes.c_size_t(-1).value and n > 0
 
 
 def test_auto_algorithm_and_workspace_queries_need_no_device():

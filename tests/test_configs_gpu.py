@@ -56,6 +56,10 @@ def test_c4_share_64_poses(dev):
     pose, a pose of the batch == the single-pose call, adjoint identity
     <g, out - bg> = ow * d/d(ow) per pose, ds_dbackground = sum(ds_dout)."""
     P, n, B = 10_000_000, 512, 64
+    # the path this test is meant to cover: AUTO must resolve to the chunk-owner algorithm here
+    # (a cost-model edit that moved C4 back to the tiled path would otherwise pass unnoticed)
+    assert dpr_amd.resolve_algo("raster", (n, n), P, B, 3) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (n, n), P, B, 3) == "chunked"
     f32 = dict(device=dev, dtype=torch.float32)
     pts = _ball_points(P, dev, torch.float32)
     rng = np.random.default_rng(5)
@@ -418,6 +422,128 @@ def test_c2_full_size_auto_vs_oracle_with_flip_report(oracle, dev):
             json.dump(report, f, indent=1)
 
 
+def test_c3_full_size_auto_vs_oracle_with_flip_report(oracle, dev):
+    """BASELINE.json configs[2] at full size ON THE CLOUD bench.py TIMES (10 M points
+    0.4*N(0,I) seed 0 in as-generated order, one random rotation, t = 0.1*N(0,I); 256^3, fp32),
+    algo="auto" (the tiled pipeline), forward + pullback against the fp32 oracle and `out`
+    against the fp64 oracle; SURVEY.md 8(c) report to gpurun_out/parity_report_c3.json."""
+    import bench
+
+    P, n = 10_000_000, 256
+    assert dpr_amd.resolve_algo("raster", (n,) * 3, P, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (n,) * 3, P, 1, 3) == "tiled"
+    pts = bench.synth_points("C3")
+    R, t = bench.synth_poses("C3", 1, seed=1)
+    assert pts.shape == (P, 3) and pts.dtype == np.float32
+    g = np.asfortranarray(np.random.default_rng(2).standard_normal(size=(n, n, n, 1), dtype=np.float32))
+    ref32 = oracle.raster((n,) * 3, pts, R, t, dtype=np.float32)
+    ref64 = oracle.raster((n,) * 3, pts, R, t, dtype=np.float64)
+    dp, dR, dt_ = T(pts, dev), T(R[0], dev), T(t[0], dev)
+    out = dpr_amd.raster((n,) * 3, dp, dR, dt_)  # algo="auto"
+    o = out.cpu().numpy()
+    assert_close(o, ref32[..., 0], tol(np.float32, "out"), "out vs fp32 oracle")
+    assert_close(o, ref64[..., 0].astype(np.float32), 5e-5, "out vs fp64 oracle")
+    rpb = oracle.raster_pullback(g, pts, R, t, dtype=np.float32)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g[..., 0], dev), dp, dR, dt_)
+    assert_close(pb.points, rpb.points, tol(np.float32, "points"), "ds_dpoints")
+    assert_close(pb.point_weight, rpb.point_weight, tol(np.float32, "points"), "ds_dpoint_weight")
+    assert_close(pb.rotation, rpb.rotation[0], tol(np.float32, "pose"), "ds_drotation")
+    assert_close(pb.translation, rpb.translation[0], tol(np.float32, "pose"), "ds_dtranslation")
+    assert abs(float(pb.out_weight) - rpb.out_weight[0]) <= 1e-3 * abs(rpb.out_weight[0]) + 1e-3
+    # the bench step's own pairing: forward keeps the binning, the pullback reuses it
+    ws = torch.empty(dpr_amd.workspace_bytes("pullback", (n,) * 3, P, 1, 3, torch.float32, "tiled"),
+                     dtype=torch.uint8, device=dev)
+    out_k = dpr_amd.empty_grid((n,) * 3, None, torch.float32, dev)
+    dpr_amd.raster_(out_k, dp, dR, dt_, algo="tiled", workspace=ws, keep_binning=True)
+    pb_k = dpr_amd.raster_pullback_(grid_to_dev(g[..., 0], dev), dp, dR, dt_, algo="tiled",
+                                    workspace=ws, reuse_binning=True)
+    assert_close(out_k, ref32[..., 0], tol(np.float32, "out"), "out (keep) vs fp32 oracle")
+    assert_close(pb_k.points, rpb.points, tol(np.float32, "points"), "ds_dpoints (reuse)")
+    report = {
+        "config": "C3: 10M points 0.4*N(0,I) seed 0, random order -> 256^3 fp32, algo=auto (tiled); "
+                  "the cloud and pose bench.py times",
+        "out_max_abs_err_vs_fp32_oracle": float(np.abs(o - ref32[..., 0]).max()),
+        "out_max_abs_err_vs_fp64_oracle": float(np.abs(o - ref64[..., 0]).max()),
+        "out_max_abs": float(np.abs(ref64).max()),
+        "out_rel_l2_err_vs_fp64_oracle": float(np.linalg.norm((o - ref64[..., 0]).ravel())
+                                               / np.linalg.norm(ref64.ravel())),
+        "ds_dpoints_max_abs_err_vs_fp32_oracle": float(np.abs(pb.points.cpu().numpy() - rpb.points).max()),
+        "ds_dpoints_equal_bit_for_bit": bool(np.array_equal(pb.points.cpu().numpy(), rpb.points)),
+        "ds_drotation_rel_err": float(np.linalg.norm(pb.rotation.cpu().numpy() - rpb.rotation[0])
+                                      / np.linalg.norm(rpb.rotation[0])),
+        "cell_selection_flips_fp32_vs_fp64": _cell_flips(pts, R[0], t[0], n),
+        "point_axis_pairs": 3 * P,
+    }
+    print("PARITY-REPORT " + json.dumps(report))
+    outdir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(outdir) and os.access(outdir, os.W_OK):
+        with open(os.path.join(outdir, "parity_report_c3.json"), "w") as f:
+            json.dump(report, f, indent=1)
+
+
+@pytest.mark.parametrize("algo", ["tiled", "atomic"])
+def test_pose_offset_beyond_2_pow_32_elements(oracle, dev, algo):
+    """Pose offsets b * G past 2^32 ELEMENTS: 33 poses of a 512^3 fp32 grid (17.7 GB per
+    array, pose 32 starts at element 4.29e9).  The last pose against the single-pose oracle,
+    forward and pullback (the other poses carry zero sensitivities, so the summed point
+    gradients are the last pose's alone).  Guards the int64 pose strides of the kernels at the
+    size of C5's one-GPU point (64 x 512^3)."""
+    P, n, B = 100_000, 512, 33
+    G = n ** 3
+    assert (B - 1) * G > 2 ** 32
+    rng = np.random.default_rng(11)
+    pts = (0.4 * rng.standard_normal(size=(P, 3))).astype(np.float32)
+    R = D.random_rotations(rng, B).astype(np.float32)
+    t = (0.1 * rng.normal(size=(B, 3))).astype(np.float32)
+    ow = np.linspace(0.5, 1.5, B).astype(np.float32)
+    bg = np.linspace(-1.0, 1.0, B).astype(np.float32)
+    out = dpr_amd.raster((n,) * 3, T(pts, dev), T(R, dev), T(t, dev), T(bg, dev), T(ow, dev), algo=algo)
+    last = B - 1
+    ref = oracle.raster((n,) * 3, pts, R[last:], t[last:], bg[last:], ow[last:], dtype=np.float32)
+    assert_close(out[..., last], ref[..., 0], tol(np.float32, "out"), "last pose of the batch")
+    assert_close(out[..., 0], oracle.raster((n,) * 3, pts, R[:1], t[:1], bg[:1], ow[:1],
+                                            dtype=np.float32)[..., 0], tol(np.float32, "out"), "pose 0")
+    del out
+    g = torch.zeros((B, n, n, n), dtype=torch.float32, device=dev)
+    g_last = rng.standard_normal(size=(n, n, n, 1), dtype=np.float32)
+    g[last] = torch.as_tensor(np.ascontiguousarray(np.transpose(g_last[..., 0], (2, 1, 0))), device=dev)
+    pb = dpr_amd.raster_pullback_(g.permute(3, 2, 1, 0), T(pts, dev), T(R, dev), T(t, dev), T(bg, dev),
+                                  T(ow, dev), algo=algo)
+    rpb = oracle.raster_pullback(np.asfortranarray(g_last), pts, R[last:], t[last:], ow[last:],
+                                 dtype=np.float32)
+    assert_close(pb.points, rpb.points, tol(np.float32, "points"), "ds_dpoints")
+    assert_close(pb.rotation[last], rpb.rotation[0], tol(np.float32, "pose"), "ds_drotation[last]")
+    assert_close(pb.translation[last], rpb.translation[0], tol(np.float32, "pose"), "ds_dtranslation[last]")
+    assert abs(float(pb.background[last]) - rpb.background[0]) <= 1e-3 * abs(rpb.background[0]) + 1e-2
+    assert abs(float(pb.out_weight[last]) - rpb.out_weight[0]) <= 1e-3 * abs(rpb.out_weight[0]) + 1e-3
+    assert float(pb.rotation[:last].abs().max()) == 0.0 and float(pb.background[:last].abs().max()) == 0.0
+
+
+def test_chunk_owner_with_more_than_65535_poses(oracle, dev):
+    """Every launch of the chunk-owner path that puts poses on grid.y is cut into blocks of at
+    most 65535 (round-2 advisor finding: k_co_reduce was not).  65 600 poses of a small cloud
+    on a 16 x 16 image; poses past the first launch block against the oracle."""
+    P, n, B = 300, 16, 65_600
+    rng = np.random.default_rng(3)
+    pts = (0.4 * rng.standard_normal(size=(P, 3))).astype(np.float32)
+    R = D.random_rotations(rng, B)[:, :2, :].astype(np.float32)
+    t = (0.1 * rng.normal(size=(B, 2))).astype(np.float32)
+    out = dpr_amd.raster((n, n), T(pts, dev), T(R, dev), T(t, dev), algo="chunked")
+    g = torch.randn((B, n, n), dtype=torch.float32, device=dev)
+    pb = dpr_amd.raster_pullback_(g.permute(2, 1, 0), T(pts, dev), T(R, dev), T(t, dev), algo="chunked")
+    pa = dpr_amd.raster_pullback_(g.permute(2, 1, 0), T(pts, dev), T(R, dev), T(t, dev), algo="atomic")
+    assert_close(pb.points, pa.points.cpu().numpy(), 1e-4, "ds_dpoints vs the direct kernels")
+    sel = [0, 65_534, 65_535, 65_536, B - 1]
+    ref = oracle.raster((n, n), pts, R[sel], t[sel], dtype=np.float32)
+    gs = np.asfortranarray(np.transpose(g[sel].cpu().numpy(), (2, 1, 0)))
+    rpb = oracle.raster_pullback(gs, pts, R[sel], t[sel], dtype=np.float32)
+    for k, b in enumerate(sel):
+        assert_close(out[..., b], ref[..., k], tol(np.float32, "out"), f"out pose {b}")
+        assert_close(pb.rotation[b], rpb.rotation[k], tol(np.float32, "pose"), f"ds_drotation {b}")
+        assert_close(pb.translation[b], rpb.translation[k], tol(np.float32, "pose"), f"ds_dtranslation {b}")
+        assert abs(float(pb.out_weight[b]) - rpb.out_weight[k]) <= 1e-3 * abs(rpb.out_weight[k]) + 1e-4
+
+
 # ------------------------------------------------------------------ the plain C entry points
 def _vp(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -594,3 +720,45 @@ def test_bench_two_ranks_over_rccl(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+
+
+def test_bench_pose_exchange_step_over_a_one_rank_rccl_group():
+    """The exchange step every `bench.py --gpus N > 1` run executes -- pose block from
+    shard_range, fused gradient buffer, double buffer, `dist.all_reduce(async_op=True)` over
+    "nccl" (= RCCL), `pending[k].wait()` before the buffer is written again, drain before the
+    closing barrier -- driven on ONE GPU with `--force-exchange` (a one-rank RCCL group).  The
+    two-rank test above is skipped on every one-GPU box; this one is not."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C4",
+                        "--poses", "6", "--force-exchange", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["steps"] == 3
+    ex = line["config"]["exchange"]
+    assert "all-reduce(sum)" in ex and "(nccl)" in ex and "overlapped" in ex, ex
+    # and serialised (no double buffer): the all-reduce completes inside each step
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C4",
+                         "--poses", "6", "--force-exchange", "--no-overlap-exchange", "--steps", "2",
+                         "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "inside the step" in json.loads(r2.stdout.strip().splitlines()[-1])["config"]["exchange"]
+
+
+def test_bench_default_line_carries_the_scaling_reference():
+    """`bench.py` at --gpus 1 keeps C3 as the headline and adds `scaling_reference`: the job of
+    the N > 1 runs (C4, 512 poses) on one GPU, so that a 1 -> N curve compares one job."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["workload"].startswith("C3") and line["scaling"] == "weak"
+    ref = line["scaling_reference"]
+    assert ref["poses_global"] == 512 and ref["value"] > 0 and ref["ms_per_step"] > 0
+    assert ref["algo"]["raster"] == "chunked"
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["ms"] > 0

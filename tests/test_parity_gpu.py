@@ -311,6 +311,23 @@ def test_reuse_binning_is_validated_on_the_device(oracle, dev):
     dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws, keep_binning=True)
     assert isnan(dpr_amd.raster_pullback_(g, pts.clone(), R, t, algo="tiled", workspace=ws,
                                           reuse_binning=True))
+    # (e) kept in ANOTHER WORKSPACE LAYOUT: coherent_points (local binning) on one call of the
+    # pair only -- the lists then live at other offsets, in another form (round-2 advisor finding)
+    ws_c = torch.zeros(dpr_amd.workspace_bytes("pullback", d.grid, d.n_points, 1, 3, torch.float32,
+                                               "tiled", coherent_points=True),
+                       dtype=torch.uint8, device=dev)
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws_c, keep_binning=True,
+                    coherent_points=True)
+    assert isnan(dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws_c,
+                                          reuse_binning=True))
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws_c, keep_binning=True)
+    assert isnan(dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws_c,
+                                          reuse_binning=True, coherent_points=True))
+    dpr_amd.raster_(out, pts, R, t, algo="tiled", workspace=ws_c, keep_binning=True,
+                    coherent_points=True)
+    pb_c = dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws_c,
+                                    reuse_binning=True, coherent_points=True)
+    assert_close(pb_c.points, ref.points, 1e-4, "ds_dpoints (coherent pair)")
     # and a pullback that re-bins is unaffected by whatever the workspace holds
     pb2 = dpr_amd.raster_pullback_(g, pts, R, t, algo="tiled", workspace=ws)
     assert_close(pb2.points, ref.points, 1e-4, "ds_dpoints (own binning)")
