@@ -357,7 +357,11 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
     # the pair of calls (include/dpr.h); the names are resolved here so that the no-share run and
     # the stage list use exactly the algorithms of the timed step.
     def shareable(a):
-        return (single_call and a in ("tiled", "chunked")) or (a == "chunked" and n_out == 2)
+        if (single_call and a in ("tiled", "chunked")) or (a == "chunked" and n_out == 2):
+            return True
+        # a batch on the tiled path: every pose keeps its own binning (B-fold records) where
+        # DPR_ALGO_AUTO judges that affordable (dpr_resolve_flags_ex)
+        return a == "tiled" and dpr_amd.sharing_effective(grid, P_local, Bq, n_in, **co)
 
     def algos(sharing):
         if args.algo != "auto":
@@ -370,10 +374,10 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
     share = can_share and not args.no_share_binning
     if not share:
         algo_f, algo_b = algos(sharing=False)
-    ws_bytes = max(dpr_amd.workspace_bytes("raster", grid, P_local, Bq, n_in, tdt, a, **co)
-                   for a in {algo_f, algo_b} | set(algos(False)))
-    ws_bytes = max(ws_bytes, *(dpr_amd.workspace_bytes("pullback", grid, P_local, Bq, n_in, tdt, a, **co)
-                               for a in {algo_f, algo_b} | set(algos(False))))
+    ws_bytes = max(dpr_amd.workspace_bytes(op, grid, P_local, Bq, n_in, tdt, a, sharing=sh, **co)
+                   for op in ("raster", "pullback")
+                   for a in {algo_f, algo_b} | set(algos(False))
+                   for sh in ({False, True} if share else {False}))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
 
     def fwd(keep=None):

@@ -39,7 +39,7 @@ ALGOS = {"auto": ALGO_AUTO, "atomic": ALGO_ATOMIC, "tiled": ALGO_TILED, "chunked
 
 EXPORTS = [
     "dpr_version", "dpr_last_error", "dpr_stage_timing_begin", "dpr_stage_timing_end",
-    "dpr_resolve_algo", "dpr_resolve_algo_ex", "dpr_sort_points_workspace_bytes", "dpr_sort_points_f32",
+    "dpr_resolve_algo", "dpr_resolve_algo_ex", "dpr_resolve_flags_ex", "dpr_sort_points_workspace_bytes", "dpr_sort_points_f32",
     "dpr_sort_points_f64",
     "dpr_workspace_bytes_f32", "dpr_workspace_bytes_f64",
     "dpr_workspace_bytes_ex_f32", "dpr_workspace_bytes_ex_f64",
@@ -98,6 +98,8 @@ def lib() -> ctypes.CDLL:
     L.dpr_resolve_algo.argtypes = [i, i, i, vp, i64, i64]
     L.dpr_resolve_algo_ex.restype = i
     L.dpr_resolve_algo_ex.argtypes = [i, ctypes.c_uint, i, i, vp, i64, i64]
+    L.dpr_resolve_flags_ex.restype = i
+    L.dpr_resolve_flags_ex.argtypes = [i, ctypes.c_uint, i, i, vp, i64, i64]
     L.dpr_sort_points_workspace_bytes.restype = sz
     L.dpr_sort_points_workspace_bytes.argtypes = [i64]
     for suf in ("f32", "f64"):

@@ -86,6 +86,24 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
     return c.fwd + c.bwd - (coherent ? 0.0 : sort_cost(pm)) < margin * (o.fwd + o.bwd);
 }
 
+// DPR_ALGO_CHUNKED on 3-D grids (chunk lists per tile, points read in place, one launch for all
+// poses): what AUTO picks for a FORWARD call over several poses of a cloud the caller vouches is
+// coherent, on a grid beyond the write-combining scatter's 4096 tiles -- there the tiled path
+// writes and re-reads a 16/32-byte record per (point, pose) through the plain scatter, the
+// chunk lists move 4 bytes per (chunk of 64 points, tile).  Measured (50 M points -> 512^3 fp64,
+// 8 poses, Hilbert-sorted, profiles/r03_chunked3d_regime.txt): 13.5 ms against 16.3 ms tiled.
+// Not for a KEEP/REUSE pair (nothing to keep) and not for the pullback (its per-pose gather
+// loses to the tiled one: 32 vs 24 ms).
+static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
+                                unsigned flags) {
+    if (op != DPR_OP_RASTER || n_out != 3 || (flags & 3u) || !(flags & DPR_FLAG_COHERENT_POINTS))
+        return false;
+    if (B < 4 || P < 200000 || P >= ((int64_t)1 << 32)) return false;
+    if (!chunked_supported(n_out, grid)) return false;
+    const int nt = tiled_tiles(n_out, grid);
+    return nt < 0 || nt > 4096;
+}
+
 static bool dims_supported(int n_in, int n_out) {
     return (n_in == 2 && n_out == 2) || (n_in == 3 && n_out == 3) || (n_in == 3 && n_out == 2);
 }
@@ -130,13 +148,18 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     const bool coherent = (*flags & DPR_FLAG_COHERENT_POINTS) != 0;
     if (*flags & 3u) {
         if (chunkown_preferred(-1, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
-        if (B == 1 && tiled_preferred(DPR_OP_RASTER, n_out, grid, P, B, G) &&
+        // tiled: one pose, or a batch on a grid too large for pose groups (every pose keeps its
+        // own binning)
+        if ((B == 1 || tiled_batch_share_ok(n_out, grid, P, B)) &&
+            tiled_preferred(DPR_OP_RASTER, n_out, grid, P, B, G) &&
             tiled_preferred(DPR_OP_PULLBACK, n_out, grid, P, B, G))
             return DPR_ALGO_TILED;
         *flags &= ~3u;
     }
     // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside
     if (chunkown_preferred(op, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
+    // forward over several poses of a coherent cloud on a large 3-D grid: chunk lists
+    if (chunked3d_preferred(op, n_out, grid, P, B, *flags)) return DPR_ALGO_CHUNKED;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
 
@@ -385,6 +408,16 @@ int dpr_resolve_algo_ex(int op, unsigned flags, int n_in, int n_out, const int64
     if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK)
         return dpr::fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
     return dpr::resolve_algo(DPR_ALGO_AUTO, op, n_in, n_out, grid, P, B, G, &flags);
+}
+
+int dpr_resolve_flags_ex(int op, unsigned flags, int n_in, int n_out, const int64_t* grid,
+                         int64_t P, int64_t B) {
+    int64_t G = 0;
+    if (int rc = dpr::check_common(n_in, n_out, grid, P, B, &G)) return rc;
+    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK)
+        return dpr::fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
+    (void)dpr::resolve_algo(DPR_ALGO_AUTO, op, n_in, n_out, grid, P, B, G, &flags);
+    return (int)(flags & 0xffffu);
 }
 
 int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t* grid, int64_t P, int64_t B) {

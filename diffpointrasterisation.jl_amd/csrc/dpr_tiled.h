@@ -17,6 +17,8 @@ bool tiled_supported(int n_out, const int64_t* grid);
 bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G);
 size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int n_out,
                              const int64_t* grid, int64_t P, int64_t B);
+bool tiled_batch_share_ok(int n_out, const int64_t* grid, int64_t P, int64_t B);
+int tiled_tiles(int n_out, const int64_t* grid);
 
 template <typename T, int NI, int NO>
 int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B, T* out,

@@ -287,39 +287,6 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
 }
 
 // ------------------------------------------------------------------ K2: scans
-// counts[nblk][NT] -> in place exclusive prefix down each column; totals[NT].
-// Block = kScanTiles tiles x kScanGroups row groups (32 x 32: NT/32 blocks keep more CUs busy
-// than the 64 x 16 split; rows of 32 tiles are still 128-byte segments).
-constexpr int kScanTiles = 32, kScanGroups = 32;
-__global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
-                                                  uint32_t* __restrict__ totals) {
-    __shared__ uint32_t part[kScanGroups][kScanTiles];
-    const int j = threadIdx.x % kScanTiles, g = threadIdx.x / kScanTiles;
-    const int tile = blockIdx.x * kScanTiles + j;
-    const int rows = (nblk + kScanGroups - 1) / kScanGroups;
-    const int r0 = g * rows, r1 = (r0 + rows < nblk) ? r0 + rows : nblk;
-    uint32_t s = 0;
-    if (tile < NT)
-        for (int r = r0; r < r1; ++r) s += counts[(size_t)r * NT + tile];
-    part[g][j] = s;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kScanGroups; ++k) {
-        const uint32_t v = part[k][j];
-        if (k < g) base += v;
-        total += v;
-    }
-    if (tile < NT) {
-        for (int r = r0; r < r1; ++r) {
-            const uint32_t c = counts[(size_t)r * NT + tile];
-            counts[(size_t)r * NT + tile] = base;
-            base += c;
-        }
-        if (g == 0) totals[tile] = total;
-    }
-}
-
 // What a DPR_FLAG_KEEP_BINNING forward leaves at the start of the workspace, and what a
 // DPR_FLAG_REUSE_BINNING pullback checks ON THE DEVICE before it trusts the work list, the
 // records and the slot map: problem shape, element size, the identity of the point / weight
@@ -483,19 +450,38 @@ __device__ __forceinline__ uint32_t load_runs(RunTable<N>& rt, const RunDesc* __
 // exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768), and the
 // work list: items[] ordered by decreasing size (log2 buckets; the heaviest items are
 // dispatched first), n_items, and per tile the number of parts and its first overflow slab.
-__global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ totals, int NT,
-                                                   uint32_t cap, uint32_t* __restrict__ tile_start,
-                                                   WorkItem* __restrict__ items,
-                                                   uint32_t* __restrict__ n_items,
-                                                   uint32_t* __restrict__ tile_parts,
-                                                   uint32_t* __restrict__ tile_slab,
-                                                   uint32_t* __restrict__ split_list,
-                                                   uint32_t* __restrict__ n_split, BinHeader hdr,
-                                                   BinHeader* __restrict__ hdr_out,
-                                                   const uint32_t* __restrict__ rot,
-                                                   int rot_words,
-                                                   const uint32_t* __restrict__ trans,
-                                                   int trans_words) {
+// Everything the tile scan reads and writes (one struct: the scan kernel carries it along).
+struct TileScanArgs {
+    const uint32_t* totals;
+    int NT;
+    uint32_t cap;
+    uint32_t* tile_start;
+    WorkItem* items;
+    uint32_t* n_items;
+    uint32_t* tile_parts;
+    uint32_t* tile_slab;
+    uint32_t* split_list;
+    uint32_t* n_split;
+    BinHeader hdr;
+    BinHeader* hdr_out;
+    const uint32_t* rot;
+    int rot_words;
+    const uint32_t* trans;
+    int trans_words;
+};
+// one block of 1024 threads
+__device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ totals, int NT,
+                                              uint32_t cap, uint32_t* __restrict__ tile_start,
+                                              WorkItem* __restrict__ items,
+                                              uint32_t* __restrict__ n_items,
+                                              uint32_t* __restrict__ tile_parts,
+                                              uint32_t* __restrict__ tile_slab,
+                                              uint32_t* __restrict__ split_list,
+                                              uint32_t* __restrict__ n_split, const BinHeader& hdr,
+                                              BinHeader* __restrict__ hdr_out,
+                                              const uint32_t* __restrict__ rot, int rot_words,
+                                              const uint32_t* __restrict__ trans,
+                                              int trans_words) {
     // header of this binning (state = kBinValid only for a KEEP_BINNING forward): the last wave
     // copies the pose words, one lane the fixed fields
     if (threadIdx.x >= 1024 - 64) {
@@ -592,6 +578,48 @@ __global__ __launch_bounds__(1024) void k_tilescan(const uint32_t* __restrict__ 
     if (threadIdx.x == 1023) tile_start[NT] = wbase + incl;
     __syncthreads();
     if (threadIdx.x == 0) *n_split = s_nsplit;
+}
+
+// counts[nblk][NT] -> in place exclusive prefix down each column; totals[NT].
+// Block = kScanTiles tiles x kScanGroups row groups (32 x 32: NT/32 blocks keep more CUs busy
+// than the 64 x 16 split; rows of 32 tiles are still 128-byte segments).
+// (Round 3 tried ONE kernel whose last block -- arrival ticket, agent-scope fences -- runs the
+// tile scan: the scan stage went from 18.5 to 40 us at C3, 81 us with 16-tile blocks; the
+// device-wide release / acquire of 64-128 blocks costs more than a launch.  Two kernels stay.)
+constexpr int kScanTiles = 32, kScanGroups = 32;
+__global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
+                                                  uint32_t* __restrict__ totals) {
+    __shared__ uint32_t part[kScanGroups][kScanTiles];
+    const int j = threadIdx.x % kScanTiles, g = threadIdx.x / kScanTiles;
+    const int tile = blockIdx.x * kScanTiles + j;
+    const int rows = (nblk + kScanGroups - 1) / kScanGroups;
+    const int r0 = g * rows, r1 = (r0 + rows < nblk) ? r0 + rows : nblk;
+    uint32_t s = 0;
+    if (tile < NT)
+        for (int r = r0; r < r1; ++r) s += counts[(size_t)r * NT + tile];
+    part[g][j] = s;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kScanGroups; ++k) {
+        const uint32_t v = part[k][j];
+        if (k < g) base += v;
+        total += v;
+    }
+    if (tile < NT) {
+        for (int r = r0; r < r1; ++r) {
+            const uint32_t c = counts[(size_t)r * NT + tile];
+            counts[(size_t)r * NT + tile] = base;
+            base += c;
+        }
+        if (g == 0) totals[tile] = total;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tilescan(TileScanArgs ts) {
+    tilescan_body(ts.totals, ts.NT, ts.cap, ts.tile_start, ts.items, ts.n_items, ts.tile_parts,
+                  ts.tile_slab, ts.split_list, ts.n_split, ts.hdr, ts.hdr_out, ts.rot,
+                  ts.rot_words, ts.trans, ts.trans_words);
 }
 
 // ------------------------------------------------------------------ K3: scatter
@@ -972,7 +1000,7 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
                                                   const uint32_t* __restrict__ rot, int rot_words,
                                                   const uint32_t* __restrict__ trans,
                                                   int trans_words) {
-    if (threadIdx.x >= 1024 - 64) {  // binning header, as in k_tilescan
+    if (threadIdx.x >= 1024 - 64) {  // binning header, as in the tile scan
         const int i = threadIdx.x - (1024 - 64);
         uint32_t* pose = (uint32_t*)hdr_out->pose;
         if (i < rot_words) pose[i] = rot[i];
@@ -2291,10 +2319,21 @@ template <typename T, int NI>
 __global__ __launch_bounds__(256) void k_unsort(int64_t P, const uint32_t* __restrict__ perm,
                                                 const T* __restrict__ dp_sorted,
                                                 const T* __restrict__ dpw_sorted,
-                                                T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw) {
+                                                T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
+                                                const BinHeader* __restrict__ hdr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    if (hdr && hdr->verdict != 1u) {
+        // REUSE_BINNING without the matching KEEP_BINNING forward: the permutation in the
+        // workspace is not this call pair's -- nothing is read through it, NaN gradients
+        const T nan = T(__builtin_nanf(""));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ds_dpoints[i * NI + j] = nan;
+        ds_dpw[i] = nan;
+        return;
+    }
     const size_t p = perm[i];
+    if (p >= (size_t)P) return;  // never for a permutation this library wrote
 #pragma unroll
     for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp_sorted[i * NI + j];
     ds_dpw[p] = dpw_sorted[i];
@@ -2347,6 +2386,10 @@ struct Plan {
     // 1.64 -> 0.68 ms per pose against 2.7 ms for the sort, once per call)
     bool sort_inside;
     size_t off_spts, off_spw, off_perm, off_sgrad, off_sgradw, off_sorttmp;
+    // KEEP_BINNING / REUSE_BINNING with B > 1: every pose owns a copy of the per-pose part of the
+    // layout (header ... slot map), pose_stride bytes apart, so that the pullback finds the binning
+    // of EVERY pose of the forward call; 0 when the poses share one copy (nothing is kept)
+    size_t pose_stride;
     // local binning (DPR_FLAG_COHERENT_POINTS, NT <= 4096)
     bool local;
     int sub;               // points per sub-chunk
@@ -2381,8 +2424,11 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
                      uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes);
 
 static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group,
-                      bool coherent = false, int n_in = 3) {
+                      bool coherent = false, int n_in = 3, bool share_batch = false) {
     Plan pl;
+    share_batch = share_batch && B > 1;
+    if (share_batch) max_group = 1;  // a kept binning is per pose
+    pl.pose_stride = 0;
     pl.sort_inside = !coherent && NT1 > 4096 && B >= 4 && P1 >= 200000;
     // (the direct-store pullback mode, an experiment knob, needs the index array only the plain
     // scatter writes)
@@ -2464,6 +2510,10 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
     (void)nrec;
+    if (share_batch) {  // everything up to here exists once per pose
+        pl.pose_stride = o;
+        o += (size_t)(B - 1) * pl.pose_stride;
+    }
     pl.off_spts = pl.off_spw = pl.off_perm = pl.off_sgrad = pl.off_sgradw = pl.off_sorttmp = o;
     if (pl.sort_inside) {
         pl.off_spts = o;
@@ -2513,6 +2563,7 @@ static uint32_t plan_layout_id(const Plan& pl) {
     mix(pl.off_slot);
     mix(pl.off_aux);
     mix(pl.local ? pl.off_sdesc : 0);
+    mix(pl.pose_stride);
     const uint32_t id = (uint32_t)(h ^ (h >> 32));
     return id ? id : 1u;
 }
@@ -2551,6 +2602,36 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
     return P >= 250000;
 }
 
+// tiles per pose of the tiled path's geometry (-1: more than it supports)
+int tiled_tiles(int n_out, const int64_t* grid) {
+    if (n_out == 3) {
+        TileGeom<3> tg;
+        return make_geom<3>(grid, &tg) ? tg.NT : -1;
+    }
+    TileGeom<2> tg;
+    return make_geom<2>(grid, &tg) ? tg.NT : -1;
+}
+
+// May a KEEP_BINNING / REUSE_BINNING pair with B > 1 poses share on the tiled path when
+// DPR_ALGO_AUTO decides?  Every pose then keeps its own records (Plan::pose_stride): only where
+// pose groups are not an option anyway (more than 2048 tiles per pose) and the kept records stay
+// below ~17 GB (P * B <= 2^29; independent of the element type, so that dpr_resolve_algo_ex needs
+// none).  An explicit DPR_ALGO_TILED shares for any B.
+bool tiled_batch_share_ok(int n_out, const int64_t* grid, int64_t P, int64_t B) {
+    if (B < 2 || P < 1 || P * B > ((int64_t)1 << 29)) return false;
+    int NT;
+    if (n_out == 3) {
+        TileGeom<3> tg;
+        if (!make_geom<3>(grid, &tg)) return false;
+        NT = tg.NT;
+    } else {
+        TileGeom<2> tg;
+        if (!make_geom<2>(grid, &tg)) return false;
+        NT = tg.NT;
+    }
+    return NT * 2 > 4096;
+}
+
 size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int n_out,
                              const int64_t* grid, int64_t P, int64_t B) {
     (void)op;
@@ -2566,7 +2647,7 @@ size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int 
         NT = tg.NT;
     }
     return make_plan(elem, n_out, NT, P, B, (int)((flags >> 8) & 0xffu),
-                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in).total;
+                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in, (flags & 3u) != 0).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -2653,7 +2734,13 @@ template <typename T, int NI, int NO>
 static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                       const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
                       const T* rot, const T* trans, int64_t b, int nb, bool want_idx, T* d_pts,
-                      T* d_pw, int zero_dropped, bool keep_valid = false) {
+                      T* d_pw, int zero_dropped, bool keep_valid = false,
+                      const T* hdr_points = nullptr, const T* hdr_pw = nullptr) {
+    // (the header names the caller's buffers; `points` may be the library's sorted copy)
+    if (!hdr_points) {
+        hdr_points = points;
+        hdr_pw = pw;
+    }
     uint32_t* counts = (uint32_t*)(ws + pl.off_counts);
     uint32_t* totals = (uint32_t*)(ws + pl.off_totals);
     uint32_t* tile_start = (uint32_t*)(ws + pl.off_tile_start);
@@ -2669,20 +2756,30 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
                            gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts);
     }
     stage_mark(st);
-    hipLaunchKernelGGL(k_colscan, dim3((NTe + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st,
-                       counts, pl.nblk, NTe, totals);
     int64_t grid64[3] = {1, 1, 1};
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
-    BinHeader hdr = make_header<T, NI, NO>(grid64, P, points, pw);
-    hdr.state = keep_valid ? kBinValid : 0u;  // only a KEEP_BINNING forward may be reused
-    hdr.layout = plan_layout_id(pl);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, totals, NTe, pl.cap, tile_start,
-                       (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
-                       (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
-                       (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split), hdr,
-                       (BinHeader*)(ws + pl.off_hdr),
-                       (const uint32_t*)(rot + b * (NO * NI)), (int)(NO * NI * sizeof(T) / 4),
-                       (const uint32_t*)(trans + b * NO), (int)(NO * sizeof(T) / 4));
+    TileScanArgs ts;
+    ts.totals = totals;
+    ts.NT = NTe;
+    ts.cap = pl.cap;
+    ts.tile_start = tile_start;
+    ts.items = (WorkItem*)(ws + pl.off_items);
+    ts.n_items = (uint32_t*)(ws + pl.off_nitems);
+    ts.tile_parts = (uint32_t*)(ws + pl.off_tparts);
+    ts.tile_slab = (uint32_t*)(ws + pl.off_tslab);
+    ts.split_list = (uint32_t*)(ws + pl.off_split) + 1;
+    ts.n_split = (uint32_t*)(ws + pl.off_split);
+    ts.hdr = make_header<T, NI, NO>(grid64, P, hdr_points, hdr_pw);
+    ts.hdr.state = keep_valid ? kBinValid : 0u;  // only a KEEP_BINNING forward may be reused
+    ts.hdr.layout = plan_layout_id(pl);
+    ts.hdr_out = (BinHeader*)(ws + pl.off_hdr);
+    ts.rot = (const uint32_t*)(rot + b * (NO * NI));
+    ts.rot_words = (int)(NO * NI * sizeof(T) / 4);
+    ts.trans = (const uint32_t*)(trans + b * NO);
+    ts.trans_words = (int)(NO * sizeof(T) / 4);
+    hipLaunchKernelGGL(k_colscan, dim3((NTe + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st,
+                       counts, pl.nblk, NTe, totals);
+    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, ts);
     stage_mark(st);
     int rc;
     if (pw) {
@@ -2713,7 +2810,12 @@ template <typename T, int NI, int NO>
 static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                             const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
                             const T* rot, const T* trans, int64_t b, bool want_idx, T* d_pts,
-                            T* d_pw, int zero_dropped, bool keep_valid) {
+                            T* d_pw, int zero_dropped, bool keep_valid,
+                            const T* hdr_points = nullptr, const T* hdr_pw = nullptr) {
+    if (!hdr_points) {  // the header names the caller's buffers
+        hdr_points = points;
+        hdr_pw = pw;
+    }
     uint32_t* ltot = (uint32_t*)(ws + pl.off_ltot);  // ndesc[NT] | npts[NT] | n_desc
     DPR_HIP(hipMemsetAsync(ltot, 0, (size_t)(2 * tg.NT + 1) * 4, st));
     stage_mark(st);
@@ -2733,7 +2835,7 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     stage_mark(st);
     int64_t grid64[3] = {1, 1, 1};
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
-    BinHeader hdr = make_header<T, NI, NO>(grid64, P, points, pw);
+    BinHeader hdr = make_header<T, NI, NO>(grid64, P, hdr_points, hdr_pw);
     hdr.state = keep_valid ? kBinValid : 0u;
     hdr.layout = plan_layout_id(pl);
     hipLaunchKernelGGL(k_runscan, dim3(1), dim3(1024), 0, st, (const uint32_t*)ltot,
@@ -2773,16 +2875,16 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
     const bool keep = flags & DPR_FLAG_KEEP_BINNING;
-    if (keep && B != 1)
-        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
-                    (long long)B);
+    // KEEP_BINNING with B > 1: every pose keeps its own binning (Plan::pose_stride)
     const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
-                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI);
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
     char* ws = (char*)ws_;
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
+    const T* const user_points = points;  // what the binning header names
+    const T* const user_pw = pw;
     if (pl.sort_inside) {
         T* spw = pw ? (T*)(ws + pl.off_spw) : (T*)nullptr;
         if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
@@ -2798,29 +2900,33 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     const int blocked = knobs().splat_blocked;
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
+        // per-pose part of the workspace (one copy, or one per pose when the binning is kept)
+        char* const wsb = ws + (size_t)b * pl.pose_stride;
         if (pl.local) {
-            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans,
-                                                     b, keep, (T*)nullptr, (T*)nullptr, 0, keep))
+            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
+                                                     b, keep, (T*)nullptr, (T*)nullptr, 0, keep,
+                                                     user_points, user_pw))
                 return rc;
-        } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
-                                                  (int)nb, keep, (T*)nullptr, (T*)nullptr, 0, keep))
+        } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans, b,
+                                                  (int)nb, keep, (T*)nullptr, (T*)nullptr, 0, keep,
+                                                  user_points, user_pw))
             return rc;
 #define DPR_LAUNCH_SPLAT_RUNS(HAS_PW, W3)                                                        \
     hipLaunchKernelGGL((k_tile_splat_runs<T, NI, NO, HAS_PW, W3, true>), dim3(pl.max_items),    \
                        dim3(kSplatThreads), 0, st, gd, tg,                                      \
-                       (const RecT<T, W3>*)(ws + pl.off_rec),                                   \
-                       (const RunDesc*)(ws + pl.off_sdesc), (uint32_t)(pl.nsub * pl.sub),       \
-                       (const WorkItem*)(ws + pl.off_items),                                    \
-                       (const uint32_t*)(ws + pl.off_nitems),                                   \
-                       (const uint32_t*)(ws + pl.off_tslab), rot, trans, ow, bg, b, out, halo,  \
+                       (const RecT<T, W3>*)(wsb + pl.off_rec),                                  \
+                       (const RunDesc*)(wsb + pl.off_sdesc), (uint32_t)(pl.nsub * pl.sub),      \
+                       (const WorkItem*)(wsb + pl.off_items),                                   \
+                       (const uint32_t*)(wsb + pl.off_nitems),                                  \
+                       (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
                        ovf, blocked)
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
                        dim3(kSplatThreads), 0, st, gd, tg,                                      \
-                       (const RecT<T, W3>*)(ws + pl.off_rec),                                   \
-                       (const WorkItem*)(ws + pl.off_items),                                    \
-                       (const uint32_t*)(ws + pl.off_nitems),                                   \
-                       (const uint32_t*)(ws + pl.off_tslab), rot, trans, ow, bg, b, out, halo,  \
+                       (const RecT<T, W3>*)(wsb + pl.off_rec),                                  \
+                       (const WorkItem*)(wsb + pl.off_items),                                   \
+                       (const uint32_t*)(wsb + pl.off_nitems),                                  \
+                       (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
                        ovf, blocked)
         if (pl.local) {
             if (pw) DPR_LAUNCH_SPLAT_RUNS(true, false);
@@ -2835,10 +2941,10 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
         hipLaunchKernelGGL((k_halo_gather<T, NO>),
                            dim3(tg.NT * (int)nb + (pl.max_slabs / 2) * kSplitBlocks),
                            dim3(256), 0, st, gd, tg, (const T*)halo, (const T*)ovf,
-                           (const uint32_t*)(ws + pl.off_tparts),
-                           (const uint32_t*)(ws + pl.off_tslab),
-                           (const uint32_t*)(ws + pl.off_split) + 1,
-                           (const uint32_t*)(ws + pl.off_split), bg, b, (int)nb, out);
+                           (const uint32_t*)(wsb + pl.off_tparts),
+                           (const uint32_t*)(wsb + pl.off_tslab),
+                           (const uint32_t*)(wsb + pl.off_split) + 1,
+                           (const uint32_t*)(wsb + pl.off_split), bg, b, (int)nb, out);
         stage_mark(st);
     }
     DPR_HIP(hipGetLastError());
@@ -2857,11 +2963,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
     const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
-    if (reuse && B != 1)
-        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
-                    (long long)B);
     const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
-                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI);
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -2870,12 +2973,17 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     const GridDesc<NO> gd = make_grid_desc<NO>(grid, G);
     T* d_pts_user = d_pts;
     T* d_pw_user = d_pw;
+    const T* const user_points = points;  // what the binning header names
+    const T* const user_pw = pw;
     if (pl.sort_inside) {
         T* spw = pw ? (T*)(ws + pl.off_spw) : (T*)nullptr;
-        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
-                                         (uint32_t*)(ws + pl.off_perm), pw, spw,
-                                         ws + pl.off_sorttmp, sort_workspace_bytes(P)))
-            return rc;
+        // REUSE_BINNING: the sorted copy and its permutation are the KEEP forward's (the per-pose
+        // headers, checked on the device, vouch for the call pair)
+        if (!reuse)
+            if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
+                                             (uint32_t*)(ws + pl.off_perm), pw, spw,
+                                             ws + pl.off_sorttmp, sort_workspace_bytes(P)))
+                return rc;
         points = (const T*)(ws + pl.off_spts);
         pw = spw;
         d_pts = (T*)(ws + pl.off_sgrad);   // gradients in sorted order, scattered back at the end
@@ -2884,12 +2992,14 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     double* partials = (double*)(ws + pl.off_aux);
     constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
     const bool unperm1 = knobs().bwd_unpermute != 0;
-    BinHeader want = make_header<T, NI, NO>(grid, P, points, pw);
+    BinHeader want = make_header<T, NI, NO>(grid, P, user_points, user_pw);
     want.layout = plan_layout_id(pl);
     if (!reuse) want.magic = 0;  // own binning: nothing to validate
-    BinHeader* hdr = reuse ? (BinHeader*)(ws + pl.off_hdr) : (BinHeader*)nullptr;
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
+        // per-pose part of the workspace (one copy, or one per pose when the binning was kept)
+        char* const wsb = ws + (size_t)b * pl.pose_stride;
+        BinHeader* hdr = reuse ? (BinHeader*)(wsb + pl.off_hdr) : (BinHeader*)nullptr;
         // a pose group always goes through the gradient records (several (pose, tile) blocks
         // own the same point, so they cannot store to ds_dpoints directly)
         const bool unperm = unperm1 || nb > 1;
@@ -2905,27 +3015,29 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             stage_mark(st);
             stage_mark(st);
         } else if (pl.local) {
-            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans,
+            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
                                                      b, true, d_pts, d_pw,
-                                                     (b == 0 && !unperm) ? 1 : 0, false))
+                                                     (b == 0 && !unperm) ? 1 : 0, false,
+                                                     user_points, user_pw))
                 return rc;
-        } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, ws, P, points, pw, rot, trans, b,
+        } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans, b,
                                                   (int)nb, true, d_pts, d_pw,
-                                                  (b == 0 && !unperm) ? 1 : 0))
+                                                  (b == 0 && !unperm) ? 1 : 0, false, user_points,
+                                                  user_pw))
             return rc;
 #define DPR_LAUNCH_GATHER_RUNS(HAS_PW, FIRST, UNP)                                               \
     hipLaunchKernelGGL((k_tile_gather_runs<T, NI, NO, HAS_PW, FIRST, UNP, true>),                \
                        dim3(pl.max_items), dim3(kGatherThreads), 0, st, gd, tg,                  \
-                       (Rec4<T>*)(ws + pl.off_rec), (const RunDesc*)(ws + pl.off_sdesc),         \
-                       pl.nsub * pl.sub, (const uint32_t*)(ws + pl.off_idx),                     \
-                       (const WorkItem*)(ws + pl.off_items),                                     \
-                       (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,   \
+                       (Rec4<T>*)(wsb + pl.off_rec), (const RunDesc*)(wsb + pl.off_sdesc),       \
+                       pl.nsub * pl.sub, (const uint32_t*)(wsb + pl.off_idx),                    \
+                       (const WorkItem*)(wsb + pl.off_items),                                    \
+                       (const uint32_t*)(wsb + pl.off_nitems), pl.max_items, g, rot, trans, ow,  \
                        b, d_pts, d_pw, partials, rs, want, hdr)
 #define DPR_LAUNCH_GATHER_PLAIN(HAS_PW, FIRST, UNP)                                              \
     hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(pl.max_items),       \
-                       dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(ws + pl.off_rec), P * nb, \
-                       (const uint32_t*)(ws + pl.off_idx), (const WorkItem*)(ws + pl.off_items), \
-                       (const uint32_t*)(ws + pl.off_nitems), pl.max_items, g, rot, trans, ow,   \
+                       dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(wsb + pl.off_rec), P * nb, \
+                       (const uint32_t*)(wsb + pl.off_idx), (const WorkItem*)(wsb + pl.off_items), \
+                       (const uint32_t*)(wsb + pl.off_nitems), pl.max_items, g, rot, trans, ow,   \
                        b, d_pts, d_pw, partials, rs, want, hdr)
 #define DPR_LAUNCH_GATHER(HAS_PW, FIRST, UNP)                       \
     do {                                                            \
@@ -2942,8 +3054,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
 #define DPR_LAUNCH_UNPERM(FIRST, UPB)                                                            \
     hipLaunchKernelGGL((k_unpermute<T, NI, FIRST, UPB>),                                         \
                        dim3((unsigned)((P + UPB * 1024 - 1) / (UPB * 1024))), dim3(1024), 0, st, \
-                       P, (int)nb, (const Rec4<T>*)(ws + pl.off_rec),                            \
-                       (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw, (const BinHeader*)hdr)
+                       P, (int)nb, (const Rec4<T>*)(wsb + pl.off_rec),                           \
+                       (const uint32_t*)(wsb + pl.off_slot), d_pts, d_pw, (const BinHeader*)hdr)
                 if (nb > 1) {
                     if (b == 0) DPR_LAUNCH_UNPERM(true, 1);
                     else DPR_LAUNCH_UNPERM(false, 1);
@@ -2969,15 +3081,16 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         stage_mark(st);
         hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>),
                            dim3(rs.target ? NVAL + 1 : NVAL, (unsigned)nb), dim3(1024), 0, st,
-                           (const double*)partials, (const WorkItem*)(ws + pl.off_items),
-                           (const uint32_t*)(ws + pl.off_nitems), pl.max_items, tg.NT, b, d_rot,
+                           (const double*)partials, (const WorkItem*)(wsb + pl.off_items),
+                           (const uint32_t*)(wsb + pl.off_nitems), pl.max_items, tg.NT, b, d_rot,
                            d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr, hdr);
         stage_mark(st);
     }
     if (pl.sort_inside && P > 0)
         hipLaunchKernelGGL((k_unsort<T, NI>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, P,
                            (const uint32_t*)(ws + pl.off_perm), (const T*)d_pts, (const T*)d_pw,
-                           d_pts_user, d_pw_user);
+                           d_pts_user, d_pw_user,
+                           reuse ? (const BinHeader*)(ws + pl.off_hdr) : (const BinHeader*)nullptr);
     DPR_HIP(hipGetLastError());
     return DPR_OK;
 }

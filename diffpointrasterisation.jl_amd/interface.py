@@ -170,6 +170,21 @@ def resolve_algo(op: str, grid_size, n_points: int, batch: int, n_in: int, *,
     return {v: k for k, v in _lib.ALGOS.items()}[rc]
 
 
+def sharing_effective(grid_size, n_points: int, batch: int, n_in: int, *,
+                      coherent_points: bool = False) -> bool:
+    """Will `algo="auto"` honour keep_binning / reuse_binning for this problem
+    (dpr_resolve_flags_ex)?  False where the pair's algorithm has nothing to share."""
+    import numpy as np
+
+    grid_arr = np.asarray(grid_size, dtype=np.int64)
+    flags = _lib.FLAG_KEEP_BINNING | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0)
+    rc = _lib.lib().dpr_resolve_flags_ex(_lib.OP_RASTER, flags, n_in, len(grid_size),
+                                         grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
+    if rc < 0:
+        _lib.check(rc)
+    return bool(rc & _lib.FLAG_KEEP_BINNING)
+
+
 def _check_dims(n_in_pts, rot_shape, trans_shape):
     """Step 5 of the reference funnel: explicit dimension errors
     (src/interface.jl:137-162, 315-366)."""

@@ -79,12 +79,17 @@ extern "C" {
                               LDS-staged ds_dout, gradients in registers across poses, no
                               atomics.  The points are Hilbert-sorted into the workspace first
                               unless DPR_FLAG_COHERENT_POINTS says they already are.
-                              3-D grids (experimental): chunks of 64 points are listed per
-                              voxel tile, tiles read the points in place.
+                              3-D grids: chunks of 64 points are listed per voxel tile, tiles
+                              read the points in place, all poses in one launch (what AUTO
+                              picks for a forward call over >= 4 poses of a cloud flagged
+                              DPR_FLAG_COHERENT_POINTS on a grid of more than 4096 tiles).
                               Correct for any point order; fast only for coherent input. */
 
-/* flags (the *_ex entry points); DPR_ALGO_TILED / 3-D DPR_ALGO_CHUNKED: B == 1 only; DPR_ALGO_CHUNKED
- * on 2-D grids: any B (what is kept there is the sorted copy of the cloud and its permutation):
+/* flags (the *_ex entry points).  DPR_ALGO_TILED: any B -- with B > 1 every pose keeps its own
+ * binning (the per-pose part of the workspace is laid out B times; pose groups are off);
+ * DPR_ALGO_CHUNKED on 2-D grids: any B (what is kept there is the sorted copy of the cloud and its
+ * permutation); 3-D DPR_ALGO_CHUNKED: B == 1 only (the chunk lists); DPR_ALGO_ATOMIC has nothing to
+ * keep (error):
  * KEEP_BINNING  (raster)   leave the per-tile binning of the points (incl. original
  *                          indices) in the workspace for the pullback of the same call pair
  * REUSE_BINNING (pullback) the workspace still holds the binning written by the preceding
@@ -129,13 +134,21 @@ const char *dpr_last_error(void);
  *  - with DPR_FLAG_KEEP_BINNING or DPR_FLAG_REUSE_BINNING the choice is made for the raster +
  *    pullback PAIR (both calls must run the same algorithm), from arguments both calls share.
  *    When the pair's algorithm has nothing to share (DPR_ALGO_ATOMIC; DPR_ALGO_TILED with
- *    B > 1), AUTO ignores the two flags -- each call then works on its own -- where an
- *    explicitly named algorithm returns an error.  So a caller may always pass AUTO + KEEP to
+ *    B > 1 on a grid small enough for pose groups, or with more than 2^29 (point, pose) pairs
+ *    to keep), AUTO ignores the two flags -- each call then works on its own -- where an
+ *    explicitly named algorithm returns an error (DPR_ALGO_ATOMIC) or shares at any size
+ *    (DPR_ALGO_TILED: every pose of the batch keeps its own binning, B-fold workspace).  So a caller may always pass AUTO + KEEP to
  *    raster and AUTO + REUSE to the pullback of the same arguments.
  * dpr_resolve_algo is dpr_resolve_algo_ex with flags = 0. */
 int dpr_resolve_algo(int op, int n_in, int n_out, const int64_t *grid, int64_t P, int64_t B);
 int dpr_resolve_algo_ex(int op, unsigned flags, int n_in, int n_out, const int64_t *grid,
                         int64_t P, int64_t B);
+/* The flags DPR_ALGO_AUTO will act on for this problem (>= 0), or a negative status: `flags`
+ * with DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING cleared where the pair's algorithm has
+ * nothing to share.  A host that wants to know whether the pullback will really skip its binning
+ * (e.g. to report it) asks here. */
+int dpr_resolve_flags_ex(int op, unsigned flags, int n_in, int n_out, const int64_t *grid,
+                         int64_t P, int64_t B);
 
 /* Optional per-stage device timing (used by bench.py for the roofline numbers): arm an
  * array of `capacity` hipEvent_t created by the caller; until dpr_stage_timing_end() every

@@ -41,7 +41,8 @@ def make(n_points=10, n_in=3, n_out=3, batch=3, grid_n=8, seed=0, dtype=np.float
     weights = 10 * rng.uniform(size=batch)
     pw = rng.uniform(size=n_points)
     pw = pw / max(pw.sum(), 1e-300)
-    grid = (grid_n,) * n_out
+    grid = tuple(grid_n) if isinstance(grid_n, (tuple, list)) else (grid_n,) * n_out
+    assert len(grid) == n_out
     ds_dout = np.asfortranarray(rng.normal(size=grid + (batch,)))
     c = lambda a: np.ascontiguousarray(a, dtype=dtype)
     return SimpleNamespace(points=c(points), rotations=c(rot), translations=c(trans),

@@ -230,17 +230,25 @@ def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
     assert rc == dpr_amd._lib.ERR_WORKSPACE and "workspace" in dpr_amd._lib.last_error()
     rc = fn(None, dpr_amd._lib.ALGO_TILED, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, d, 64)
     assert rc == dpr_amd._lib.ERR_WORKSPACE
-    # keep / reuse flags: tiled or chunked only, one pose only
+    # keep / reuse flags: tiled or chunked only
     rc = fn(None, dpr_amd._lib.ALGO_ATOMIC, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 1, d, d,
             d, d, None, None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_UNSUPPORTED_ALGO
-    rc = fn(None, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 2, d, d,
-            d, d, None, None, None, d, 1 << 30)
-    assert rc == dpr_amd._lib.ERR_INVALID_ARG and "B == 1" in dpr_amd._lib.last_error()
+    # tiled with B > 1: every pose keeps its own binning (the per-pose part of the workspace is
+    # laid out B times, pose groups are off): another layout and size than the same call without
+    # the flag, the same for the two calls of a pair, and checked before any launch
+    wsx = getattr(L, f"dpr_workspace_bytes_ex_{suf}")
+    one = wsx(0, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 1)
+    kept = wsx(0, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 3)
+    assert kept > one
+    assert wsx(1, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_REUSE_BINNING, 3, 3, gp, 1000, 3) == kept
+    rc = fn(None, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, gp, 1000, 3, d, d,
+            d, d, None, None, None, d, kept - 256)
+    assert rc == dpr_amd._lib.ERR_WORKSPACE and "workspace" in dpr_amd._lib.last_error()
     pb = getattr(L, f"dpr_raster_pullback_ex_{suf}")
-    rc = pb(None, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_REUSE_BINNING, 3, 3, gp, 1000, 2,
-            *([d] * 4), None, None, *([d] * 6), d, 1 << 30)
-    assert rc == dpr_amd._lib.ERR_INVALID_ARG
+    rc = pb(None, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_REUSE_BINNING, 3, 3, gp, 1000, 3,
+            *([d] * 4), None, None, *([d] * 6), d, kept - 256)
+    assert rc == dpr_amd._lib.ERR_WORKSPACE
     # unknown algorithm id
     rc = fn(None, 77, 0, 3, 3, gp, 1000, 1, d, d, d, d, None, None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_UNSUPPORTED_ALGO

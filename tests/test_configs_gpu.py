@@ -490,7 +490,7 @@ def test_pose_offset_beyond_2_pow_32_elements(oracle, dev, algo):
     size of C5's one-GPU point (64 x 512^3)."""
     P, n, B = 100_000, 512, 33
     G = n ** 3
-    assert (B - 1) * G > 2 ** 32
+    assert (B - 1) * G >= 2 ** 32  # every element of the last pose lies at or past 2^32
     rng = np.random.default_rng(11)
     pts = (0.4 * rng.standard_normal(size=(P, 3))).astype(np.float32)
     R = D.random_rotations(rng, B).astype(np.float32)

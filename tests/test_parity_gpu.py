@@ -280,6 +280,49 @@ def test_pullback_reusing_forward_binning(oracle, dev, algo, npdt, tdt, n_in, n_
         dpr_amd.raster_(out, *args, algo="atomic", workspace=ws, keep_binning=True)
 
 
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_points,batch,grid,coherent", [
+    (30_000, 3, (40, 40, 40), False),       # a small batch: B copies of the per-pose lists
+    (30_000, 5, (90, 70), False),           # 2-D grid on the tiled path (pose groups are off)
+    (210_000, 4, (336, 336, 336), False),   # > 4096 tiles, B >= 4: the cloud is sorted inside the
+                                            # call -- the REUSE pullback reuses the sorted copy too
+    (60_000, 3, (64, 48, 40), True),        # local binning (coherent flag) per pose
+])
+def test_batched_pullback_reusing_forward_binning(oracle, dev, npdt, tdt, n_points, batch, grid, coherent):
+    """DPR_FLAG_KEEP_BINNING / REUSE_BINNING with B > 1 on the tiled path: every pose keeps its
+    own binning (the per-pose part of the workspace exists B times), the pullback consumes all
+    of them; a stale pose header gives NaN."""
+    n_out = len(grid)
+    d = D.make(n_points=n_points, n_in=3, n_out=n_out, batch=batch, grid_n=grid, seed=31, dtype=npdt)
+    d.points[::9] *= 3.0  # some points outside the grid
+    kw = dict(coherent_points=True) if coherent else {}
+    need = max(dpr_amd.workspace_bytes(op, d.grid, n_points, batch, 3, tdt, "tiled", sharing=True, **kw)
+               for op in ("raster", "pullback"))
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, batch, tdt, dev)
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(d.point_weights, dev))
+    g = grid_to_dev(d.ds_dout, dev)
+    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=True, **kw)
+    pb = dpr_amd.raster_pullback_(g, *args, algo="tiled", workspace=ws, reuse_binning=True, **kw)
+    ref_out = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds,
+                            d.weights, d.point_weights, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                    d.point_weights, dtype=npdt)
+    _compare(ref_out, ref_pb, out, pb, npdt)
+    # consumed: a second reuse finds no valid binning
+    pb2 = dpr_amd.raster_pullback_(g, *args, algo="tiled", workspace=ws, reuse_binning=True, **kw)
+    assert bool(torch.isnan(pb2.points).all()) and bool(torch.isnan(pb2.rotation).all())
+    # one pose changed between the calls: that pose's outputs (and the summed point gradients) NaN
+    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=True, **kw)
+    t2 = args[2].clone()
+    t2[batch - 1] += 0.01
+    pb3 = dpr_amd.raster_pullback_(g, args[0], args[1], t2, *args[3:], algo="tiled", workspace=ws,
+                                   reuse_binning=True, **kw)
+    assert bool(torch.isnan(pb3.points).all()) and bool(torch.isnan(pb3.rotation[batch - 1]).all())
+    assert not bool(torch.isnan(pb3.rotation[0]).any())
+
+
 def test_reuse_binning_is_validated_on_the_device(oracle, dev):
     """DPR_FLAG_REUSE_BINNING without a matching DPR_FLAG_KEEP_BINNING forward (stale workspace,
     other pose, other points, binning already consumed) must not read through stale lists:

@@ -1,0 +1,31 @@
+#!/bin/bash
+# usage: bash tools/r3_run.sh <tag> <step> [<step> ...]   -- steps: tests bench_c3 bench_c3_<variant> bench_c4 bench_c5 regret ...
+# Every step runs under its own timeout; a step that is killed at its limit ends the script
+# (no further GPU step after a hang).  Outputs under gpurun_out/<tag>/.
+set -o pipefail
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+run() {  # run <name> <limit_s> <cmd...>
+  local name=$1 lim=$2; shift 2
+  echo "== $name"
+  timeout -k 10 $lim "$@" > $O/$name.log 2>&1
+  local rc=$?
+  echo "$name rc=$rc" | tee -a $O/steps.txt
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name hit its limit: stopping"; exit 1; fi
+}
+for step in "$@"; do
+  case $step in
+    tests)      run tests 900 python -m pytest tests -m gpu -x -q ;;
+    tests_all)  run tests 900 python -m pytest tests -m gpu -q ;;
+    tests_k)    run tests_k 600 python -m pytest tests -m gpu -q -k "$K" ;;
+    bench_c3)   run bench_c3 300 python bench.py --steps 20 --warmup 5 --cpu-budget 5 ;;
+    bench_c3_*) v=${step#bench_c3_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c3_$v 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference ;;
+    bench_c4)   run bench_c4 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_c5)   run bench_c5 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline ;;
+    bench_c5_noshare) run bench_c5_noshare 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline --no-share-binning ;;
+    regret)     run regret 1000 python tools/auto_regret.py ;;
+    regret_quick) run regret 600 python tools/auto_regret.py --quick ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+done
+echo all steps done
