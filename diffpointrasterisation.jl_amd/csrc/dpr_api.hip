@@ -34,11 +34,16 @@ int fail(int code, const char* fmt, ...) {
             return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
 
-// AUTO and DPR_ALGO_CHUNKED on 2-D grids: a small cost model (ms on one MI355X, fitted to
-// profiles/r02_chunkown_sweep.txt) instead of fixed thresholds, because the crossover moves with
-// three things at once -- the poses that share the Hilbert sort, the size of the cloud, and how
-// far a 4096-point chunk spreads over the image (`spread`, in pixels: chunks whose footprint
-// outgrows the LDS tile take the slower banded path).
+// AUTO and DPR_ALGO_CHUNKED on 2-D grids: a small cost model (ms on one MI355X) instead of fixed
+// thresholds, because the crossover moves with three things at once -- the poses that share the
+// Hilbert sort, the size of the cloud, and how far a 4096-point chunk spreads over the image
+// (`spread`, in pixels: chunks whose footprint outgrows the LDS tile take the slower banded path,
+// and beyond the double-size tile the direct one).  Round 3 refitted it to the regret table
+// (tools/auto_regret.py, profiles/r03_auto_regret.txt: Gaussian, uniform and clustered clouds,
+// 1e4-1e7 points, 1-64 poses, 128^2-1024^2): per-pose fixed costs of the chunk-owner kernels were
+// 4x too high (1e4 points x 64 poses: 0.07 ms measured, 0.21 modelled), the tiled path's
+// per-pose floor grows with the image (1024 tiles at 1024^2: +13 us per pose), and very sparse
+// images (spread beyond ~2e4 pixels) cost the chunk-owner forward a second tier.
 struct PairCost {
     double fwd, bwd;
 };
@@ -47,39 +52,51 @@ static double chunk_spread(int n_in, int64_t G, int64_t P) {
     return (double)G * (n_in == 3 ? std::cbrt(frac * frac) : frac);
 }
 static double clamp01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
-static double sort_cost(double pm) { return 0.04 + 0.052 * pm; }
+// Hilbert keys + rocPRIM radix sort + gather of the points (mid-size clouds pay the sort's fixed
+// passes: 1e6 points 0.17 ms, 1e7 points 0.62 ms)
+static double sort_cost(double pm) { return 0.07 + 0.05 * pm + 0.05 * (pm < 1.0 ? pm : 1.0); }
 static PairCost chunkown_cost(int n_in, int64_t G, int64_t P, int64_t B, bool coherent) {
-    const double pm = (double)P * 1e-6, f = chunk_spread(n_in, G, P);
+    const double pm = (double)P * 1e-6, f = chunk_spread(n_in, G, P), gm = (double)G / 1048576.0;
     PairCost c;
-    c.fwd = 0.03 + 0.004 * pm + (double)B * (0.002 + pm * (0.0055 + 0.02 * clamp01((f - 2000) / 10000)));
-    c.bwd = 0.025 + 0.0075 * pm + (double)B * (0.002 + pm * (0.007 + 0.006 * clamp01((f - 2000) / 5000)));
+    c.fwd = 0.03 + 0.004 * pm +
+            (double)B * (0.0004 + 0.0035 * gm * gm +
+                         pm * (0.0055 + 0.02 * clamp01((f - 2000) / 10000) +
+                               0.06 * clamp01((f - 20000) / 100000)));
+    c.bwd = 0.025 + 0.0075 * pm +
+            (double)B * (0.0006 + 0.0006 * gm + pm * (0.007 + 0.006 * clamp01((f - 2000) / 5000)));
     if (!coherent) {
         c.fwd += sort_cost(pm);
         c.bwd += sort_cost(pm) + 0.01 + 0.033 * pm;  // + gradients back to the caller's order
     }
     return c;
 }
-static PairCost other_cost(int n_out, const int64_t* grid, int64_t P, int64_t B) {
-    const double pm = (double)P * 1e-6;
+static PairCost other_cost(int n_out, const int64_t* grid, int64_t G, int64_t P, int64_t B) {
+    const double pm = (double)P * 1e-6, gm = (double)G / 1048576.0;
     PairCost a, t;
     a.fwd = 0.01 + (double)B * (0.001 + 0.19 * pm);
     a.bwd = 0.05 + (double)B * (0.0003 + 0.05 * pm);
     if (!tiled_supported(n_out, grid) || P >= ((int64_t)1 << 32)) return a;
     const double pf = 0.005 + 0.0128 * pm, pb = 0.005 + 0.0207 * pm;
-    t.fwd = 0.03 + (double)B * (pf > 0.0115 ? pf : 0.0115);
-    t.bwd = 0.03 + (double)B * (pb > 0.0135 ? pb : 0.0135);
+    t.fwd = 0.03 + (double)B * ((pf > 0.0115 ? pf : 0.0115) + 0.0135 * gm);
+    t.bwd = 0.03 + (double)B * ((pb > 0.0135 ? pb : 0.0135) + 0.016 * gm);
     PairCost c;
     c.fwd = a.fwd < t.fwd ? a.fwd : t.fwd;
     c.bwd = a.bwd < t.bwd ? a.bwd : t.bwd;
     return c;
 }
 // op < 0: the raster + pullback pair of a KEEP_BINNING / REUSE_BINNING call pair (one sort)
+//
+// The margin is on the chunk-owner side (1.2 from 16 poses on: taken even when modelled 20 % behind): the
+// model is fitted to clouds that fill the image, where the alternatives are at their best; on a
+// clustered cloud the chunk-owner footprints shrink and it wins by 2-3x (1e7 points x 64 poses on
+// 1024^2: 3.5 vs 9.6 ms tiled), while nothing makes it lose by more than ~1.2x where the model
+// calls a tie.  AUTO cannot see the cloud from the host, so it minimises the worst case.
 static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid, int64_t G,
                                int64_t P, int64_t B, bool coherent) {
     if (n_out != 2 || P >= ((int64_t)1 << 32) || P < 1 || B < 1) return false;
     if (B > 65535 * 64) return false;  // the chunk-owner kernels' grid.y (pose slices of <= 64)
-    const PairCost c = chunkown_cost(n_in, G, P, B, coherent), o = other_cost(n_out, grid, P, B);
-    const double margin = 0.85;  // stay with the established paths unless clearly ahead
+    const PairCost c = chunkown_cost(n_in, G, P, B, coherent), o = other_cost(n_out, grid, G, P, B);
+    const double margin = B >= 16 ? 1.2 : 0.9;
     if (op == DPR_OP_RASTER) return c.fwd < margin * o.fwd;
     if (op == DPR_OP_PULLBACK) return c.bwd < margin * o.bwd;
     const double pm = (double)P * 1e-6;
@@ -88,20 +105,23 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
 
 // DPR_ALGO_CHUNKED on 3-D grids (chunk lists per tile, points read in place, one launch for all
 // poses): what AUTO picks for a FORWARD call over several poses of a cloud the caller vouches is
-// coherent, on a grid beyond the write-combining scatter's 4096 tiles -- there the tiled path
-// writes and re-reads a 16/32-byte record per (point, pose) through the plain scatter, the
-// chunk lists move 4 bytes per (chunk of 64 points, tile).  Measured (50 M points -> 512^3 fp64,
-// 8 poses, Hilbert-sorted, profiles/r03_chunked3d_regime.txt): 13.5 ms against 16.3 ms tiled.
-// Not for a KEEP/REUSE pair (nothing to keep) and not for the pullback (its per-pose gather
-// loses to the tiled one: 32 vs 24 ms).
-static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
-                                unsigned flags) {
+// coherent when the cloud is SPARSE on the grid (at most one point per ten voxels: 1e5 points
+// into 128^3, 1e6 into 256^3, the reference README's 1e5 into 1024^3).  There a tile holds few
+// points, the per-pose binning of the tiled path is all fixed cost, and the lists win by 1.5-3.5x
+// on Gaussian, uniform and clustered clouds alike (profiles/r03_auto_regret.txt, coherent
+// section: 1e5 points x 64 poses -> 128^3 0.44 vs 1.53 ms; 1e6 x 64 -> 256^3 2.8 vs 5.8 ms).
+// Denser clouds are a tie on clouds that fill the grid and a 3-5x loss on clustered ones (heavy
+// tiles are not split on this path), so they stay with the tiled path -- including the
+// 50 M -> 512^3 fp64 share of config C5, where the lists measured 13.5 vs 16.7 ms on the Gaussian
+// cloud.  Not for a KEEP/REUSE pair (the tiled pair with a shared binning wins the step) and not
+// for the pullback (per-pose gather with read-modify-write of the point gradients).
+static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t G, int64_t P,
+                                int64_t B, unsigned flags) {
     if (op != DPR_OP_RASTER || n_out != 3 || (flags & 3u) || !(flags & DPR_FLAG_COHERENT_POINTS))
         return false;
-    if (B < 4 || P < 200000 || P >= ((int64_t)1 << 32)) return false;
+    if (B < 4 || P < 30000 || P >= ((int64_t)1 << 32)) return false;
     if (!chunked_supported(n_out, grid)) return false;
-    const int nt = tiled_tiles(n_out, grid);
-    return nt < 0 || nt > 4096;
+    return P * 10 <= G;
 }
 
 static bool dims_supported(int n_in, int n_out) {
@@ -159,7 +179,13 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside
     if (chunkown_preferred(op, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
     // forward over several poses of a coherent cloud on a large 3-D grid: chunk lists
-    if (chunked3d_preferred(op, n_out, grid, P, B, *flags)) return DPR_ALGO_CHUNKED;
+    if (chunked3d_preferred(op, n_out, grid, G, P, B, *flags)) return DPR_ALGO_CHUNKED;
+    // pullback over many (>= 32) poses of a coherent cloud on a grid without pose groups: the direct
+    // kernel (point in registers across the poses, cache-friendly gathers on sorted input) is
+    // never more than ~6 % behind the tiled pipeline there and up to 1.9x ahead (clustered cloud,
+    // 1e6 points x 64 poses -> 256^3: 3.0 vs 5.6 ms)
+    if (op == DPR_OP_PULLBACK && coherent && B >= 32 && n_out == 3 && tiled_tiles(n_out, grid) > 1024)
+        return DPR_ALGO_ATOMIC;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
 

@@ -450,6 +450,32 @@ __device__ __forceinline__ uint32_t load_runs(RunTable<N>& rt, const RunDesc* __
 // exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768), and the
 // work list: items[] ordered by decreasing size (log2 buckets; the heaviest items are
 // dispatched first), n_items, and per tile the number of parts and its first overflow slab.
+// Bucket counters of the work-list builders (33 log2-size buckets in LDS).  Nearly every tile of a
+// cloud falls into the same two or three buckets, so per-lane atomics on them serialise (~3
+// cycles per lane: 2 x 2048 of them were most of k_tilescan's 6.7 us).  One atomic per distinct
+// bucket and wave instead: the lanes of `active` that share the leader's bucket add `amount`
+// each (the common amount 1 by popcount) and get consecutive positions.
+//   returns the lane's position (base + rank among the lanes of its bucket) when RETURNING
+template <bool RETURNING>
+__device__ __forceinline__ uint32_t bucket_add_one(uint32_t* buckets, int bucket, bool active) {
+    const int lane = threadIdx.x & (kWave - 1);
+    unsigned long long todo = __ballot(active);
+    uint32_t pos = 0;
+    while (todo) {  // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lb = __shfl(bucket, leader, kWave);
+        const unsigned long long same = __ballot(active && bucket == lb) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&buckets[lb], (uint32_t)__popcll(same));
+        if (RETURNING) {
+            base = __shfl(base, leader, kWave);
+            if ((same >> lane) & 1ull) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return pos;
+}
+
 // Everything the tile scan reads and writes (one struct: the scan kernel carries it along).
 struct TileScanArgs {
     const uint32_t* totals;
@@ -515,13 +541,19 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
     const int per = (NT + 1023) / 1024;
     const int i0 = threadIdx.x * per;
     uint32_t s = 0, slabs = 0;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = totals[i];
+    for (int q = 0; q < per; ++q) {  // (uniform trip count: the bucket updates are wave-wide)
+        const int i = i0 + q;
+        const bool live = i < NT;
+        const uint32_t c = live ? totals[i] : 0u;
         s += c;
         const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
         const uint32_t sz = (c + k - 1) / k;  // records per part
-        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
-        if (k > 1) slabs += k;
+        const int bucket = sz ? 32 - __clz(sz) : 0;
+        bucket_add_one<false>(bcount, bucket, live && k == 1);
+        if (live && k > 1) {
+            atomicAdd(&bcount[bucket], k);
+            slabs += k;
+        }
     }
     uint32_t incl = s, incl_slab = slabs;
 #pragma unroll
@@ -552,24 +584,36 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
     }
     __syncthreads();
     uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = totals[i];
-        tile_start[i] = run;
+    for (int q = 0; q < per; ++q) {
+        const int i = i0 + q;
+        const bool live = i < NT;
+        const uint32_t c = live ? totals[i] : 0u;
         const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
         const uint32_t sz = (c + k - 1) / k;
         const int bucket = sz ? 32 - __clz(sz) : 0;
+        // the usual case, a tile that is one work item: positions handed out per wave and bucket
+        const uint32_t pos1 = bucket_add_one<true>(bstart, bucket, live && k == 1);
+        if (!live) continue;
+        tile_start[i] = run;
         tile_parts[i] = k;
         tile_slab[i] = slab_run;
-        for (uint32_t part = 0; part < k; ++part) {
+        if (k == 1) {
             WorkItem it;
             it.tile = (uint32_t)i;
-            it.begin = run + part * sz;
-            it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
-            if (it.begin > run + c) it.begin = run + c;
-            it.part_nparts = part | (k << 16);
-            items[atomicAdd(&bstart[bucket], 1u)] = it;
-        }
-        if (k > 1) {
+            it.begin = run;
+            it.end = run + c;
+            it.part_nparts = 0u | (1u << 16);
+            items[pos1] = it;
+        } else {
+            for (uint32_t part = 0; part < k; ++part) {
+                WorkItem it;
+                it.tile = (uint32_t)i;
+                it.begin = run + part * sz;
+                it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
+                if (it.begin > run + c) it.begin = run + c;
+                it.part_nparts = part | (k << 16);
+                items[atomicAdd(&bstart[bucket], 1u)] = it;
+            }
             slab_run += k;
             split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
         }
@@ -586,7 +630,10 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
 // (Round 3 tried ONE kernel whose last block -- arrival ticket, agent-scope fences -- runs the
 // tile scan: the scan stage went from 18.5 to 40 us at C3, 81 us with 16-tile blocks; the
 // device-wide release / acquire of 64-128 blocks costs more than a launch.  Two kernels stay.)
-constexpr int kScanTiles = 32, kScanGroups = 32;
+#ifndef DPR_SCAN_TILES
+#define DPR_SCAN_TILES 32
+#endif
+constexpr int kScanTiles = DPR_SCAN_TILES, kScanGroups = 1024 / DPR_SCAN_TILES;
 __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
                                                   uint32_t* __restrict__ totals) {
     __shared__ uint32_t part[kScanGroups][kScanTiles];
@@ -1037,13 +1084,19 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
         return k ? k : 1u;
     };
     uint32_t s = 0, slabs = 0;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
+    for (int q = 0; q < per; ++q) {  // (uniform trip count: the bucket updates are wave-wide)
+        const int i = i0 + q;
+        const bool live = i < NT;
+        const uint32_t c = live ? tile_npts[i] : 0u, nd = live ? tile_ndesc[i] : 0u;
         s += nd;
         const uint32_t k = parts_of(c, nd);
         const uint32_t sz = (c + k - 1) / k;  // records per part (estimate)
-        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
-        if (k > 1) slabs += k;
+        const int bucket = sz ? 32 - __clz(sz) : 0;
+        bucket_add_one<false>(bcount, bucket, live && k == 1);
+        if (live && k > 1) {
+            atomicAdd(&bcount[bucket], k);
+            slabs += k;
+        }
     }
     uint32_t incl = s, incl_slab = slabs;
 #pragma unroll
@@ -1075,27 +1128,38 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
     }
     __syncthreads();
     uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
-        tile_dstart[i] = run;
-        tile_cursor[i] = 0;
+    for (int q = 0; q < per; ++q) {
+        const int i = i0 + q;
+        const bool live = i < NT;
+        const uint32_t c = live ? tile_npts[i] : 0u, nd = live ? tile_ndesc[i] : 0u;
         const uint32_t k = parts_of(c, nd);
         const uint32_t sz = (c + k - 1) / k;
         const uint32_t dsz = (nd + k - 1) / k;  // descriptors per part
         const int bucket = sz ? 32 - __clz(sz) : 0;
+        const uint32_t pos1 = bucket_add_one<true>(bstart, bucket, live && k == 1);
+        if (!live) continue;
+        tile_dstart[i] = run;
+        tile_cursor[i] = 0;
         tile_parts[i] = k;
         tile_slab[i] = slab_run;
-        for (uint32_t part = 0; part < k; ++part) {
+        if (k == 1) {
             WorkItem it;
             it.tile = (uint32_t)i;
-            it.begin = run + part * dsz;
-            it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
-            if (it.begin > run + nd) it.begin = run + nd;
-            it.part_nparts = part | (k << 16);
-            const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
-            if (pos < (uint32_t)max_items) items[pos] = it;
-        }
-        if (k > 1) {
+            it.begin = run;
+            it.end = run + nd;
+            it.part_nparts = 0u | (1u << 16);
+            if (pos1 < (uint32_t)max_items) items[pos1] = it;
+        } else {
+            for (uint32_t part = 0; part < k; ++part) {
+                WorkItem it;
+                it.tile = (uint32_t)i;
+                it.begin = run + part * dsz;
+                it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
+                if (it.begin > run + nd) it.begin = run + nd;
+                it.part_nparts = part | (k << 16);
+                const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
+                if (pos < (uint32_t)max_items) items[pos] = it;
+            }
             slab_run += k;
             split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
         }
@@ -2072,7 +2136,12 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
                 const uint32_t rcur = nxt_phys;
                 r += kGatherThreads;
                 if (r < r1r) {
+#ifdef DPR_RUNS_SEEK
+                    cu.seek(rt, r, nruns);  // experiment: fixed-depth search instead of the cursor
+                    nxt_phys = cu.pos;
+#else
                     nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1r);
+#endif
                     nxt = rec[nxt_phys];
                     if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
                 }
@@ -2597,6 +2666,10 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
     // ~6e4 points; the direct pullback kernel, which keeps a point in registers across the poses
     // of a slice, stays ahead up to ~3e5 points (~6e5 when the grid is too large for groups).
     const bool grouped = B >= 4 && pose_group(NT, P, B, 0) >= 4;
+    // (one pose on a small grid -- up to 256^2 or 128^3: from 1e5 points -- the direct kernel's atomics are
+    // at most 1.25x ahead there on a cloud that fills the grid and 2x behind on a clustered one,
+    // profiles/r03_auto_regret.txt)
+    if (op == DPR_OP_RASTER && B == 1 && (NT <= 64 || (n_out == 3 && NT <= 256))) return P >= 100000;
     if (op == DPR_OP_RASTER) return P >= (grouped ? 60000 : 250000);
     if (B >= 4) return P >= (grouped ? 300000 : 600000);
     return P >= 250000;

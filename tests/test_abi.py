@@ -145,7 +145,17 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     # batched poses on a grid with few tiles: pose groups repay the forward binning earlier,
     # the direct pullback kernel stays ahead longer (profiles/r01_algo_sweep_batched.txt)
     assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 16, 3) == "tiled"
-    assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 1, 3) == "atomic"
+    # one pose: the direct kernels up to 2.5e5 points -- on small grids (<= 128^3) only up to 1e5:
+    # their atomics are 2x behind there on a clustered cloud (profiles/r03_auto_regret.txt)
+    assert dpr_amd.resolve_algo("raster", (256, 256, 256), 100_000, 1, 3) == "atomic"
+    assert dpr_amd.resolve_algo("raster", (128, 128, 128), 100_000, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (128, 128, 128), 50_000, 1, 3) == "atomic"
+    # 3-D chunk lists: forward over several poses of a coherent cloud that is sparse on the grid
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 64, 3, coherent_points=True) == "atomic"
     assert dpr_amd.resolve_algo("pullback", (512, 512), 20_000, 64, 3) == "atomic"
     # many poses onto a 2-D grid: chunk-owned LDS tiles with the pose loop inside
     assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3) == "chunked"
