@@ -124,7 +124,14 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
     return P * 10 <= G;
 }
 
+// (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both
+// (/root/reference/src/raster.jl:5-13, src/util.jl:26-27).  The three shapes its tests use --
+// (2,2), (3,3), (3,2) -- have every algorithm; the others ((1,1), (2,1), (3,1)) run on the direct
+// kernels (DPR_ALGO_ATOMIC), which are templates over both dimensions.
 static bool dims_supported(int n_in, int n_out) {
+    return n_out >= 1 && n_out <= n_in && n_in <= 3;
+}
+static bool dims_have_all_algos(int n_in, int n_out) {
     return (n_in == 2 && n_out == 2) || (n_in == 3 && n_out == 3) || (n_in == 3 && n_out == 2);
 }
 
@@ -132,7 +139,7 @@ static int check_common(int n_in, int n_out, const int64_t* grid, int64_t P, int
                         int64_t* G_out) {
     if (!dims_supported(n_in, n_out))
         return fail(DPR_ERR_UNSUPPORTED_DIMS,
-                    "unsupported (n_in, n_out) = (%d, %d); supported: (2,2), (3,3), (3,2)", n_in,
+                    "unsupported (n_in, n_out) = (%d, %d); supported: 1 <= n_out <= n_in <= 3", n_in,
                     n_out);
     if (!grid) return fail(DPR_ERR_INVALID_ARG, "grid is NULL");
     if (P < 0 || B < 0) return fail(DPR_ERR_INVALID_ARG, "negative P (%lld) or B (%lld)",
@@ -164,6 +171,12 @@ template <int NO> static GridDesc<NO> make_grid(const int64_t* grid, int64_t G) 
 // An explicit algorithm keeps the strict behaviour (error).
 static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* grid, int64_t P,
                         int64_t B, int64_t G, unsigned* flags) {
+    if (!dims_have_all_algos(n_in, n_out)) {
+        // direct kernels only: AUTO drops the sharing flags (nothing to keep), an explicit other
+        // algorithm is refused by the dispatch below
+        if (algo == DPR_ALGO_AUTO) *flags &= ~3u;
+        return algo == DPR_ALGO_AUTO ? DPR_ALGO_ATOMIC : algo;
+    }
     if (algo != DPR_ALGO_AUTO) return algo;
     const bool coherent = (*flags & DPR_FLAG_COHERENT_POINTS) != 0;
     if (*flags & 3u) {
@@ -277,6 +290,16 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
     DPR_CASE(3, 3)
     DPR_CASE(3, 2)
 #undef DPR_CASE
+#define DPR_CASE_DIRECT(NI, NO)                                                                 \
+    if (n_in == NI && n_out == NO && algo == DPR_ALGO_ATOMIC && !(flags & 3u))                  \
+        return raster_atomic<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow, pw);
+    DPR_CASE_DIRECT(1, 1)
+    DPR_CASE_DIRECT(2, 1)
+    DPR_CASE_DIRECT(3, 1)
+#undef DPR_CASE_DIRECT
+    if (!dims_have_all_algos(n_in, n_out))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO,
+                    "(n_in, n_out) = (%d, %d) runs on DPR_ALGO_ATOMIC only (no flags)", n_in, n_out);
     return fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d (flags %u need DPR_ALGO_TILED)", algo,
                 flags);
 }
@@ -386,6 +409,17 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     DPR_CASE(3, 3)
     DPR_CASE(3, 2)
 #undef DPR_CASE
+#define DPR_CASE_DIRECT(NI, NO)                                                                   \
+    if (n_in == NI && n_out == NO && algo == DPR_ALGO_ATOMIC && !(flags & 3u))                    \
+        return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw, d_pts, \
+                                          d_rot, d_trans, d_bg, d_ow, d_pw, rs);
+    DPR_CASE_DIRECT(1, 1)
+    DPR_CASE_DIRECT(2, 1)
+    DPR_CASE_DIRECT(3, 1)
+#undef DPR_CASE_DIRECT
+    if (!dims_have_all_algos(n_in, n_out))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO,
+                    "(n_in, n_out) = (%d, %d) runs on DPR_ALGO_ATOMIC only (no flags)", n_in, n_out);
     return fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
 }
 
@@ -400,6 +434,11 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
     }
     algo = resolve_algo(algo, op, n_in, n_out, grid, P, B, G, &flags);
     if (algo == DPR_ALGO_ATOMIC) return 0;
+    if (!dims_have_all_algos(n_in, n_out)) {
+        fail(DPR_ERR_UNSUPPORTED_ALGO, "(n_in, n_out) = (%d, %d) runs on DPR_ALGO_ATOMIC only", n_in,
+             n_out);
+        return (size_t)-1;
+    }
     if (algo == DPR_ALGO_TILED) {
         const size_t n = tiled_workspace_bytes(sizeof(T), op, flags, n_in, n_out, grid, P, B);
         if (n == (size_t)-1)

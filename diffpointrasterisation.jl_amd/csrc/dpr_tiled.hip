@@ -450,32 +450,6 @@ __device__ __forceinline__ uint32_t load_runs(RunTable<N>& rt, const RunDesc* __
 // exclusive scan of totals[NT] -> tile_start[NT + 1]   (single block, NT <= 32768), and the
 // work list: items[] ordered by decreasing size (log2 buckets; the heaviest items are
 // dispatched first), n_items, and per tile the number of parts and its first overflow slab.
-// Bucket counters of the work-list builders (33 log2-size buckets in LDS).  Nearly every tile of a
-// cloud falls into the same two or three buckets, so per-lane atomics on them serialise (~3
-// cycles per lane: 2 x 2048 of them were most of k_tilescan's 6.7 us).  One atomic per distinct
-// bucket and wave instead: the lanes of `active` that share the leader's bucket add `amount`
-// each (the common amount 1 by popcount) and get consecutive positions.
-//   returns the lane's position (base + rank among the lanes of its bucket) when RETURNING
-template <bool RETURNING>
-__device__ __forceinline__ uint32_t bucket_add_one(uint32_t* buckets, int bucket, bool active) {
-    const int lane = threadIdx.x & (kWave - 1);
-    unsigned long long todo = __ballot(active);
-    uint32_t pos = 0;
-    while (todo) {  // wave-uniform
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lb = __shfl(bucket, leader, kWave);
-        const unsigned long long same = __ballot(active && bucket == lb) & todo;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&buckets[lb], (uint32_t)__popcll(same));
-        if (RETURNING) {
-            base = __shfl(base, leader, kWave);
-            if ((same >> lane) & 1ull) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        }
-        todo &= ~same;
-    }
-    return pos;
-}
-
 // Everything the tile scan reads and writes (one struct: the scan kernel carries it along).
 struct TileScanArgs {
     const uint32_t* totals;
@@ -541,19 +515,16 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
     const int per = (NT + 1023) / 1024;
     const int i0 = threadIdx.x * per;
     uint32_t s = 0, slabs = 0;
-    for (int q = 0; q < per; ++q) {  // (uniform trip count: the bucket updates are wave-wide)
-        const int i = i0 + q;
-        const bool live = i < NT;
-        const uint32_t c = live ? totals[i] : 0u;
+    // (Round 3 tried one LDS atomic per (wave, bucket) by ballot instead of one per tile -- nearly
+    // all tiles share two or three buckets: the serial ballot / shuffle / returning-atomic round
+    // trips cost more than the same-address atomics they replace, scan stage 18.5 -> 22.2 us.)
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = totals[i];
         s += c;
         const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
         const uint32_t sz = (c + k - 1) / k;  // records per part
-        const int bucket = sz ? 32 - __clz(sz) : 0;
-        bucket_add_one<false>(bcount, bucket, live && k == 1);
-        if (live && k > 1) {
-            atomicAdd(&bcount[bucket], k);
-            slabs += k;
-        }
+        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
+        if (k > 1) slabs += k;
     }
     uint32_t incl = s, incl_slab = slabs;
 #pragma unroll
@@ -584,36 +555,24 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
     }
     __syncthreads();
     uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
-    for (int q = 0; q < per; ++q) {
-        const int i = i0 + q;
-        const bool live = i < NT;
-        const uint32_t c = live ? totals[i] : 0u;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = totals[i];
+        tile_start[i] = run;
         const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
         const uint32_t sz = (c + k - 1) / k;
         const int bucket = sz ? 32 - __clz(sz) : 0;
-        // the usual case, a tile that is one work item: positions handed out per wave and bucket
-        const uint32_t pos1 = bucket_add_one<true>(bstart, bucket, live && k == 1);
-        if (!live) continue;
-        tile_start[i] = run;
         tile_parts[i] = k;
         tile_slab[i] = slab_run;
-        if (k == 1) {
+        for (uint32_t part = 0; part < k; ++part) {
             WorkItem it;
             it.tile = (uint32_t)i;
-            it.begin = run;
-            it.end = run + c;
-            it.part_nparts = 0u | (1u << 16);
-            items[pos1] = it;
-        } else {
-            for (uint32_t part = 0; part < k; ++part) {
-                WorkItem it;
-                it.tile = (uint32_t)i;
-                it.begin = run + part * sz;
-                it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
-                if (it.begin > run + c) it.begin = run + c;
-                it.part_nparts = part | (k << 16);
-                items[atomicAdd(&bstart[bucket], 1u)] = it;
-            }
+            it.begin = run + part * sz;
+            it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
+            if (it.begin > run + c) it.begin = run + c;
+            it.part_nparts = part | (k << 16);
+            items[atomicAdd(&bstart[bucket], 1u)] = it;
+        }
+        if (k > 1) {
             slab_run += k;
             split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
         }
@@ -1084,19 +1043,13 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
         return k ? k : 1u;
     };
     uint32_t s = 0, slabs = 0;
-    for (int q = 0; q < per; ++q) {  // (uniform trip count: the bucket updates are wave-wide)
-        const int i = i0 + q;
-        const bool live = i < NT;
-        const uint32_t c = live ? tile_npts[i] : 0u, nd = live ? tile_ndesc[i] : 0u;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
         s += nd;
         const uint32_t k = parts_of(c, nd);
         const uint32_t sz = (c + k - 1) / k;  // records per part (estimate)
-        const int bucket = sz ? 32 - __clz(sz) : 0;
-        bucket_add_one<false>(bcount, bucket, live && k == 1);
-        if (live && k > 1) {
-            atomicAdd(&bcount[bucket], k);
-            slabs += k;
-        }
+        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
+        if (k > 1) slabs += k;
     }
     uint32_t incl = s, incl_slab = slabs;
 #pragma unroll
@@ -1128,38 +1081,27 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
     }
     __syncthreads();
     uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
-    for (int q = 0; q < per; ++q) {
-        const int i = i0 + q;
-        const bool live = i < NT;
-        const uint32_t c = live ? tile_npts[i] : 0u, nd = live ? tile_ndesc[i] : 0u;
+    for (int i = i0; i < i0 + per && i < NT; ++i) {
+        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
+        tile_dstart[i] = run;
+        tile_cursor[i] = 0;
         const uint32_t k = parts_of(c, nd);
         const uint32_t sz = (c + k - 1) / k;
         const uint32_t dsz = (nd + k - 1) / k;  // descriptors per part
         const int bucket = sz ? 32 - __clz(sz) : 0;
-        const uint32_t pos1 = bucket_add_one<true>(bstart, bucket, live && k == 1);
-        if (!live) continue;
-        tile_dstart[i] = run;
-        tile_cursor[i] = 0;
         tile_parts[i] = k;
         tile_slab[i] = slab_run;
-        if (k == 1) {
+        for (uint32_t part = 0; part < k; ++part) {
             WorkItem it;
             it.tile = (uint32_t)i;
-            it.begin = run;
-            it.end = run + nd;
-            it.part_nparts = 0u | (1u << 16);
-            if (pos1 < (uint32_t)max_items) items[pos1] = it;
-        } else {
-            for (uint32_t part = 0; part < k; ++part) {
-                WorkItem it;
-                it.tile = (uint32_t)i;
-                it.begin = run + part * dsz;
-                it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
-                if (it.begin > run + nd) it.begin = run + nd;
-                it.part_nparts = part | (k << 16);
-                const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
-                if (pos < (uint32_t)max_items) items[pos] = it;
-            }
+            it.begin = run + part * dsz;
+            it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
+            if (it.begin > run + nd) it.begin = run + nd;
+            it.part_nparts = part | (k << 16);
+            const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
+            if (pos < (uint32_t)max_items) items[pos] = it;
+        }
+        if (k > 1) {
             slab_run += k;
             split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
         }
@@ -2136,12 +2078,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
                 const uint32_t rcur = nxt_phys;
                 r += kGatherThreads;
                 if (r < r1r) {
-#ifdef DPR_RUNS_SEEK
-                    cu.seek(rt, r, nruns);  // experiment: fixed-depth search instead of the cursor
-                    nxt_phys = cu.pos;
-#else
                     nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1r);
-#endif
                     nxt = rec[nxt_phys];
                     if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
                 }
@@ -2271,6 +2208,61 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
     }
 }
 
+// ------------------------------------------------------------------ pullback K5 (body)
+// partials[NVAL][items] (f64) -> the per-pose outputs: one block of 1024 threads per (scalar k,
+// pose j of the group); an item belongs to pose item.tile / NT.  Runs as k_pose_reduce or, for a
+// single pose, as the first blocks of k_unpermute (one launch and its gap less per pullback).
+template <typename T> struct PoseReduceArgs {
+    const double* partials;
+    const WorkItem* items;
+    const uint32_t* n_items;
+    int max_items, NT, n_in, n_out;
+    int64_t b0;
+    T* ds_drotation;
+    T* ds_dtranslation;
+    T* ds_dbackground;
+    T* ds_dout_weight;
+    T* loss;
+    BinHeader* hdr;
+};
+template <typename T>
+__device__ __forceinline__ void pose_reduce_body(int k, uint32_t j, bool grouped,
+                                                 const PoseReduceArgs<T>& a) {
+    __shared__ double wsum[16];
+    const int64_t b = a.b0 + j;
+    double s = 0.0;
+    const bool stale = a.hdr && a.hdr->verdict != 1u;  // see k_tile_gather
+    // the binning is consumed: the gradient records have overwritten the point records
+    if (a.hdr && k == 0 && j == 0 && threadIdx.x == 0) a.hdr->state = 0u;
+    const int n = stale ? 0 : (int)*a.n_items;
+    if (!grouped) {
+        for (int t = threadIdx.x; t < n; t += 1024) s += a.partials[(size_t)k * a.max_items + t];
+    } else {
+        for (int t = threadIdx.x; t < n; t += 1024)
+            if (a.items[t].tile / (uint32_t)a.NT == j) s += a.partials[(size_t)k * a.max_items + t];
+    }
+    s = wave_sum<double>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (stale) tot = __builtin_nan("");
+        const int nr = a.n_out * a.n_in;
+        if (k < nr)
+            a.ds_drotation[b * nr + k] = (T)tot;
+        else if (k < nr + a.n_out)
+            a.ds_dtranslation[b * a.n_out + (k - nr)] = (T)tot;
+        else if (k == nr + a.n_out)
+            a.ds_dout_weight[b] = (T)tot;
+        else if (k == nr + a.n_out + 1)
+            a.ds_dbackground[b] = (T)tot;
+        else if (a.loss)
+            a.loss[b] = (T)tot;
+    }
+}
+
 // ------------------------------------------------------------------ pullback un-permute
 // thread per ORIGINAL point: gradient record(s) of its slot(s) -> ds_dpoints /
 // ds_dpoint_weight (coalesced stores; accumulating over poses when !FIRST_POSE).  A pose
@@ -2281,11 +2273,19 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
                                                     const uint32_t* __restrict__ slot_of,
                                                     T* __restrict__ ds_dpoints,
                                                     T* __restrict__ ds_dpw,
-                                                    const BinHeader* __restrict__ hdr) {
+                                                    const BinHeader* __restrict__ hdr,
+                                                    int reduce_blocks, PoseReduceArgs<T> pr) {
+    // the first `reduce_blocks` blocks are the per-pose reduction (single pose only)
+    if ((int)blockIdx.x < reduce_blocks) {
+        pose_reduce_body<T>((int)blockIdx.x, 0u, false, pr);
+        return;
+    }
+    const unsigned ublock = blockIdx.x - (unsigned)reduce_blocks;
+    const unsigned ublocks = gridDim.x - (unsigned)reduce_blocks;
     if (hdr && hdr->verdict != 1u) {
         // REUSE_BINNING without a matching KEEP_BINNING forward: no gradient was computed
         const T nan = T(__builtin_nanf(""));
-        const int64_t b0 = (int64_t)blockIdx.x * (kUPB * 1024) + threadIdx.x;
+        const int64_t b0 = (int64_t)ublock * (kUPB * 1024) + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < kUPB; ++k) {
             const int64_t p = b0 + k * 1024;
@@ -2299,7 +2299,7 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
     // One block covers kUPB * 1024 consecutive points = one sub-chunk of the scatter: points of
     // a sub-chunk that fell into the same tile sit next to each other in that tile's record
     // run, so the 64-byte sectors this block fetches are shared among its own threads.
-    const int64_t base = (int64_t)xcd_slice(blockIdx.x, gridDim.x) * (kUPB * 1024) + threadIdx.x;
+    const int64_t base = (int64_t)xcd_slice(ublock, ublocks) * (kUPB * 1024) + threadIdx.x;
     uint32_t slot[kUPB];
 #pragma unroll
     for (int k = 0; k < kUPB; ++k) {
@@ -2335,52 +2335,10 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
 }
 
 // ------------------------------------------------------------------ pullback K5
-// partials[NVAL][items] (f64) -> the per-pose outputs.  One block per (scalar, pose of the
-// group); an item belongs to pose item.tile / NT.
-template <typename T, int NI, int NO>
-__global__ __launch_bounds__(1024) void k_pose_reduce(const double* __restrict__ partials,
-                                                      const WorkItem* __restrict__ items,
-                                                      const uint32_t* __restrict__ n_items,
-                                                      int max_items, int NT, int64_t b0,
-                                                      T* __restrict__ ds_drotation,
-                                                      T* __restrict__ ds_dtranslation,
-                                                      T* __restrict__ ds_dbackground,
-                                                      T* __restrict__ ds_dout_weight,
-                                                      T* __restrict__ loss, BinHeader* hdr) {
-    __shared__ double wsum[16];
-    const int k = blockIdx.x;
-    const uint32_t j = blockIdx.y;
-    const int64_t b = b0 + j;
-    double s = 0.0;
-    const bool stale = hdr && hdr->verdict != 1u;  // see k_tile_gather
-    // the binning is consumed: the gradient records have overwritten the point records
-    if (hdr && k == 0 && j == 0 && threadIdx.x == 0) hdr->state = 0u;
-    const int n = stale ? 0 : (int)*n_items;
-    if (gridDim.y == 1) {
-        for (int t = threadIdx.x; t < n; t += 1024) s += partials[(size_t)k * max_items + t];
-    } else {
-        for (int t = threadIdx.x; t < n; t += 1024)
-            if (items[t].tile / (uint32_t)NT == j) s += partials[(size_t)k * max_items + t];
-    }
-    s = wave_sum<double>(s);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) tot += wsum[w];
-        if (stale) tot = __builtin_nan("");
-        if (k < NO * NI)
-            ds_drotation[b * (NO * NI) + k] = (T)tot;
-        else if (k < NO * NI + NO)
-            ds_dtranslation[b * NO + (k - NO * NI)] = (T)tot;
-        else if (k == NO * NI + NO)
-            ds_dout_weight[b] = (T)tot;
-        else if (k == NO * NI + NO + 1)
-            ds_dbackground[b] = (T)tot;
-        else if (loss)
-            loss[b] = (T)tot;
-    }
+// (pose groups and the direct-store mode: the reduction as a launch of its own)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_pose_reduce(PoseReduceArgs<T> pr) {
+    pose_reduce_body<T>((int)blockIdx.x, blockIdx.y, gridDim.y > 1, pr);
 }
 
 // gradients of an internally sorted cloud back to the caller's order: dst[perm[i]] = src[i]
@@ -3073,6 +3031,23 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         // per-pose part of the workspace (one copy, or one per pose when the binning was kept)
         char* const wsb = ws + (size_t)b * pl.pose_stride;
         BinHeader* hdr = reuse ? (BinHeader*)(wsb + pl.off_hdr) : (BinHeader*)nullptr;
+        PoseReduceArgs<T> pr;
+        pr.partials = partials;
+        pr.items = (const WorkItem*)(wsb + pl.off_items);
+        pr.n_items = (const uint32_t*)(wsb + pl.off_nitems);
+        pr.max_items = pl.max_items;
+        pr.NT = tg.NT;
+        pr.n_in = NI;
+        pr.n_out = NO;
+        pr.b0 = b;
+        pr.ds_drotation = d_rot;
+        pr.ds_dtranslation = d_trans;
+        pr.ds_dbackground = d_bg;
+        pr.ds_dout_weight = d_ow;
+        pr.loss = rs.target ? rs.loss : nullptr;
+        pr.hdr = hdr;
+        const unsigned n_reduce = (unsigned)(rs.target ? NVAL + 1 : NVAL);
+        bool reduced = false;
         // a pose group always goes through the gradient records (several (pose, tile) blocks
         // own the same point, so they cannot store to ds_dpoints directly)
         const bool unperm = unperm1 || nb > 1;
@@ -3124,17 +3099,20 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             if (P > 0) {
                 // one pose: a block covers a whole scatter sub-chunk (4 points per thread); a
                 // pose group already has nb gradient records in flight per point
-#define DPR_LAUNCH_UNPERM(FIRST, UPB)                                                            \
+#define DPR_LAUNCH_UNPERM(FIRST, UPB, RB)                                                        \
     hipLaunchKernelGGL((k_unpermute<T, NI, FIRST, UPB>),                                         \
-                       dim3((unsigned)((P + UPB * 1024 - 1) / (UPB * 1024))), dim3(1024), 0, st, \
-                       P, (int)nb, (const Rec4<T>*)(wsb + pl.off_rec),                           \
-                       (const uint32_t*)(wsb + pl.off_slot), d_pts, d_pw, (const BinHeader*)hdr)
+                       dim3((unsigned)((P + UPB * 1024 - 1) / (UPB * 1024)) + (RB)), dim3(1024), \
+                       0, st, P, (int)nb, (const Rec4<T>*)(wsb + pl.off_rec),                    \
+                       (const uint32_t*)(wsb + pl.off_slot), d_pts, d_pw, (const BinHeader*)hdr, \
+                       (int)(RB), pr)
                 if (nb > 1) {
-                    if (b == 0) DPR_LAUNCH_UNPERM(true, 1);
-                    else DPR_LAUNCH_UNPERM(false, 1);
+                    if (b == 0) DPR_LAUNCH_UNPERM(true, 1, 0);
+                    else DPR_LAUNCH_UNPERM(false, 1, 0);
                 } else {
-                    if (b == 0) DPR_LAUNCH_UNPERM(true, 4);
-                    else DPR_LAUNCH_UNPERM(false, 4);
+                    // one pose: the per-pose reduction rides in the same launch
+                    if (b == 0) DPR_LAUNCH_UNPERM(true, 4, n_reduce);
+                    else DPR_LAUNCH_UNPERM(false, 4, n_reduce);
+                    reduced = true;
                 }
 #undef DPR_LAUNCH_UNPERM
             }
@@ -3152,11 +3130,9 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
 #undef DPR_LAUNCH_GATHER_RUNS
 #undef DPR_LAUNCH_GATHER_PLAIN
         stage_mark(st);
-        hipLaunchKernelGGL((k_pose_reduce<T, NI, NO>),
-                           dim3(rs.target ? NVAL + 1 : NVAL, (unsigned)nb), dim3(1024), 0, st,
-                           (const double*)partials, (const WorkItem*)(wsb + pl.off_items),
-                           (const uint32_t*)(wsb + pl.off_nitems), pl.max_items, tg.NT, b, d_rot,
-                           d_trans, d_bg, d_ow, rs.target ? rs.loss : nullptr, hdr);
+        if (!reduced)
+            hipLaunchKernelGGL((k_pose_reduce<T>), dim3(n_reduce, (unsigned)nb), dim3(1024), 0, st,
+                               pr);
         stage_mark(st);
     }
     if (pl.sort_inside && P > 0)

@@ -18,6 +18,8 @@ def uneven_batch(n_workers: int) -> int:
 
 
 def random_rotations(rng, batch, n=3):
+    if n == 1:  # "rotations" of the line: +-1
+        return rng.choice([-1.0, 1.0], size=(batch, 1, 1))
     if n == 2:
         th = rng.uniform(0, 2 * np.pi, batch)
         return np.stack([np.stack([np.cos(th), -np.sin(th)], -1),

@@ -69,7 +69,9 @@ def test_argument_errors_are_reported_without_a_device(suf):
             None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_INVALID_ARG
     pb = getattr(L, f"dpr_raster_pullback_{suf}")
-    rc = pb(None, 3, 1, gp, 10, 1, *([None] * 12), None, 0)
+    rc = pb(None, 1, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_out > n_in
+    assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
+    rc = pb(None, 4, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_in > 3
     assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
     ws = getattr(L, f"dpr_workspace_bytes_{suf}")
     assert ws(0, 0, 3, 3, gp, 1000, 2) != ctypes.c_size_t(-1).value

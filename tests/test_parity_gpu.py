@@ -139,6 +139,23 @@ def test_device_equals_oracle(oracle, dev, algo, npdt, tdt, n_in, n_out, n_point
     _compare(*_run_both(oracle, dev, d, npdt, algo), npdt)
 
 
+@pytest.mark.parametrize("algo", ["auto", "atomic"])
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out", [(1, 1), (2, 1), (3, 1)])
+@pytest.mark.parametrize("n_points,grid_n", [(10, 8), (30_000, 100), (400_000, 37)])
+def test_other_dimension_pairs_on_the_direct_kernels(oracle, dev, algo, npdt, tdt, n_in, n_out,
+                                                     n_points, grid_n):
+    """The reference is generic in (N_in, N_out) (src/raster.jl:5-13, src/util.jl:26-27); beyond
+    the three shapes its tests use, 1 <= N_out <= N_in <= 3 runs on the direct kernels: AUTO
+    resolves to them, the other algorithms are refused."""
+    d = D.make(n_points=n_points, n_in=n_in, n_out=n_out, batch=D.uneven_batch(4), grid_n=grid_n,
+               seed=19, dtype=npdt)
+    assert dpr_amd.resolve_algo("raster", d.grid, n_points, d.batch, n_in, sharing=True) == "atomic"
+    _compare(*_run_both(oracle, dev, d, npdt, algo), npdt)
+    with pytest.raises(dpr_amd.DprError):
+        dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), algo="tiled")
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
 @pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 37), (3, 2, 100), (2, 2, 33), (3, 3, 64)])
