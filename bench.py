@@ -125,7 +125,7 @@ def load_traffic_profile(cfg, algo_f, order):
     """HBM bytes per forward call from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in
     separate rocprofv3 passes of this same command and corrected as MI355X_MICROARCH.md
     prescribes); measured offline, committed under profiles/ -- bench.py cannot profile itself."""
-    for name in ("r02_c3_hbm_traffic.json", "r01_c3_hbm_traffic.json"):
+    for name in ("r03_c3_hbm_traffic.json", "r02_c3_hbm_traffic.json", "r01_c3_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

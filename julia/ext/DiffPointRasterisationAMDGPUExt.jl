@@ -310,6 +310,52 @@ function raster_pullback_reuse!(ds_dout::ROCArray{T,N_out}, points::ROCVector{<:
             point_weight=o_pw)
 end
 
+# Batch of poses (round 3: the library keeps the binning of EVERY pose of a batch on the tiled
+# path, and the sorted copy of the cloud on the chunk-owner path): same two calls with B poses.
+function raster_keep_batch!(out::ROCArray{T,N_out_p1}, points::ROCVector{<:StaticVector{N_in,T}},
+                            rotation::AbstractVector{<:StaticMatrix{N_out,N_in}},
+                            translation::AbstractVector{<:StaticVector{N_out}},
+                            background, out_weight, point_weight, ws) where {T,N_in,N_out,N_out_p1}
+    B = length(rotation)
+    rot, tr = devbuf(rotation, T), devbuf(translation, T)
+    bg, ow, pw = devbuf(background, T), devbuf(out_weight, T), devbuf(point_weight, T)
+    grid = collect(Int64, size(out)[1:N_out])
+    stream = AMDGPU.stream()
+    sym = T === Float32 ? :dpr_raster_ex_f32 : :dpr_raster_ex_f64
+    GC.@preserve out points rot tr bg ow pw ws begin
+        check(ccall((sym, libdpr), Cint,
+            (Ptr{Cvoid}, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
+            stream.stream, DPR_ALGO_AUTO, DPR_FLAG_KEEP_BINNING, N_in, N_out, grid, length(points), B,
+            devptr(out, T), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(bg, T),
+            devptr(ow, T), devptr(pw, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws)))
+    end
+    keep_until_done(stream, rot, tr, bg, ow, pw)
+    return rot, tr, ow, pw
+end
+
+function raster_pullback_reuse_batch!(ds_dout::ROCArray{T,N_out_p1}, points::ROCVector{<:StaticVector{N_in,T}},
+                                      rot, tr, ow, pw, ws) where {T,N_in,N_out_p1}
+    N_out = N_out_p1 - 1
+    P, B = length(points), size(ds_dout, N_out_p1)
+    o_pts = similar(ds_dout, T, (N_in, P))
+    o_rot, o_tr = similar(ds_dout, T, (N_out, N_in, B)), similar(ds_dout, T, (N_out, B))
+    o_bg, o_ow, o_pw = similar(ds_dout, T, B), similar(ds_dout, T, B), similar(ds_dout, T, P)
+    grid = collect(Int64, size(ds_dout)[1:N_out])
+    stream = AMDGPU.stream()
+    sym = T === Float32 ? :dpr_raster_pullback_ex_f32 : :dpr_raster_pullback_ex_f64
+    GC.@preserve ds_dout points rot tr ow pw o_pts o_rot o_tr o_bg o_ow o_pw ws begin
+        check(ccall((sym, libdpr), Cint,
+            (Ptr{Cvoid}, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
+            stream.stream, DPR_ALGO_AUTO, DPR_FLAG_REUSE_BINNING, N_in, N_out, grid, P, B,
+            devptr(ds_dout, T), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(ow, T),
+            devptr(pw, T), devptr(o_pts, T), devptr(o_rot, T), devptr(o_tr, T), devptr(o_bg, T),
+            devptr(o_ow, T), devptr(o_pw, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws)))
+    end
+    keep_until_done(stream, rot, tr, ow, pw, ws)
+    return (; points=o_pts, rotation=o_rot, translation=o_tr, background=o_bg, out_weight=o_ow,
+            point_weight=o_pw)
+end
+
 # The ChainRules `rrule` for ROCArray points (forward keeps the binning, the pullback closure
 # reuses it: `raster_keep!` / `raster_pullback_reuse!` above) needs BOTH AMDGPU and ChainRulesCore
 # and therefore lives in its own two-trigger extension,
