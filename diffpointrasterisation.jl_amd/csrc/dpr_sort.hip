@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void k_gather_points(int64_t P, const uint32_t
                                                        const T* __restrict__ points,
                                                        const T* __restrict__ pw,
                                                        T* __restrict__ points_sorted,
-                                                       T* __restrict__ pw_sorted) {
+                                                       T* __restrict__ pw_sorted,
+                                                       uint32_t* __restrict__ inv_perm) {
+    // inv_perm (optional): inv_perm[perm[i]] = i, for consumers that bring results back to the
+    // caller's order by GATHERING (random reads run ~1.7x faster than scattered stores here)
     const int64_t i0 = (int64_t)blockIdx.x * (256 * kGatherPer) + threadIdx.x;
     uint32_t p[kGatherPer];
 #pragma unroll
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(256) void k_gather_points(int64_t P, const uint32_t
 #pragma unroll
         for (int j = 0; j < NI; ++j) points_sorted[i * NI + j] = v[k][j];
         if (pw_sorted) pw_sorted[i] = w[k];
+        if (inv_perm) inv_perm[p[k]] = (uint32_t)i;
     }
 }
 
@@ -146,7 +150,8 @@ size_t sort_workspace_bytes(int64_t P) {
 
 template <typename T>
 int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
-                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes) {
+                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes,
+                     uint32_t* inv_perm) {
     if (n_in != 2 && n_in != 3)
         return fail(DPR_ERR_UNSUPPORTED_DIMS, "dpr_sort_points: n_in must be 2 or 3 (got %d)", n_in);
     if (P < 0 || P >= ((int64_t)1 << 32))
@@ -183,19 +188,19 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
     const dim3 ggrid((unsigned)((P + 256 * kGatherPer - 1) / (256 * kGatherPer)));
     if (n_in == 3)
         hipLaunchKernelGGL((k_gather_points<T, 3>), ggrid, dim3(256), 0, st, P, perm, points, pw,
-                           points_sorted, pw_sorted);
+                           points_sorted, pw_sorted, inv_perm);
     else
         hipLaunchKernelGGL((k_gather_points<T, 2>), ggrid, dim3(256), 0, st, P, perm, points, pw,
-                           points_sorted, pw_sorted);
+                           points_sorted, pw_sorted, inv_perm);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(DPR_ERR_HIP, "dpr_sort_points: %s", hipGetErrorString(e));
     return DPR_OK;
 }
 
 template int sort_points_impl<float>(void*, int, int64_t, const float*, float*, uint32_t*,
-                                     const float*, float*, void*, size_t);
+                                     const float*, float*, void*, size_t, uint32_t*);
 template int sort_points_impl<double>(void*, int, int64_t, const double*, double*, uint32_t*,
-                                      const double*, double*, void*, size_t);
+                                      const double*, double*, void*, size_t, uint32_t*);
 
 }  // namespace dpr
 
@@ -207,7 +212,7 @@ int dpr_sort_points_f32(void* stream, int n_in, int64_t P, const float* points,
                         float* points_sorted, uint32_t* perm, const float* point_weight,
                         float* point_weight_sorted, void* workspace, size_t workspace_bytes) {
     return dpr::sort_points_impl<float>(stream, n_in, P, points, points_sorted, perm, point_weight,
-                                        point_weight_sorted, workspace, workspace_bytes);
+                                        point_weight_sorted, workspace, workspace_bytes, nullptr);
 }
 
 int dpr_sort_points_f64(void* stream, int n_in, int64_t P, const double* points,
@@ -215,6 +220,6 @@ int dpr_sort_points_f64(void* stream, int n_in, int64_t P, const double* points,
                         double* point_weight_sorted, void* workspace, size_t workspace_bytes) {
     return dpr::sort_points_impl<double>(stream, n_in, P, points, points_sorted, perm,
                                          point_weight, point_weight_sorted, workspace,
-                                         workspace_bytes);
+                                         workspace_bytes, nullptr);
 }
 }

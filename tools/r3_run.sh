@@ -24,6 +24,8 @@ for step in "$@"; do
     bench_c5)   run bench_c5 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_c5_64) run bench_c5_64 900 python bench.py --config C5 --poses 64 --steps 2 --warmup 1 --no-cpu-baseline ;;
     bench_c5_noshare) run bench_c5_noshare 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline --no-share-binning ;;
+    fuzz_co)    run fuzz_co 900 python tools/fuzz_chunkown.py 600 ;;
+    fuzz_more)  run fuzz_more 900 python tools/fuzz_more.py ;;
     regret)     run regret 1000 python tools/auto_regret.py ;;
     regret_quick) run regret 600 python tools/auto_regret.py --quick ;;
     *) echo "unknown step $step"; exit 2 ;;
