@@ -52,7 +52,11 @@ constexpr int kCOWideBlocks = 512;                // grid of k_co_splat_wide (wa
 constexpr int kCOPPT = DPR_CO_PPT;               // points per thread
 constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
 constexpr int kCOWaves = kCOThreads / kWave;
-constexpr int kCOCap = 9216;                     // LDS tile cells (8 bytes each): 72 KiB, 2 blocks / CU
+#ifndef DPR_CO_CAP
+#define DPR_CO_CAP 10112
+#endif
+constexpr int kCOCap = DPR_CO_CAP;               // LDS tile cells (8 bytes each): 79 KiB, 2 blocks / CU
+                                                 // (9216 -> 10112: fewer wide pairs, C4 forward -2 %)
 constexpr int kCOWideCap = 2 * kCOCap;            // tile of k_co_splat_wide (one workgroup per CU)
 constexpr int kCOMaxSlice = 64;                  // poses per block (per-pose sums live in LDS)
 static_assert(kCOChunk / kWave == kCOWaves * kCOPPT, "spread assignment covers the chunk");
@@ -184,6 +188,36 @@ __device__ __forceinline__ int64_t co_footprint(const T (&c)[NI], const T (&h)[N
     return cells;
 }
 
+#ifdef DPR_CO_FOOT_TABLE
+// Footprints of the block's poses, computed ONCE per pose by one thread each and parked in LDS
+// (every thread recomputing them cost ~50 VALU per pose: a tenth of the pose loop's instructions).
+// Ends with a barrier.  foot[j] = {lo0, lo1, hi0, hi1} of pose b_lo + j.
+template <typename T, int NI>
+__device__ __forceinline__ void co_fill_footprints(int (*foot)[4], const T (&c)[NI], const T (&h)[NI],
+                                                   const GridDesc<2>& gd, const T* __restrict__ rot,
+                                                   const T* __restrict__ trans, int64_t b_lo, int nbs) {
+    if ((int)threadIdx.x < nbs) {
+        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, nullptr, b_lo + threadIdx.x);
+        int lo[2], hi[2];
+        (void)co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+        foot[threadIdx.x][0] = lo[0];
+        foot[threadIdx.x][1] = lo[1];
+        foot[threadIdx.x][2] = hi[0];
+        foot[threadIdx.x][3] = hi[1];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ int64_t co_read_footprint(const int (*foot)[4], int j, int (&lo)[2],
+                                                     int (&hi)[2]) {
+    lo[0] = foot[j][0];
+    lo[1] = foot[j][1];
+    hi[0] = foot[j][2];
+    hi[1] = foot[j][3];
+    const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
+    return (W > 0 && H > 0) ? (int64_t)W * H : 0;
+}
+#endif
+
 // What a DPR_FLAG_KEEP_BINNING forward leaves at the start of the workspace: the identity of the
 // cloud whose sorted copy (+ permutation) follows.  A DPR_FLAG_REUSE_BINNING pullback skips its
 // own sort and checks this ON THE DEVICE; on a mismatch it reads nothing through the stale
@@ -239,11 +273,19 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     // pixels, and float atomics of many workgroups into the same rows at the same time run an
     // order of magnitude slower than spread ones.
     const int rot0 = nbs > 0 ? (int)(blockIdx.x % (unsigned)nbs) : 0;
+#ifdef DPR_CO_FOOT_TABLE
+    __shared__ int foot[kCOMaxSlice][4];
+    co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, nbs);
+#endif
     for (int jb = 0; jb < nbs; ++jb) {
         const int64_t b = b_lo + (jb + rot0) % nbs;
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
+#ifdef DPR_CO_FOOT_TABLE
+        const int64_t cells = co_read_footprint(foot, (int)(b - b_lo), lo, hi);
+#else
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+#endif
         if (cells == 0) continue;  // uniform
         if (cells > kCOCap) {  // uniform: left to k_co_splat_wide
             if (threadIdx.x == 0)
@@ -261,6 +303,31 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
             const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
             const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
             const int lx0 = ref0[0] - lo[0], ly0 = ref0[1] - lo[1];
+#ifndef DPR_CO_SPLAT_PER_NEIGHBOUR
+            // one range test for all four neighbours (the footprint is clipped to the grid; round 3:
+            // C4 forward 4.04 -> 4.00 ms; the same change in the gather kernel: 4.69 -> 4.16 ms)
+            if (ok && (unsigned)lx0 < (unsigned)(W - 1) && (unsigned)ly0 < (unsigned)(H - 1)) {
+                double* b0 = &acc[ly0 * W + lx0];
+                atomicAdd(b0, (double)voxel_weight<T, 2>(dlo, 0, wk));
+                atomicAdd(b0 + 1, (double)voxel_weight<T, 2>(dlo, 1, wk));
+                atomicAdd(b0 + W, (double)voxel_weight<T, 2>(dlo, 2, wk));
+                atomicAdd(b0 + W + 1, (double)voxel_weight<T, 2>(dlo, 3, wk));
+            } else if (ok) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    int lx = lx0 + (s & 1), ly = ly0 + (s >> 1);
+                    asm volatile("" : "+v"(lx), "+v"(ly));  // keep this path out of the hot one
+                    const T v = voxel_weight<T, 2>(dlo, s, wk);
+                    if ((unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)H) {
+                        atomicAdd(&acc[ly * W + lx], (double)v);
+                    } else {
+                        const int ix = lx + lo[0], iy = ly + lo[1];
+                        if (ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1])
+                            atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
+                    }
+                }
+            }
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int lx = lx0 + (s & 1), ly = ly0 + (s >> 1);
@@ -274,6 +341,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
                         atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
                 }
             }
+#endif
         }
         lds_barrier();
         // flush + re-zero: one wave per image row segment, contiguous x across the lanes
@@ -432,10 +500,18 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     }
     const int64_t b_lo = (int64_t)blockIdx.y * poses_per_slice;
     const int64_t b_hi = (b_lo + poses_per_slice < B) ? b_lo + poses_per_slice : B;
+#ifdef DPR_CO_FOOT_TABLE
+    __shared__ int foot[kCOMaxSlice][4];
+    co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, any ? (int)(b_hi - b_lo) : 0);
+#endif
     for (int64_t b = b_lo; any && b < b_hi; ++b) {
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
+#ifdef DPR_CO_FOOT_TABLE
+        const int64_t cells = co_read_footprint(foot, (int)(b - b_lo), lo, hi);
+#else
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+#endif
         if (cells == 0) continue;  // uniform: no neighbour of the chunk is in the grid (sums stay 0)
         // A footprint that does not fit the LDS tile (sparse tails of the cloud, incoherent
         // input) is gathered from global memory directly (L2-resident image; unlike the
@@ -469,19 +545,39 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
             if (!ok) continue;  // no in-range neighbour (or non-finite): empty gradient
             const T pwi = HAS_PW ? w[k] : T(1);
             T dcoord[2] = {T(0), T(0)}, dow_part = T(0), dpw_part = T(0);
+            // all four neighbours inside the staged footprint (which is clipped to the grid): two
+            // unsigned compares instead of eight signed range tests per neighbour
+            T gq[4];
+            {
+                const int lx0 = ref0[0] - lo[0], ly0 = ref0[1] - lo[1];
+                if (fits && (unsigned)lx0 < (unsigned)(W - 1) && (unsigned)ly0 < (unsigned)(H - 1)) {
+                    const T* b0 = &tile[ly0 * W + lx0];
+                    gq[0] = b0[0];
+                    gq[1] = b0[1];
+                    gq[2] = b0[W];
+                    gq[3] = b0[W + 1];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        int ix = ref0[0] + (s & 1), iy = ref0[1] + (s >> 1);
+                        asm volatile("" : "+v"(ix), "+v"(iy));  // keep this path out of the hot one
+                        const bool in = ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1];
+                        const bool in_tile = fits && ix >= lo[0] && ix <= hi[0] && iy >= lo[1] && iy <= hi[1];
+                        T gi = T(0);
+                        if (in && in_tile) {
+                            gi = tile[(iy - lo[1]) * W + (ix - lo[0])];
+                        } else if (in) {
+                            const size_t off = (size_t)iy * gd.n[0] + ix;
+                            gi = gb[off];
+                            if (tb) gi = rs.scale * (gi - tb[off]);
+                        }
+                        gq[s] = gi;
+                    }
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int ix = ref0[0] + (s & 1), iy = ref0[1] + (s >> 1);
-                const bool in = ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1];
-                const bool in_tile = fits && ix >= lo[0] && ix <= hi[0] && iy >= lo[1] && iy <= hi[1];
-                T gi = T(0);
-                if (in && in_tile) {
-                    gi = tile[(iy - lo[1]) * W + (ix - lo[0])];
-                } else if (in) {
-                    const size_t off = (size_t)iy * gd.n[0] + ix;
-                    gi = gb[off];
-                    if (tb) gi = rs.scale * (gi - tb[off]);
-                }
+                const T gi = gq[s];
                 // src/raster_pullback.jl:51-60 (a dropped neighbour adds nothing: gi == 0)
                 const T dweight = voxel_weight<T, 2>(dlo, s, gi);
                 dow_part += dweight * pwi;

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define DPR_VERSION 100 /* 0.1.0 */
+#define DPR_VERSION 103 /* 0.1.3: + dpr_resolve_flags_ex, batch KEEP / REUSE, 1 <= n_out <= n_in <= 3 */
 
 /* status codes */
 #define DPR_OK 0
