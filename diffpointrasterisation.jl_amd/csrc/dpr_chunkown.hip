@@ -53,10 +53,10 @@ constexpr int kCOPPT = DPR_CO_PPT;               // points per thread
 constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
 constexpr int kCOWaves = kCOThreads / kWave;
 #ifndef DPR_CO_CAP
-#define DPR_CO_CAP 10112
+#define DPR_CO_CAP 9984
 #endif
-constexpr int kCOCap = DPR_CO_CAP;               // LDS tile cells (8 bytes each): 79 KiB, 2 blocks / CU
-                                                 // (9216 -> 10112: fewer wide pairs, C4 forward -2 %)
+constexpr int kCOCap = DPR_CO_CAP;               // LDS tile cells (8 bytes each): 78 KiB, 2 blocks / CU
+                                                 // (round 2: 9216; fewer wide pairs, C4 forward -2 %)
 constexpr int kCOWideCap = 2 * kCOCap;            // tile of k_co_splat_wide (one workgroup per CU)
 constexpr int kCOMaxSlice = 64;                  // poses per block (per-pose sums live in LDS)
 static_assert(kCOChunk / kWave == kCOWaves * kCOPPT, "spread assignment covers the chunk");
@@ -188,7 +188,7 @@ __device__ __forceinline__ int64_t co_footprint(const T (&c)[NI], const T (&h)[N
     return cells;
 }
 
-#ifdef DPR_CO_FOOT_TABLE
+#ifndef DPR_CO_NO_FOOT_TABLE
 // Footprints of the block's poses, computed ONCE per pose by one thread each and parked in LDS
 // (every thread recomputing them cost ~50 VALU per pose: a tenth of the pose loop's instructions).
 // Ends with a barrier.  foot[j] = {lo0, lo1, hi0, hi1} of pose b_lo + j.
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     // pixels, and float atomics of many workgroups into the same rows at the same time run an
     // order of magnitude slower than spread ones.
     const int rot0 = nbs > 0 ? (int)(blockIdx.x % (unsigned)nbs) : 0;
-#ifdef DPR_CO_FOOT_TABLE
+#ifndef DPR_CO_NO_FOOT_TABLE
     __shared__ int foot[kCOMaxSlice][4];
     co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, nbs);
 #endif
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
         const int64_t b = b_lo + (jb + rot0) % nbs;
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
-#ifdef DPR_CO_FOOT_TABLE
+#ifndef DPR_CO_NO_FOOT_TABLE
         const int64_t cells = co_read_footprint(foot, (int)(b - b_lo), lo, hi);
 #else
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
                 wide_items[atomicAdd(wide_count, 1u)] = make_uint2(blockIdx.x, (unsigned)b);
             continue;
         }
+
         // the footprint is clipped to the grid, so a neighbour inside it is in the grid: two
         // unsigned compares per neighbour; whatever falls outside the bound takes the cold path
         const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
@@ -500,14 +501,14 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     }
     const int64_t b_lo = (int64_t)blockIdx.y * poses_per_slice;
     const int64_t b_hi = (b_lo + poses_per_slice < B) ? b_lo + poses_per_slice : B;
-#ifdef DPR_CO_FOOT_TABLE
+#ifndef DPR_CO_NO_FOOT_TABLE
     __shared__ int foot[kCOMaxSlice][4];
     co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, any ? (int)(b_hi - b_lo) : 0);
 #endif
     for (int64_t b = b_lo; any && b < b_hi; ++b) {
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
-#ifdef DPR_CO_FOOT_TABLE
+#ifndef DPR_CO_NO_FOOT_TABLE
         const int64_t cells = co_read_footprint(foot, (int)(b - b_lo), lo, hi);
 #else
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);

@@ -8,7 +8,7 @@ for a, b in [("bench_default.json", "r03_bench_default.json"), ("bench_under_roc
     shutil.copy(f"{O}/{a}", f"profiles/{b}")
 
 def kernel_stats(sub, title, dst):
-    ks_path = glob.glob(f"{O}/{sub}/*/*_kernel_stats.csv")[0]
+    ks_path = max(glob.glob(f"{O}/{sub}/*/*_kernel_stats.csv"), key=os.path.getmtime)  # the latest run
     shutil.copy(ks_path, f"profiles/{dst}.csv")
     ks = list(csv.DictReader(open(ks_path)))
     lines = [title, ""]
@@ -27,7 +27,7 @@ kernel_stats("stats_c5", "rocprofv3 --kernel-trace --stats -- python bench.py --
              "(C5 at the share of one GPU of 8: 50M points -> 512^3 fp64, 8 poses, tiled algorithm, the pullback reuses the binning of every pose)", "r03_c5_kernel_stats")
 
 def pmc(pattern, name):
-    rows = list(csv.DictReader(open(glob.glob(pattern)[0])))
+    rows = list(csv.DictReader(open(max(glob.glob(pattern), key=os.path.getmtime))))
     agg = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == name:
