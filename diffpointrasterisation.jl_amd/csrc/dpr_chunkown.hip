@@ -49,6 +49,10 @@ constexpr int kCOThreads = 1024;
 #define DPR_CO_PPT 4
 #endif
 constexpr int kCOWideBlocks = 512;                // grid of k_co_splat_wide (walks a work list)
+#ifndef DPR_CO_WIDE_GROUP
+#define DPR_CO_WIDE_GROUP 8
+#endif
+constexpr int kCOWideGroup = DPR_CO_WIDE_GROUP;   // poses per work item of k_co_splat_wide
 constexpr int kCOPPT = DPR_CO_PPT;               // points per thread
 constexpr int kCOChunk = kCOThreads * kCOPPT;    // 4096 points per block
 constexpr int kCOWaves = kCOThreads / kWave;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     GridDesc<2> gd, int64_t P, int64_t B, int poses_per_slice, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans,
     const T* __restrict__ ow, T* __restrict__ out, uint32_t* __restrict__ wide_count,
-    uint2* __restrict__ wide_items) {
+    uint4* __restrict__ wide_items) {
     __shared__ double acc[kCOCap];
     __shared__ T sbox[kCOWaves][6];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -277,6 +281,8 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     __shared__ int foot[kCOMaxSlice][4];
     co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, nbs);
 #endif
+    unsigned long long wide_mask = 0;  // poses of this slice whose footprint outgrows the tile
+    static_assert(kCOMaxSlice <= 64, "one bit per pose of a slice");
     for (int jb = 0; jb < nbs; ++jb) {
         const int64_t b = b_lo + (jb + rot0) % nbs;
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
@@ -288,8 +294,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
 #endif
         if (cells == 0) continue;  // uniform
         if (cells > kCOCap) {  // uniform: left to k_co_splat_wide
-            if (threadIdx.x == 0)
-                wide_items[atomicAdd(wide_count, 1u)] = make_uint2(blockIdx.x, (unsigned)b);
+            wide_mask |= 1ull << (unsigned)(b - b_lo);
             continue;
         }
 
@@ -358,6 +363,18 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
         }
         lds_barrier();  // LDS only: the flush's atomics stay in flight
     }
+    // Work items of k_co_splat_wide: (chunk, first pose, mask of up to kCOWideGroup poses).  One
+    // item per GROUP of poses rather than per pose: the wide kernel loads the chunk (and reduces
+    // its bounding box) once per item, and a sparse chunk is wide for nearly every pose; groups
+    // of 8 still spread the few sparse chunks over the whole chip (64 poses: 8 items per chunk).
+    if (threadIdx.x == 0 && wide_mask) {
+        for (int g0 = 0; g0 < nbs; g0 += kCOWideGroup) {
+            const unsigned m = (unsigned)((wide_mask >> g0) & ((1ull << kCOWideGroup) - 1ull));
+            if (m)
+                wide_items[atomicAdd(wide_count, 1u)] =
+                    make_uint4(blockIdx.x, (unsigned)(b_lo + g0), m, (unsigned)((b_lo + g0) >> 32));
+        }
+    }
 }
 
 template <typename T, int NI, bool HAS_PW>
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
     GridDesc<2> gd, int64_t P, const T* __restrict__ points, const T* __restrict__ pw,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
     T* __restrict__ out, const uint32_t* __restrict__ wide_count,
-    const uint2* __restrict__ wide_items) {
+    const uint4* __restrict__ wide_items) {
     // one workgroup per CU here (the register budget of the general path): twice the tile
     __shared__ double acc[kCOWideCap];
     __shared__ T sbox[kCOWaves][6];
@@ -373,16 +390,18 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
     const uint32_t n_items = *wide_count;  // 0 in the usual case
     if (blockIdx.x >= n_items) return;
     for (int i = threadIdx.x; i < kCOWideCap; i += kCOThreads) acc[i] = 0.0;
-    // one (chunk, pose) pair at a time, so that a few sparse chunks with every pose wide still
-    // spread over the whole chip
+    // one (chunk, group of poses) item at a time, so that a few sparse chunks with every pose wide
+    // still spread over the whole chip
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const uint2 item = wide_items[it];
+        const uint4 item = wide_items[it];
         __syncthreads();  // sbox of the previous item has been read
         T pt[kCOPPT][NI], w[kCOPPT], c[NI], h[NI];
         bool live[kCOPPT];
         co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P, (int64_t)item.x * kCOChunk, pt, w,
                              live, c, h, sbox);
-        const int64_t b = item.y;
+        const int64_t b_first = (int64_t)item.y | ((int64_t)item.w << 32);
+        for (unsigned pm = item.z; pm; pm &= pm - 1) {  // the wide poses of the group (uniform)
+        const int64_t b = b_first + (__ffs((int)pm) - 1);
         const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
         int lo[2], hi[2];
         const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
@@ -444,6 +463,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
             }
             lds_barrier();  // LDS only: the flush's atomics stay in flight
         }
+        }  // poses of the item
     }
 }
 
@@ -816,10 +836,10 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
     gd.G = G;
     const T* pts = points;
     const T* pws = pw;
-    // list of the (chunk, pose) pairs left to k_co_splat_wide: a counter + at most nblk * B
-    // entries, in the (forward-unused) region of the pullback's partial sums
+    // list of the (chunk, group of <= 8 poses) items left to k_co_splat_wide: a counter + at most
+    // nblk * B entries of 16 bytes, in the (forward-unused) region of the pullback's partial sums
     uint32_t* wide_count = (uint32_t*)(ws + pl.off_part);
-    uint2* wide_items = (uint2*)(ws + pl.off_part + 16);
+    uint4* wide_items = (uint4*)(ws + pl.off_part + 16);
     if (sort && P > 0) {
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
