@@ -9,16 +9,19 @@ extension (/root/reference/ext/DiffPointRasterisationChainRulesCoreExt.jl:6-27 s
 Like the rrule, the primal is `raster` and the pullback closure is `raster_pullback!` on the
 same arguments; the tangents come back in the rrule's order (points, rotation, translation and
 then the optional arguments that were passed).  Where the reference recomputes everything in
-the closure (src/raster_pullback.jl:20-22), a single-pose call on the tiled path keeps the
-forward's binning in a private workspace and the first backward pass reuses it
-(DPR_FLAG_KEEP_BINNING / DPR_FLAG_REUSE_BINNING); the binning is consumed by that pass, any
-further backward pass through the same node re-bins.
+the closure (src/raster_pullback.jl:20-22), a call whose raster + pullback pair shares on the
+device -- one pose on the tiled path, a batch on the chunk-owner path, a batch on the tiled path
+where DPR_ALGO_AUTO keeps every pose's binning -- keeps the forward's binning (or sorted cloud)
+in a private workspace and the first backward pass reuses it (DPR_FLAG_KEEP_BINNING /
+DPR_FLAG_REUSE_BINNING); it is consumed by that pass, any further backward pass through the same
+node re-bins.
 """
 from __future__ import annotations
 
 import torch
 
-from .interface import empty_grid, raster_, raster_pullback_, resolve_algo, workspace_bytes
+from .interface import (empty_grid, raster_, raster_pullback_, resolve_algo, sharing_effective,
+                        workspace_bytes)
 
 
 class _RasterFn(torch.autograd.Function):
@@ -36,12 +39,21 @@ class _RasterFn(torch.autograd.Function):
         out = empty_grid(grid_size, batch, dtype, points.device)
         ws = None
         P, n_in = points.shape
-        if single and P > 0:
-            f = algo if algo != "auto" else resolve_algo("raster", grid_size, P, 1, n_in)
-            b = algo if algo != "auto" else resolve_algo("pullback", grid_size, P, 1, n_in)
-            if f == b and f in ("tiled", "chunked"):
-                need = max(workspace_bytes("raster", grid_size, P, 1, n_in, dtype, f),
-                           workspace_bytes("pullback", grid_size, P, 1, n_in, dtype, f))
+        B = 1 if single else int(batch)
+        if P > 0 and B > 0:
+            # one algorithm for the raster + pullback pair (dpr_resolve_algo_ex with a sharing
+            # flag); share where the library does: one pose, a batch on the chunk-owner path (the
+            # sorted copy of the cloud), a batch on the tiled path where AUTO keeps every pose's
+            # binning (large grids, bounded record volume: dpr_resolve_flags_ex)
+            f = algo if algo != "auto" else resolve_algo("raster", grid_size, P, B, n_in, sharing=True)
+            b = algo if algo != "auto" else resolve_algo("pullback", grid_size, P, B, n_in, sharing=True)
+            shares = f == b and (
+                (B == 1 and f in ("tiled", "chunked"))
+                or (f == "chunked" and len(grid_size) == 2)
+                or (f == "tiled" and algo == "auto" and sharing_effective(grid_size, P, B, n_in)))
+            if shares:
+                need = max(workspace_bytes("raster", grid_size, P, B, n_in, dtype, f, sharing=True),
+                           workspace_bytes("pullback", grid_size, P, B, n_in, dtype, f, sharing=True))
                 ws = torch.empty(max(need, 16), dtype=torch.uint8, device=points.device)
                 algo = f
         raster_(out, points, rotation, translation, background, out_weight, point_weight,

@@ -262,8 +262,9 @@ def raster_(out, points, rotation, translation, background=None, out_weight=None
             coherent_points: bool = False) -> torch.Tensor:
     """In-place forward, the reference's `raster!`.  `out` is fully overwritten and
     returned (same object).  Enqueued on torch's current stream; not synchronised.
-    `keep_binning=True` (tiled algorithm, one pose, explicit `workspace`) leaves the binning
-    in `workspace` for `raster_pullback_(..., reuse_binning=True)` with the same arguments."""
+    `keep_binning=True` (explicit `workspace`, sized with `sharing=True`) leaves the binning of
+    every pose (tiled algorithm) or the sorted copy of the cloud (chunk-owner algorithm) in
+    `workspace` for `raster_pullback_(..., reuse_binning=True)` with the same arguments."""
     import numpy as np
 
     c = _canonicalise(points, rotation, translation, background, out_weight, point_weight)

@@ -622,6 +622,41 @@ def test_autograd_rule_matches_the_explicit_pullback(oracle, dev):
     assert abs(float(lval) - float(ref_loss[0])) <= 5e-5 * float(ref_loss[0])
 
 
+@pytest.mark.parametrize("n_points,n_out,grid,batch", [
+    (150_000, 2, (96, 96), 12),        # AUTO -> the chunk-owner pair: the sorted cloud is shared
+    (650_000, 3, (336, 336, 336), 4),  # AUTO -> tiled pair on a grid too large for pose groups:
+                                       # every pose keeps its binning
+])
+def test_autograd_rule_on_batches_that_share(oracle, dev, n_points, n_out, grid, batch):
+    """`raster_ad` on a BATCH: where the library shares between a raster call and its pullback
+    (dpr_resolve_flags_ex) the rule keeps a workspace between forward and backward; gradients
+    against the oracle, and a second backward pass (binning consumed) gives the same."""
+    npdt = np.float32
+    d = D.make(n_points=n_points, n_in=3, n_out=n_out, batch=batch, grid_n=grid, seed=71, dtype=npdt)
+    assert dpr_amd.sharing_effective(d.grid, n_points, batch, 3)
+    pts = T(d.points, dev).requires_grad_(True)
+    R = T(d.rotations, dev).requires_grad_(True)
+    t = T(d.translations, dev).requires_grad_(True)
+    ow = T(d.weights, dev).requires_grad_(True)
+    g = grid_to_dev(d.ds_dout, dev)
+    out = dpr_amd.raster_ad(d.grid, pts, R, t, None, ow)
+    loss = (out * g).sum()
+    loss.backward(retain_graph=True)
+    g1 = [x.grad.clone() for x in (pts, R, t, ow)]
+    for x in (pts, R, t, ow):
+        x.grad = None
+    loss.backward()
+    g2 = [x.grad.clone() for x in (pts, R, t, ow)]
+    ref = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights, None,
+                                 dtype=npdt)
+    for ga, gb in zip(g1, g2):
+        assert_close(ga, gb.cpu().numpy(), 1e-4, "first vs second backward pass")
+    assert_close(g1[0], ref.points, 1e-4, "points")
+    assert_close(g1[1], ref.rotation, 1e-3, "rotation")
+    assert_close(g1[2], ref.translation, 1e-3, "translation")
+    assert_close(g1[3], ref.out_weight, 1e-3, "out_weight")
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
