@@ -28,6 +28,8 @@ for step in "$@"; do
     rehearse2)  DPR_BENCH_BACKEND=gloo run rehearse2 600 python bench.py --gpus 2 --poses 8 --steps 2 --warmup 1 ;;
     rehearse2_c3) DPR_BENCH_BACKEND=gloo run rehearse2_c3 600 python bench.py --gpus 2 --config C3 --shard points --steps 2 --warmup 1 ;;
     torchrun2)  DPR_BENCH_BACKEND=gloo run torchrun2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --poses 8 --steps 2 --warmup 1 ;;
+    fuzz_big)   run fuzz_big 900 python tools/fuzz_big.py 60 ;;
+    fuzz_share) run fuzz_share 900 python tools/fuzz_share.py 60 ;;
     fuzz_co)    run fuzz_co 900 python tools/fuzz_chunkown.py 600 ;;
     fuzz_more)  run fuzz_more 900 python tools/fuzz_more.py ;;
     regret)     run regret 1000 python tools/auto_regret.py ;;
