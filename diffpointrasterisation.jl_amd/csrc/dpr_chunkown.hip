@@ -114,6 +114,9 @@ __device__ __forceinline__ bool co_load_chunk(const T* __restrict__ points,
         live[k] = p < P;
         const int64_t pl = live[k] ? p : P - 1;
         load_point<T, NI>(points, pl, pt[k]);
+        // a slot past the end of the cloud holds a NaN point: ref_and_deltas rejects it for every
+        // pose, so the kernels need no per-point `live` flag in their pose loops
+        if (!live[k]) pt[k][0] = T(__builtin_nanf(""));
         w[k] = pw ? pw[pl] : T(1);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
         for (int k = 0; k < kCOPPT; ++k) {
             int ref0[2];
             T dlo[2];
-            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo);  // (NaN beyond the cloud)
             const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
             const int lx0 = ref0[0] - lo[0], ly0 = ref0[1] - lo[1];
 #ifndef DPR_CO_SPLAT_PER_NEIGHBOUR
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
         for (int k = 0; k < kCOPPT; ++k) {
             int ref0[2];
             T dlo[2];
-            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo);  // (NaN beyond the cloud)
             const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
             lx0[k] = ref0[0] - lo[0];
             ly0[k] = ok ? ref0[1] - lo[1] : (1 << 29);  // no point: outside every band, and the grid
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
         for (int k = 0; k < kCOPPT; ++k) {
             int ref0[2];
             T dlo[2];
-            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo) && live[k];
+            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo);  // (NaN beyond the cloud)
             if (!ok) continue;  // no in-range neighbour (or non-finite): empty gradient
             const T pwi = HAS_PW ? w[k] : T(1);
             T dcoord[2] = {T(0), T(0)}, dow_part = T(0), dpw_part = T(0);
