@@ -18,6 +18,8 @@ for step in "$@"; do
     tests)      run tests 900 python -m pytest tests -m gpu -x -q ;;
     tests_all)  run tests 900 python -m pytest tests -m gpu -q ;;
     tests_k)    run tests_k 600 python -m pytest tests -m gpu -q -k "$K" ;;
+    tests_kv)   DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$VARIANT.so run tests_kv 600 python -m pytest tests -m gpu -q -k "$K" ;;
+    fuzz_share_v) DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$VARIANT.so run fuzz_share_v 900 python tools/fuzz_share.py 60 ;;
     bench_c3)   run bench_c3 300 python bench.py --steps 20 --warmup 5 --cpu-budget 5 ;;
     bench_c3_*) v=${step#bench_c3_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c3_$v 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference ;;
     bench_c4_*) v=${step#bench_c4_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c4_$v 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline ;;
