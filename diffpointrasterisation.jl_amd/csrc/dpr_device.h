@@ -126,17 +126,28 @@ __device__ __forceinline__ void point_backward(const int (&ref0)[NO], const T (&
     for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
     dow_part = T(0);
     dpw_part = T(0);
+    // All 2^N gathers are requested before the first is used: with the fetch inside the
+    // "neighbour is in the grid" branch every gather waited for the one before it (2^N dependent
+    // round trips per point and pose).  A dropped neighbour fetches cell 0 and adds nothing
+    // (selects, not multiplications by zero: weights may be non-finite).
+    int off[1 << NO];
+    T gq[1 << NO];
 #pragma unroll
     for (int s = 0; s < (1 << NO); ++s) {
-        const int off = nbr_offset<NO>(ref0, s, gd);
-        if (off < 0) continue;
-        const T gi = fetch(off);
+        off[s] = nbr_offset<NO>(ref0, s, gd);
+        gq[s] = fetch(off[s] < 0 ? 0 : off[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < (1 << NO); ++s) {
+        const bool in = off[s] >= 0;
+        const T gi = gq[s];
         const T dweight = voxel_weight<T, NO>(dlo, s, gi);
-        dow_part += dweight * pw;
-        dpw_part += dweight * ow;
+        dow_part += in ? dweight * pw : T(0);
+        dpw_part += in ? dweight * ow : T(0);
         const T factor = gi * ow * pw;
 #pragma unroll
-        for (int n = 0; n < NO; ++n) dcoord[n] += factor * interp_weight<T, NO>(n, dlo, s);
+        for (int n = 0; n < NO; ++n)
+            dcoord[n] += in ? factor * interp_weight<T, NO>(n, dlo, s) : T(0);
     }
 #pragma unroll
     for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));
@@ -152,12 +163,6 @@ template <typename T> struct Residual {
     T scale;
     T* loss;          // B values or nullptr
 };
-
-template <typename T>
-__device__ __forceinline__ T sens(const Residual<T>& rs, const T* __restrict__ g, int64_t i) {
-    const T x = g[i];
-    return rs.target ? rs.scale * (x - rs.target[i]) : x;
-}
 
 // wave-level sum (all 64 lanes must call)
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {

@@ -155,9 +155,15 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gather(
         if (live && ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo)) {
             const int64_t gb = b * gd.G;
             T scaled[NO], dow_part, dpw_part;
-            point_backward<T, NI, NO>(ref0, dlo, gd, ps.ow, pwi,
-                                      [&](int off) { return sens<T>(rs, g, gb + off); }, scaled,
-                                      dow_part, dpw_part);
+            if (rs.target)  // (uniform; decided once, not per gather)
+                point_backward<T, NI, NO>(
+                    ref0, dlo, gd, ps.ow, pwi,
+                    [&](int off) { return rs.scale * (g[gb + off] - rs.target[gb + off]); }, scaled,
+                    dow_part, dpw_part);
+            else
+                point_backward<T, NI, NO>(ref0, dlo, gd, ps.ow, pwi,
+                                          [&](int off) { return g[gb + off]; }, scaled, dow_part,
+                                          dpw_part);
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
 #pragma unroll

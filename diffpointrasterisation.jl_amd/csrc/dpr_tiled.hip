@@ -345,6 +345,22 @@ struct alignas(16) WorkItem {
     uint32_t part_nparts;  // part | nparts << 16
 };
 
+// Wait HERE for every outstanding global load / store of the wave (s_waitcnt vmcnt(0) through the
+// builtin, which the compiler's own wait insertion sees; an inline-asm wait it does not).  Used
+// in front of loops that start with a prefetched element: left pending into the loop, that
+// prefetch is joined with the back edge as "outstanding behind an unknown number of accesses", and
+// the compiler opens EVERY iteration with s_waitcnt vmcnt(0) -- a wait for the stores the
+// previous iteration has just issued (k_scatter, the fp64 k_tile_gather: see
+// profiles/r03_experiments.md).
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// ... after the prefetched values have been "used" by an empty asm, which keeps the prefetch in
+// front of the wait (the builtin alone does not order a load that nothing depends on yet)
+template <typename V> __device__ __forceinline__ void pin_value(V& x) { asm volatile("" : "+v"(x)); }
+template <typename R> __device__ __forceinline__ void pin_record(R& r) {
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(r.v) / sizeof(r.v[0])); ++k) pin_value(r.v[k]);
+}
+
 // ---- LOCAL BINNING (DPR_FLAG_COHERENT_POINTS) ------------------------------------------------
 // For a spatially coherent cloud the per-pose permutation can stay LOCAL: a block orders one
 // sub-chunk of S consecutive points by tile in LDS and writes it out as ONE contiguous run of
@@ -658,6 +674,11 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
         load_point<T, NI>(points, pl, nxt);
         if (HAS_PW) nxt_w = pw[pl];
     }
+    // the first point: waited for here, not at the top of every iteration
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pin_value(nxt[j]);
+    if (HAS_PW) pin_value(nxt_w);
+    drain_vmem();
     while (p < hi) {
         T pt[NI];
 #pragma unroll
@@ -1799,6 +1820,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
     T vals[NVAL - 2];
 #pragma unroll
     for (int k = 0; k < NVAL - 2; ++k) vals[k] = T(0);
+    // the first record was requested before the staging: it has arrived
+    pin_record(nxt);
+    if (HAS_PW && !UNPERM) pin_value(nxt_idx);
+    drain_vmem();
     while (r < r1) {
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
@@ -2072,6 +2097,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
     {
         uint32_t r1r = r1;
         for (;;) {
+            // the round's first record: waited for before the loop
+            pin_record(nxt);
+            if (HAS_PW && !UNPERM) pin_value(nxt_idx);
+            drain_vmem();
             while (r < r1r) {
                 const Rec4<T> rc = nxt;
                 const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
