@@ -753,29 +753,42 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     const int bin0 = threadIdx.x * bpt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lo >= hi) return;
-    T nxt_pt[PPT][NI], nxt_w[PPT];
+    // Single pose: the next sub-chunk's points are requested while the current one goes through
+    // its LDS phases.  Pose groups load at the top of the round instead: the second register set
+    // pushed that kernel over 128 VGPRs (it spilled the prefetched points straight to scratch,
+    // i.e. waited for them at once), and a group pays the latency once per nb poses anyway.
+#ifndef DPR_GROUP_PREFETCH
+#define DPR_GROUP_PREFETCH 0
+#endif
+    constexpr bool kPrefetch = !GROUP || DPR_GROUP_PREFETCH;
+    T nxt_pt[kPrefetch ? PPT : 1][NI], nxt_w[kPrefetch ? PPT : 1];
+    if constexpr (kPrefetch) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t p = lo + threadIdx.x + (int64_t)k * kBinThreads;
-        const int64_t pl = p < hi ? p : hi - 1;
-        load_point<T, NI>(points, pl, nxt_pt[k]);
-        nxt_w[k] = HAS_PW ? pw[pl] : T(1);
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = lo + threadIdx.x + (int64_t)k * kBinThreads;
+            const int64_t pl = p < hi ? p : hi - 1;
+            load_point<T, NI>(points, pl, nxt_pt[k]);
+            nxt_w[k] = HAS_PW ? pw[pl] : T(1);
+        }
     }
     for (int64_t base = lo; base < hi; base += S) {
         T pt[PPT][NI], w[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
+            if constexpr (kPrefetch) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) pt[k][j] = nxt_pt[k][j];
-            w[k] = nxt_w[k];
-        }
-        // the next sub-chunk's points are requested now and arrive during the LDS phases
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base + S + threadIdx.x + (int64_t)k * kBinThreads;
-            const int64_t pl = p < hi ? p : hi - 1;
-            load_point<T, NI>(points, pl, nxt_pt[k]);
-            nxt_w[k] = HAS_PW ? pw[pl] : T(1);
+                for (int j = 0; j < NI; ++j) pt[k][j] = nxt_pt[k][j];
+                w[k] = nxt_w[k];
+                const int64_t p = base + S + threadIdx.x + (int64_t)k * kBinThreads;
+                const int64_t pl = p < hi ? p : hi - 1;
+                load_point<T, NI>(points, pl, nxt_pt[k]);
+                nxt_w[k] = HAS_PW ? pw[pl] : T(1);
+            } else {
+                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                const int64_t pl = p < hi ? p : hi - 1;
+                load_point<T, NI>(points, pl, pt[k]);
+                w[k] = HAS_PW ? pw[pl] : T(1);
+            }
         }
         for (int jp = 0; jp < (GROUP ? nb : 1); ++jp) {
             const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
