@@ -196,8 +196,10 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     // pullback over many (>= 32) poses of a coherent cloud on a grid without pose groups: the direct
     // kernel (point in registers across the poses, cache-friendly gathers on sorted input) is
     // never more than ~6 % behind the tiled pipeline there and up to 1.9x ahead (clustered cloud,
-    // 1e6 points x 64 poses -> 256^3: 3.0 vs 5.6 ms)
-    if (op == DPR_OP_PULLBACK && coherent && B >= 32 && n_out == 3 && tiled_tiles(n_out, grid) > 1024)
+    // 1e6 points x 64 poses -> 256^3: 2.9 vs 5.4 ms); from 8 poses on while the cloud is small
+    // enough for the tiled path's per-pose fixed cost to show (1e6 x 16 -> 256^3: 1.1 vs 1.3 ms)
+    if (op == DPR_OP_PULLBACK && coherent && n_out == 3 && tiled_tiles(n_out, grid) > 1024 &&
+        (B >= 32 || (B >= 8 && P <= 1500000)))
         return DPR_ALGO_ATOMIC;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
