@@ -1589,11 +1589,100 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     T* o = out + b * gd.G;
+    if constexpr (NO == 3 && TileDims<NO>::T[0] == kWave) {
+        if (!any_split) {
+            // Common case, 3-D, ROW form.  The flat form below spends ~2000 VALU instructions per
+            // thread on index arithmetic (face coordinates by div / mod, seven neighbour
+            // combinations each with its own tile and halo index) for 7 voxels: the kernel was
+            // bound by that, not by its 40 MB of traffic (20 us at C3).  Here
+            //   (A) a wave takes a row (l1, l2) with l1 == 0 or l2 == 0 -- TY + TZ - 1 rows -- its
+            //       lanes are l0 = 1..63: everything but "+ lane" is wave-uniform, and only the
+            //       y / z / yz neighbours can contribute;
+            //   (B) the 128 voxels with l0 == 0 (the only ones the x neighbours reach) take the
+            //       general seven-combination form, one voxel per thread.
+            // Every voxel still has exactly one writer; all loads are issued before the first
+            // store; the sums run in the same order (m = 1..7) as in the flat form.
+            constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1], TZ = TileDims<NO>::T[2];
+            constexpr int NROW = TY + TZ - 1, NW = 256 / kWave, RIT = (NROW + NW - 1) / NW;
+            constexpr int YF = (TY + 1) * (TZ + 1), ZF = YF + TX * (TZ + 1);  // face bases (halo_index)
+            static_assert(TY * TZ <= 256, "one thread per l0 == 0 voxel");
+            const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+            const bool x_ok = x0[0] + lane < gd.n[0] && lane >= 1;
+            const int s1 = tg.nt[0], s2 = tg.nt[0] * tg.nt[1];
+            const T* hy_t = halo + (size_t)(ptile - s1) * halo_count<NO>() + YF + lane;       // y neighbour
+            const T* hz_t = halo + (size_t)(ptile - s2) * halo_count<NO>() + ZF + lane;       // z neighbour
+            const T* hyz_t = halo + (size_t)(ptile - s1 - s2) * halo_count<NO>() + YF + TX * TZ + lane;
+            T cur[RIT], vy[RIT], vz[RIT], vyz[RIT];
+            bool act[RIT], by[RIT], bz[RIT];
+            int offs[RIT];
+#pragma unroll
+            for (int k = 0; k < RIT; ++k) {
+                const int row = __builtin_amdgcn_readfirstlane(wave + k * NW);
+                const bool live = row < NROW;
+                const int l1 = row < TY ? row : 0, l2 = row < TY ? 0 : row - (TY - 1);
+                const int g1 = x0[1] + l1, g2 = x0[2] + l2;
+                by[k] = live && l1 == 0 && tc[1] > 0;
+                bz[k] = live && l2 == 0 && tc[2] > 0;
+                act[k] = live && x_ok && g1 < gd.n[1] && g2 < gd.n[2] && (by[k] || bz[k]);
+                offs[k] = act[k] ? (g2 * gd.n[1] + g1) * gd.n[0] + x0[0] + lane : 0;
+                cur[k] = o[offs[k]];
+                // (selects on the ADDRESS: an invalid combination reads halo[0] and is dropped)
+                vy[k] = *((act[k] && by[k]) ? hy_t + TX * l2 : halo);
+                vz[k] = *((act[k] && bz[k]) ? hz_t + TX * l1 : halo);
+                vyz[k] = *((act[k] && by[k] && bz[k]) ? hyz_t : halo);
+            }
+            // (B)
+            const int j = threadIdx.x < TY * TZ ? threadIdx.x : 0;
+            int lB[NO] = {0, j % TY, j / TY};
+            int offB = 0, strideB = 1;
+            bool okB = threadIdx.x < TY * TZ, lowB = false;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int gcoord = x0[d] + lB[d];
+                okB = okB && gcoord < gd.n[d];
+                lowB = lowB || (lB[d] == 0 && tc[d] > 0);
+                offB += gcoord * strideB;
+                strideB *= gd.n[d];
+            }
+            const bool actB = okB && lowB;
+            offB = actB ? offB : 0;
+            const T curB = o[offB];
+            double addB = 0.0;
+#pragma unroll
+            for (int m = 1; m < (1 << NO); ++m) {
+                bool valid = actB;
+                int h[NO];
+                int src = 0, tstride = 1;
+#pragma unroll
+                for (int d = 0; d < NO; ++d) {
+                    const bool in_m = (m >> d) & 1;
+                    valid = valid && (!in_m || (lB[d] == 0 && tc[d] > 0));
+                    h[d] = in_m ? TileDims<NO>::T[d] : lB[d];
+                    src += (tc[d] - (in_m ? 1 : 0)) * tstride;
+                    tstride *= tg.nt[d];
+                }
+                const size_t hi = valid ? (size_t)(src + pbase) * halo_count<NO>() + halo_index<NO>(h)
+                                        : (size_t)0;
+                const T hv = halo[hi];
+                addB += valid ? (double)hv : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < RIT; ++k) {
+                double add = 0.0;  // m = 2 (y), 4 (z), 6 (yz)
+                add += (act[k] && by[k]) ? (double)vy[k] : 0.0;
+                add += (act[k] && bz[k]) ? (double)vz[k] : 0.0;
+                add += (act[k] && by[k] && bz[k]) ? (double)vyz[k] : 0.0;
+                if (act[k]) o[offs[k]] = (T)((double)cur[k] + add);
+            }
+            if (actB) o[offB] = (T)((double)curB + addB);
+            return;
+        }
+    }
     if (!any_split) {
-        // Common case (no split tile anywhere): the thread's voxels are handled with every load
-        // issued before the first store -- branch-free, invalid neighbour combinations read
-        // halo[0] and are multiplied away -- so the ~IT dependent round trips of the general
-        // loop below collapse into one.
+        // Common case (no split tile anywhere), flat form (2-D grids): the thread's voxels are
+        // handled with every load issued before the first store -- branch-free, invalid neighbour
+        // combinations read halo[0] and are multiplied away -- so the ~IT dependent round trips of
+        // the general loop below collapse into one.
         constexpr int IT = (low_face_count<NO>() + 255) / 256;
         T cur[IT];
         double add[IT];

@@ -23,6 +23,7 @@ for step in "$@"; do
     bench_c3)   run bench_c3 300 python bench.py --steps 20 --warmup 5 --cpu-budget 5 ;;
     bench_c3_*) v=${step#bench_c3_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c3_$v 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference ;;
     bench_c4_*) v=${step#bench_c4_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c4_$v 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_c2)   run bench_c2 300 python bench.py --config C2 --steps 30 --warmup 3 --no-cpu-baseline ;;
     bench_c4)   run bench_c4 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_c5)   run bench_c5 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_c5_64) run bench_c5_64 900 python bench.py --config C5 --poses 64 --steps 2 --warmup 1 --no-cpu-baseline ;;
