@@ -76,7 +76,9 @@ constexpr int kBinThreads = 1024;    // K1 / K3 block
 constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
 constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
 constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
-constexpr int kSplitBlocks = 8;      // k_halo_gather blocks per split tile
+constexpr int kSplitChunks = 32;     // k_halo_gather work items per split tile (256 voxels a step)
+constexpr int kSplitGrid = 2048;     // ... and the blocks that walk them (idle blocks cost nothing
+                                     // measurable: a grid limited to the live items changed no kernel time)
 
 template <int NO> struct TileGeom {
     int nt[NO];  // tiles per axis
@@ -1549,39 +1551,22 @@ template <int NO> __device__ __forceinline__ void low_face_coords(int i, int (&l
 // Split tiles (tile_parts > 1): their parts left whole LDS tiles in overflow slabs; the block
 // then walks ALL owned voxels (out = background + sum of parts) and neighbours read a split
 // tile's halo as the sum over its slabs.
+// One (pose, tile) = `ptile`: the low faces of an unsplit tile (split == false), or chunk `c` of
+// kSplitChunks of ALL owned voxels of a split tile.
 template <typename T, int NO>
-__global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<NO> tg,
-                                                     const T* __restrict__ halo,
-                                                     const T* __restrict__ ovf,
-                                                     const uint32_t* __restrict__ tile_parts,
-                                                     const uint32_t* __restrict__ tile_slab,
-                                                     const uint32_t* __restrict__ split_list,
-                                                     const uint32_t* __restrict__ n_split,
-                                                     const T* __restrict__ bg, int64_t b0,
-                                                     int nb, T* __restrict__ out) {
+__device__ __forceinline__ void halo_gather_tile(const GridDesc<NO>& gd, const TileGeom<NO>& tg,
+                                                 const T* __restrict__ halo,
+                                                 const T* __restrict__ ovf,
+                                                 const uint32_t* __restrict__ tile_parts,
+                                                 const uint32_t* __restrict__ tile_slab,
+                                                 const T* __restrict__ bg, int64_t b0,
+                                                 T* __restrict__ out, bool any_split, int ptile,
+                                                 bool split, int c) {
     constexpr int NV = tile_voxels<NO>();
     constexpr int NVH = tile_voxels_halo<NO>();
-    constexpr int CH = kSplitBlocks;  // blocks sharing the owned voxels of one split tile
-    // blocks [0, NT*nb): the low faces of an unsplit (pose, tile); blocks NT*nb + s*CH + c: every
-    // CH-th 256-voxel chunk of the s-th split tile (all of its owned voxels)
-    const int NTe = tg.NT * nb;
-    int ptile, i_begin, i_end;
-    bool split;
-    const bool any_split = *n_split != 0;  // uniform; the common case has no split tile
-    if ((int)blockIdx.x < NTe) {
-        ptile = blockIdx.x;
-        split = false;
-        if (any_split && tile_parts[ptile] > 1) return;  // handled by its chunk blocks
-        i_begin = 0;
-        i_end = low_face_count<NO>();
-    } else {
-        const int sidx = ((int)blockIdx.x - NTe) / CH, c = ((int)blockIdx.x - NTe) % CH;
-        if (!any_split || sidx >= (int)*n_split) return;
-        ptile = (int)split_list[sidx];
-        split = true;
-        i_begin = c * 256;
-        i_end = NV;
-    }
+    constexpr int CH = kSplitChunks;
+    const int i_begin = split ? c * 256 : 0;
+    const int i_end = split ? NV : low_face_count<NO>();
     const int tile = ptile % tg.NT;
     const int pbase = ptile - tile;  // first bin of this pose
     const int64_t b = b0 + ptile / tg.NT;
@@ -1589,29 +1574,58 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
     T* o = out + b * gd.G;
+    // The 2^N - 1 lower neighbours (combination m: bit d = one tile down along axis d): which exist,
+    // which are split tiles and where their slabs start is block-uniform and fetched ONCE, up
+    // front -- looked up per voxel and combination it was a chain of dependent loads.
+    constexpr int NC = 1 << NO;
+    uint32_t nparts[NC], nslab[NC];
+    bool nvalid[NC], any_nbr_split = false;
+    int nsrc[NC];
+#pragma unroll
+    for (int m = 1; m < NC; ++m) {
+        bool v = true;
+        int src = ptile, tstride = 1;
+#pragma unroll
+        for (int d = 0; d < NO; ++d) {
+            if ((m >> d) & 1) {
+                v = v && tc[d] > 0;
+                src -= tstride;
+            }
+            tstride *= tg.nt[d];
+        }
+        nvalid[m] = v;
+        nsrc[m] = v ? src : ptile;
+        nparts[m] = any_split ? tile_parts[nsrc[m]] : 1u;
+        nslab[m] = any_split ? tile_slab[nsrc[m]] : 0u;
+        any_nbr_split = any_nbr_split || (v && nparts[m] > 1);
+    }
     if constexpr (NO == 3 && TileDims<NO>::T[0] == kWave) {
-        if (!any_split) {
-            // Common case, 3-D, ROW form.  The flat form below spends ~2000 VALU instructions per
-            // thread on index arithmetic (face coordinates by div / mod, seven neighbour
+        if (!split) {
+            // An unsplit 3-D tile, ROW form.  The flat form below spends ~2000 VALU instructions
+            // per thread on index arithmetic (face coordinates by div / mod, seven neighbour
             // combinations each with its own tile and halo index) for 7 voxels: the kernel was
-            // bound by that, not by its 40 MB of traffic (20 us at C3).  Here
+            // bound by that, not by its 40 MB of traffic (20 us at C3), and with a split tile
+            // anywhere every block walked ~100 dependent loads (22 us for the 256 tiles of C2).  Here
             //   (A) a wave takes a row (l1, l2) with l1 == 0 or l2 == 0 -- TY + TZ - 1 rows -- its
             //       lanes are l0 = 1..63: everything but "+ lane" is wave-uniform, and only the
             //       y / z / yz neighbours can contribute;
             //   (B) the 128 voxels with l0 == 0 (the only ones the x neighbours reach) take the
             //       general seven-combination form, one voxel per thread.
-            // Every voxel still has exactly one writer; all loads are issued before the first
-            // store; the sums run in the same order (m = 1..7) as in the flat form.
+            // Every voxel still has exactly one writer and all loads are issued before the first
+            // store.  Which of the seven lower neighbours are split tiles is block-uniform and
+            // fetched once; their contribution (a sum over the parts' slabs) is added in a second,
+            // rare pass.
             constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1], TZ = TileDims<NO>::T[2];
             constexpr int NROW = TY + TZ - 1, NW = 256 / kWave, RIT = (NROW + NW - 1) / NW;
             constexpr int YF = (TY + 1) * (TZ + 1), ZF = YF + TX * (TZ + 1);  // face bases (halo_index)
             static_assert(TY * TZ <= 256, "one thread per l0 == 0 voxel");
             const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
             const bool x_ok = x0[0] + lane < gd.n[0] && lane >= 1;
-            const int s1 = tg.nt[0], s2 = tg.nt[0] * tg.nt[1];
-            const T* hy_t = halo + (size_t)(ptile - s1) * halo_count<NO>() + YF + lane;       // y neighbour
-            const T* hz_t = halo + (size_t)(ptile - s2) * halo_count<NO>() + ZF + lane;       // z neighbour
-            const T* hyz_t = halo + (size_t)(ptile - s1 - s2) * halo_count<NO>() + YF + TX * TZ + lane;
+            const T* hy_t = halo + (size_t)nsrc[2] * halo_count<NO>() + YF + lane;            // y neighbour
+            const T* hz_t = halo + (size_t)nsrc[4] * halo_count<NO>() + ZF + lane;            // z neighbour
+            const T* hyz_t = halo + (size_t)nsrc[6] * halo_count<NO>() + YF + TX * TZ + lane;  // yz
+            const bool uy = nvalid[2] && nparts[2] == 1, uz = nvalid[4] && nparts[4] == 1,
+                       uyz = nvalid[6] && nparts[6] == 1;  // unsplit sources: one halo value each
             T cur[RIT], vy[RIT], vz[RIT], vyz[RIT];
             bool act[RIT], by[RIT], bz[RIT];
             int offs[RIT];
@@ -1627,13 +1641,13 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
                 offs[k] = act[k] ? (g2 * gd.n[1] + g1) * gd.n[0] + x0[0] + lane : 0;
                 cur[k] = o[offs[k]];
                 // (selects on the ADDRESS: an invalid combination reads halo[0] and is dropped)
-                vy[k] = *((act[k] && by[k]) ? hy_t + TX * l2 : halo);
-                vz[k] = *((act[k] && bz[k]) ? hz_t + TX * l1 : halo);
-                vyz[k] = *((act[k] && by[k] && bz[k]) ? hyz_t : halo);
+                vy[k] = *((act[k] && by[k] && uy) ? hy_t + TX * l2 : halo);
+                vz[k] = *((act[k] && bz[k] && uz) ? hz_t + TX * l1 : halo);
+                vyz[k] = *((act[k] && by[k] && bz[k] && uyz) ? hyz_t : halo);
             }
             // (B)
             const int j = threadIdx.x < TY * TZ ? threadIdx.x : 0;
-            int lB[NO] = {0, j % TY, j / TY};
+            const int lB[NO] = {0, j % TY, j / TY};
             int offB = 0, strideB = 1;
             bool okB = threadIdx.x < TY * TZ, lowB = false;
 #pragma unroll
@@ -1647,34 +1661,75 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
             const bool actB = okB && lowB;
             offB = actB ? offB : 0;
             const T curB = o[offB];
-            double addB = 0.0;
+            T vB[8];
+            bool bB[8];
+            int cellB[8];  // index of the source cell in a (T + 1)^3 tile (for the slab pass)
 #pragma unroll
-            for (int m = 1; m < (1 << NO); ++m) {
-                bool valid = actB;
+            for (int m = 1; m < 8; ++m) {
+                bool valid = actB && nvalid[m];
                 int h[NO];
-                int src = 0, tstride = 1;
 #pragma unroll
                 for (int d = 0; d < NO; ++d) {
                     const bool in_m = (m >> d) & 1;
-                    valid = valid && (!in_m || (lB[d] == 0 && tc[d] > 0));
+                    valid = valid && (!in_m || lB[d] == 0);
                     h[d] = in_m ? TileDims<NO>::T[d] : lB[d];
-                    src += (tc[d] - (in_m ? 1 : 0)) * tstride;
-                    tstride *= tg.nt[d];
                 }
-                const size_t hi = valid ? (size_t)(src + pbase) * halo_count<NO>() + halo_index<NO>(h)
-                                        : (size_t)0;
-                const T hv = halo[hi];
-                addB += valid ? (double)hv : 0.0;
+                bB[m] = valid;
+                cellB[m] = lds_index<NO>(h);
+                const size_t hi = (valid && nparts[m] == 1)
+                                      ? (size_t)nsrc[m] * halo_count<NO>() + halo_index<NO>(h)
+                                      : (size_t)0;
+                vB[m] = halo[hi];
+            }
+            double addA[RIT][3], addB[8];
+#pragma unroll
+            for (int k = 0; k < RIT; ++k) {
+                addA[k][0] = (act[k] && by[k] && uy) ? (double)vy[k] : 0.0;
+                addA[k][1] = (act[k] && bz[k] && uz) ? (double)vz[k] : 0.0;
+                addA[k][2] = (act[k] && by[k] && bz[k] && uyz) ? (double)vyz[k] : 0.0;
+            }
+#pragma unroll
+            for (int m = 1; m < 8; ++m) addB[m] = (bB[m] && nparts[m] == 1) ? (double)vB[m] : 0.0;
+            if (any_nbr_split) {  // uniform, rare: sources that are split tiles = sums over slabs
+                auto slab_sum = [&](int m, int cell) {
+                    const T* sp = ovf + (size_t)nslab[m] * NVH + cell;
+                    double sum = 0.0;
+                    uint32_t q = 0;
+                    for (; q + 4 <= nparts[m]; q += 4) {  // four loads in flight
+                        const T a0 = sp[(size_t)q * NVH], a1 = sp[(size_t)(q + 1) * NVH],
+                                a2 = sp[(size_t)(q + 2) * NVH], a3 = sp[(size_t)(q + 3) * NVH];
+                        sum += (double)a0;
+                        sum += (double)a1;
+                        sum += (double)a2;
+                        sum += (double)a3;
+                    }
+                    for (; q < nparts[m]; ++q) sum += (double)sp[(size_t)q * NVH];
+                    return sum;
+                };
+#pragma unroll
+                for (int k = 0; k < RIT; ++k) {
+                    const int row = __builtin_amdgcn_readfirstlane(wave + k * NW);
+                    const int l1 = row < TY ? row : 0, l2 = row < TY ? 0 : row - (TY - 1);
+                    if (nvalid[2] && nparts[2] > 1 && act[k] && by[k])
+                        addA[k][0] = slab_sum(2, lane + (TX + 1) * (TY + (TY + 1) * l2));
+                    if (nvalid[4] && nparts[4] > 1 && act[k] && bz[k])
+                        addA[k][1] = slab_sum(4, lane + (TX + 1) * (l1 + (TY + 1) * TZ));
+                    if (nvalid[6] && nparts[6] > 1 && act[k] && by[k] && bz[k])
+                        addA[k][2] = slab_sum(6, lane + (TX + 1) * (TY + (TY + 1) * TZ));
+                }
+#pragma unroll
+                for (int m = 1; m < 8; ++m)
+                    if (bB[m] && nparts[m] > 1) addB[m] = slab_sum(m, cellB[m]);
             }
 #pragma unroll
             for (int k = 0; k < RIT; ++k) {
-                double add = 0.0;  // m = 2 (y), 4 (z), 6 (yz)
-                add += (act[k] && by[k]) ? (double)vy[k] : 0.0;
-                add += (act[k] && bz[k]) ? (double)vz[k] : 0.0;
-                add += (act[k] && by[k] && bz[k]) ? (double)vyz[k] : 0.0;
+                const double add = (addA[k][0] + addA[k][1]) + addA[k][2];  // m = 2, 4, 6
                 if (act[k]) o[offs[k]] = (T)((double)cur[k] + add);
             }
-            if (actB) o[offB] = (T)((double)curB + addB);
+            double sumB = 0.0;
+#pragma unroll
+            for (int m = 1; m < 8; ++m) sumB += addB[m];
+            if (actB) o[offB] = (T)((double)curB + sumB);
             return;
         }
     }
@@ -1732,7 +1787,23 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
         return;
     }
     const uint32_t my_parts = split ? tile_parts[ptile] : 1u;
+    const uint32_t my_slab = split ? tile_slab[ptile] : 0u;
     const double bgv = bg ? (double)bg[b] : 0.0;
+    // acc + the n parts' values of one cell, in part order; four loads in flight (one at a time
+    // it was a chain of n round trips per voxel: 22 us for the 256 tiles of C2, 8 parts at the centre)
+    auto add_parts = [&](double acc, const T* sp, uint32_t n) {
+        uint32_t q = 0;
+        for (; q + 4 <= n; q += 4) {
+            const T a0 = sp[(size_t)q * NVH], a1 = sp[(size_t)(q + 1) * NVH],
+                    a2 = sp[(size_t)(q + 2) * NVH], a3 = sp[(size_t)(q + 3) * NVH];
+            acc += (double)a0;
+            acc += (double)a1;
+            acc += (double)a2;
+            acc += (double)a3;
+        }
+        for (; q < n; ++q) acc += (double)sp[(size_t)q * NVH];
+        return acc;
+    };
     for (int i = i_begin + threadIdx.x; i < i_end; i += i_step) {
         int l[NO];
         if (split) {
@@ -1760,37 +1831,58 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
         if (low) {
 #pragma unroll
             for (int m = 1; m < (1 << NO); ++m) {
-                bool valid = true;
+                bool valid = nvalid[m];
                 int h[NO];
-                int src = 0, tstride = 1;
 #pragma unroll
                 for (int d = 0; d < NO; ++d) {
                     const bool in_m = (m >> d) & 1;
-                    valid = valid && (!in_m || (l[d] == 0 && tc[d] > 0));
+                    valid = valid && (!in_m || l[d] == 0);
                     h[d] = in_m ? TileDims<NO>::T[d] : l[d];
-                    src += (tc[d] - (in_m ? 1 : 0)) * tstride;
-                    tstride *= tg.nt[d];
                 }
                 if (!valid) continue;
-                src += pbase;
-                const uint32_t sp = any_split ? tile_parts[src] : 1u;
-                if (sp > 1) {
-                    const T* slab = ovf + (size_t)tile_slab[src] * NVH + lds_index<NO>(h);
-                    for (uint32_t q = 0; q < sp; ++q) add += (double)slab[(size_t)q * NVH];
-                } else {
-                    add += (double)halo[(size_t)src * halo_count<NO>() + halo_index<NO>(h)];
-                }
+                if (nparts[m] > 1)
+                    add = add_parts(add, ovf + (size_t)nslab[m] * NVH + lds_index<NO>(h), nparts[m]);
+                else
+                    add += (double)halo[(size_t)nsrc[m] * halo_count<NO>() + halo_index<NO>(h)];
             }
         }
         if (split) {
-            const T* slab = ovf + (size_t)tile_slab[ptile] * NVH + lds_index<NO>(l);
-            double own = bgv;
-            for (uint32_t q = 0; q < my_parts; ++q) own += (double)slab[(size_t)q * NVH];
+            const double own = add_parts(bgv, ovf + (size_t)my_slab * NVH + lds_index<NO>(l), my_parts);
             o[off] = (T)(own + add);
         } else {
             o[off] = (T)((double)o[off] + add);
         }
     }
+}
+
+// blocks [0, NT*nb): one (pose, tile) each (a split tile's block returns: its voxels belong to
+// the chunk blocks); the kSplitGrid blocks behind them walk the (split tile, chunk) work items --
+// a fixed number, whatever the worst case of split tiles (a grid sized for that case was ~20 000
+// blocks at C3 that did nothing but read n_split and exit).
+template <typename T, int NO>
+__global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<NO> tg,
+                                                     const T* __restrict__ halo,
+                                                     const T* __restrict__ ovf,
+                                                     const uint32_t* __restrict__ tile_parts,
+                                                     const uint32_t* __restrict__ tile_slab,
+                                                     const uint32_t* __restrict__ split_list,
+                                                     const uint32_t* __restrict__ n_split,
+                                                     const T* __restrict__ bg, int64_t b0,
+                                                     int nb, T* __restrict__ out) {
+    const int NTe = tg.NT * nb;
+    const uint32_t ns = *n_split;
+    const bool any_split = ns != 0;  // uniform; the common case has no split tile
+    if ((int)blockIdx.x < NTe) {
+        const int ptile = blockIdx.x;
+        if (any_split && tile_parts[ptile] > 1) return;  // handled by the chunk blocks
+        halo_gather_tile<T, NO>(gd, tg, halo, ovf, tile_parts, tile_slab, bg, b0, out, any_split,
+                                ptile, false, 0);
+        return;
+    }
+    const int n_items = (int)ns * kSplitChunks;
+    for (int w = (int)blockIdx.x - NTe; w < n_items; w += (int)gridDim.x - NTe)
+        halo_gather_tile<T, NO>(gd, tg, halo, ovf, tile_parts, tile_slab, bg, b0, out, true,
+                                (int)split_list[w / kSplitChunks], true, w % kSplitChunks);
 }
 
 // ------------------------------------------------------------------ pullback K4
@@ -3147,7 +3239,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
 #undef DPR_LAUNCH_SPLAT_RUNS
         stage_mark(st);
         hipLaunchKernelGGL((k_halo_gather<T, NO>),
-                           dim3(tg.NT * (int)nb + (pl.max_slabs / 2) * kSplitBlocks),
+                           dim3(tg.NT * (int)nb + kSplitGrid),
                            dim3(256), 0, st, gd, tg, (const T*)halo, (const T*)ovf,
                            (const uint32_t*)(wsb + pl.off_tparts),
                            (const uint32_t*)(wsb + pl.off_tslab),
