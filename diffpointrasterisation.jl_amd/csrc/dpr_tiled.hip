@@ -536,13 +536,23 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
     // (Round 3 tried one LDS atomic per (wave, bucket) by ballot instead of one per tile -- nearly
     // all tiles share two or three buckets: the serial ballot / shuffle / returning-atomic round
     // trips cost more than the same-address atomics they replace, scan stage 18.5 -> 22.2 us.)
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = totals[i];
-        s += c;
-        const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
-        const uint32_t sz = (c + k - 1) / k;  // records per part
-        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
-        if (k > 1) slabs += k;
+    // (the thread's totals are fetched four at a time in both passes: one per iteration was a
+    // chain of 2 x per round trips -- 46 us per pose for the 16 384 tiles of C5)
+    const int iend = (i0 + per < NT) ? i0 + per : NT;
+    for (int ib = i0; ib < iend; ib += 4) {
+        uint32_t cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cc[u] = (ib + u < iend) ? totals[ib + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ib + u >= iend) continue;
+            const uint32_t c = cc[u];
+            s += c;
+            const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
+            const uint32_t sz = (c + k - 1) / k;  // records per part
+            atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
+            if (k > 1) slabs += k;
+        }
     }
     uint32_t incl = s, incl_slab = slabs;
 #pragma unroll
@@ -573,28 +583,36 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
     }
     __syncthreads();
     uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = totals[i];
-        tile_start[i] = run;
-        const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
-        const uint32_t sz = (c + k - 1) / k;
-        const int bucket = sz ? 32 - __clz(sz) : 0;
-        tile_parts[i] = k;
-        tile_slab[i] = slab_run;
-        for (uint32_t part = 0; part < k; ++part) {
-            WorkItem it;
-            it.tile = (uint32_t)i;
-            it.begin = run + part * sz;
-            it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
-            if (it.begin > run + c) it.begin = run + c;
-            it.part_nparts = part | (k << 16);
-            items[atomicAdd(&bstart[bucket], 1u)] = it;
+    for (int ib = i0; ib < iend; ib += 4) {
+        uint32_t cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cc[u] = (ib + u < iend) ? totals[ib + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = ib + u;
+            if (i >= iend) continue;
+            const uint32_t c = cc[u];
+            tile_start[i] = run;
+            const uint32_t k = c > cap ? (c + cap - 1) / cap : 1u;
+            const uint32_t sz = (c + k - 1) / k;
+            const int bucket = sz ? 32 - __clz(sz) : 0;
+            tile_parts[i] = k;
+            tile_slab[i] = slab_run;
+            for (uint32_t part = 0; part < k; ++part) {
+                WorkItem it;
+                it.tile = (uint32_t)i;
+                it.begin = run + part * sz;
+                it.end = (it.begin + sz < run + c) ? it.begin + sz : run + c;
+                if (it.begin > run + c) it.begin = run + c;
+                it.part_nparts = part | (k << 16);
+                items[atomicAdd(&bstart[bucket], 1u)] = it;
+            }
+            if (k > 1) {
+                slab_run += k;
+                split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
+            }
+            run += c;
         }
-        if (k > 1) {
-            slab_run += k;
-            split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
-        }
-        run += c;
     }
     if (threadIdx.x == 1023) tile_start[NT] = wbase + incl;
     __syncthreads();
@@ -613,31 +631,50 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
 constexpr int kScanTiles = DPR_SCAN_TILES, kScanGroups = 1024 / DPR_SCAN_TILES;
 __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
                                                   uint32_t* __restrict__ totals) {
+    // A thread owns `rows` consecutive rows of one column.  Its loads are issued kRowBatch at a
+    // time (one row per iteration was a chain of 2 x rows dependent round trips: 9.2 us for the
+    // 512 x 2048 table of C3, 16 rows per thread); when the rows fit one batch -- up to 512 count
+    // blocks -- the values stay in registers between the two passes.
+    constexpr int kRowBatch = 16;
     __shared__ uint32_t part[kScanGroups][kScanTiles];
     const int j = threadIdx.x % kScanTiles, g = threadIdx.x / kScanTiles;
     const int tile = blockIdx.x * kScanTiles + j;
     const int rows = (nblk + kScanGroups - 1) / kScanGroups;
     const int r0 = g * rows, r1 = (r0 + rows < nblk) ? r0 + rows : nblk;
+    const bool one = rows <= kRowBatch;  // uniform
+    const bool live = tile < NT;
+    uint32_t v[kRowBatch];
     uint32_t s = 0;
-    if (tile < NT)
-        for (int r = r0; r < r1; ++r) s += counts[(size_t)r * NT + tile];
+    for (int rb = r0; rb < r1; rb += kRowBatch) {
+#pragma unroll
+        for (int k = 0; k < kRowBatch; ++k)
+            v[k] = (live && rb + k < r1) ? counts[(size_t)(rb + k) * NT + tile] : 0u;
+#pragma unroll
+        for (int k = 0; k < kRowBatch; ++k) s += v[k];
+    }
     part[g][j] = s;
     __syncthreads();
     uint32_t base = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < kScanGroups; ++k) {
-        const uint32_t v = part[k][j];
-        if (k < g) base += v;
-        total += v;
+        const uint32_t pv = part[k][j];
+        if (k < g) base += pv;
+        total += pv;
     }
-    if (tile < NT) {
-        for (int r = r0; r < r1; ++r) {
-            const uint32_t c = counts[(size_t)r * NT + tile];
-            counts[(size_t)r * NT + tile] = base;
-            base += c;
+    if (!live) return;
+    for (int rb = r0; rb < r1; rb += kRowBatch) {
+        if (!one) {
+#pragma unroll
+            for (int k = 0; k < kRowBatch; ++k)
+                v[k] = (rb + k < r1) ? counts[(size_t)(rb + k) * NT + tile] : 0u;
         }
-        if (g == 0) totals[tile] = total;
+#pragma unroll
+        for (int k = 0; k < kRowBatch; ++k) {
+            if (rb + k < r1) counts[(size_t)(rb + k) * NT + tile] = base;
+            base += v[k];
+        }
     }
+    if (g == 0) totals[tile] = total;
 }
 
 __global__ __launch_bounds__(1024) void k_tilescan(TileScanArgs ts) {
@@ -1079,13 +1116,24 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
         return k ? k : 1u;
     };
     uint32_t s = 0, slabs = 0;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
-        s += nd;
-        const uint32_t k = parts_of(c, nd);
-        const uint32_t sz = (c + k - 1) / k;  // records per part (estimate)
-        atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
-        if (k > 1) slabs += k;
+    const int iend = (i0 + per < NT) ? i0 + per : NT;
+    for (int ib = i0; ib < iend; ib += 4) {  // four tiles' totals in flight (see tilescan_body)
+        uint32_t cc[4], dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cc[u] = (ib + u < iend) ? tile_npts[ib + u] : 0u;
+            dd[u] = (ib + u < iend) ? tile_ndesc[ib + u] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ib + u >= iend) continue;
+            const uint32_t c = cc[u], nd = dd[u];
+            s += nd;
+            const uint32_t k = parts_of(c, nd);
+            const uint32_t sz = (c + k - 1) / k;  // records per part (estimate)
+            atomicAdd(&bcount[sz ? 32 - __clz(sz) : 0], k);
+            if (k > 1) slabs += k;
+        }
     }
     uint32_t incl = s, incl_slab = slabs;
 #pragma unroll
@@ -1117,31 +1165,42 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
     }
     __syncthreads();
     uint32_t run = wbase + incl - s, slab_run = sbase + incl_slab - slabs;
-    for (int i = i0; i < i0 + per && i < NT; ++i) {
-        const uint32_t c = tile_npts[i], nd = tile_ndesc[i];
-        tile_dstart[i] = run;
-        tile_cursor[i] = 0;
-        const uint32_t k = parts_of(c, nd);
-        const uint32_t sz = (c + k - 1) / k;
-        const uint32_t dsz = (nd + k - 1) / k;  // descriptors per part
-        const int bucket = sz ? 32 - __clz(sz) : 0;
-        tile_parts[i] = k;
-        tile_slab[i] = slab_run;
-        for (uint32_t part = 0; part < k; ++part) {
-            WorkItem it;
-            it.tile = (uint32_t)i;
-            it.begin = run + part * dsz;
-            it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
-            if (it.begin > run + nd) it.begin = run + nd;
-            it.part_nparts = part | (k << 16);
-            const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
-            if (pos < (uint32_t)max_items) items[pos] = it;
+    for (int ib = i0; ib < iend; ib += 4) {
+        uint32_t cc[4], dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cc[u] = (ib + u < iend) ? tile_npts[ib + u] : 0u;
+            dd[u] = (ib + u < iend) ? tile_ndesc[ib + u] : 0u;
         }
-        if (k > 1) {
-            slab_run += k;
-            split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = ib + u;
+            if (i >= iend) continue;
+            const uint32_t c = cc[u], nd = dd[u];
+            tile_dstart[i] = run;
+            tile_cursor[i] = 0;
+            const uint32_t k = parts_of(c, nd);
+            const uint32_t sz = (c + k - 1) / k;
+            const uint32_t dsz = (nd + k - 1) / k;  // descriptors per part
+            const int bucket = sz ? 32 - __clz(sz) : 0;
+            tile_parts[i] = k;
+            tile_slab[i] = slab_run;
+            for (uint32_t part = 0; part < k; ++part) {
+                WorkItem it;
+                it.tile = (uint32_t)i;
+                it.begin = run + part * dsz;
+                it.end = (it.begin + dsz < run + nd) ? it.begin + dsz : run + nd;
+                if (it.begin > run + nd) it.begin = run + nd;
+                it.part_nparts = part | (k << 16);
+                const uint32_t pos = atomicAdd(&bstart[bucket], 1u);
+                if (pos < (uint32_t)max_items) items[pos] = it;
+            }
+            if (k > 1) {
+                slab_run += k;
+                split_list[atomicAdd(&s_nsplit, 1u)] = (uint32_t)i;
+            }
+            run += nd;
         }
-        run += nd;
     }
     if (threadIdx.x == 1023) tile_dstart[NT] = wbase + incl;
     __syncthreads();
