@@ -67,6 +67,13 @@ template <> struct TileDims<2> {
 };
 constexpr int kMaxTiles = 32768;     // LDS cursor table: 4 B per tile, <= 128 KiB
 constexpr int kBinThreads = 1024;    // K1 / K3 block
+#ifndef DPR_WC_THREADS
+#define DPR_WC_THREADS 1024
+#endif
+#ifndef DPR_WC_PPT
+#define DPR_WC_PPT 4
+#endif
+constexpr int kWcThreads = DPR_WC_THREADS;  // block of the write-combining scatter
 #ifndef DPR_SPLAT_THREADS
 #define DPR_SPLAT_THREADS 1024
 #endif
@@ -759,14 +766,14 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
 // ones, profiles/r01_experiments.md).
 //   LDS: cursor[NT * nb] (dynamic) | lhist[NT] (dynamic) | recs[S] | dest[S]
 template <typename T, int NI, int NO, bool HAS_PW, int S, bool GROUP, bool W3>
-__global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
+__global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, int64_t chunk, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
     int nb, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
     RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
     T* __restrict__ ds_dpw, int zero_dropped) {
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
-    constexpr int PPT = S / kBinThreads;  // points per thread per sub-chunk
+    constexpr int PPT = S / kWcThreads;  // points per thread per sub-chunk
     // Pose group (nb > 1): the S points of a sub-chunk stay in registers while the poses of the
     // group are binned one after the other, each into its own NT bins -- the runs that are
     // written out stay as long as in the single-pose case, the points are read once per group.
@@ -778,17 +785,17 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     uint32_t* lhist = dyn + NTe;   // [NT]
     __shared__ RecT<T, W3> recs[S];
     __shared__ uint32_t dest[S];
-    __shared__ uint32_t wsum[kBinThreads / kWave];
+    __shared__ uint32_t wsum[kWcThreads / kWave];
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
     const uint32_t* row = prefix + (size_t)slice * NTe;
-    for (int i = threadIdx.x; i < NTe; i += kBinThreads) cursor[i] = tile_start[i] + row[i];
-    for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
+    for (int i = threadIdx.x; i < NTe; i += kWcThreads) cursor[i] = tile_start[i] + row[i];
+    for (int i = threadIdx.x; i < NT; i += kWcThreads) lhist[i] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
     // bins owned by this thread in the scan / cursor update (NT <= 4096: at most 4)
-    constexpr int kMaxBpt = 4096 / kBinThreads;
-    const int bpt = (NT + kBinThreads - 1) / kBinThreads;
+    constexpr int kMaxBpt = 4096 / kWcThreads;
+    const int bpt = (NT + kWcThreads - 1) / kWcThreads;
     const int bin0 = threadIdx.x * bpt;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lo >= hi) return;
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
     if constexpr (kPrefetch) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int64_t p = lo + threadIdx.x + (int64_t)k * kBinThreads;
+            const int64_t p = lo + threadIdx.x + (int64_t)k * kWcThreads;
             const int64_t pl = p < hi ? p : hi - 1;
             load_point<T, NI>(points, pl, nxt_pt[k]);
             nxt_w[k] = HAS_PW ? pw[pl] : T(1);
@@ -818,12 +825,12 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
 #pragma unroll
                 for (int j = 0; j < NI; ++j) pt[k][j] = nxt_pt[k][j];
                 w[k] = nxt_w[k];
-                const int64_t p = base + S + threadIdx.x + (int64_t)k * kBinThreads;
+                const int64_t p = base + S + threadIdx.x + (int64_t)k * kWcThreads;
                 const int64_t pl = p < hi ? p : hi - 1;
                 load_point<T, NI>(points, pl, nxt_pt[k]);
                 nxt_w[k] = HAS_PW ? pw[pl] : T(1);
             } else {
-                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
                 const int64_t pl = p < hi ? p : hi - 1;
                 load_point<T, NI>(points, pl, pt[k]);
                 w[k] = HAS_PW ? pw[pl] : T(1);
@@ -838,7 +845,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             uint32_t lrank[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
                 int ref0[NO];
                 T dlo[NO];
                 const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
             uint32_t n_valid = 0;
 #pragma unroll
-            for (int wv = 0; wv < kBinThreads / kWave; ++wv) n_valid += wsum[wv];
+            for (int wv = 0; wv < kWcThreads / kWave; ++wv) n_valid += wsum[wv];
 #pragma unroll
             for (int q = 0; q < kMaxBpt; ++q) {
                 const int i = bin0 + q;
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             // c. place into LDS in tile order; remember the global destination
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+                const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
                 if (tile[k] >= 0) {
                     const uint32_t sidx = lhist[tile[k]] + lrank[k];
                     const uint32_t d = cur[tile[k]] + lrank[k];
@@ -901,7 +908,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter_wc(
             }
             lds_barrier();
             // d. write-out in LDS (= tile) order; e. advance cursors, clear the histogram
-            for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[dest[i]] = recs[i];
+            for (uint32_t i = threadIdx.x; i < n_valid; i += kWcThreads) rec[dest[i]] = recs[i];
             // advance the cursors by the owned bins' counts (kept in registers since the scan)
             // and clear the histogram; the next round's atomics start after the barrier
 #pragma unroll
@@ -3054,11 +3061,11 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
     // write-combining variant: needs 2 NT counters + the sub-chunk in LDS, and does not
     // produce rec_idx (only the direct-store pullback mode with point weights reads that)
     if (scatter_is_wc(tg.NT, nb, HAS_PW, WANT_IDX)) {
-        constexpr int S = (sizeof(T) == 4) ? 4096 : 2048;
+        constexpr int S = (sizeof(T) == 4) ? DPR_WC_PPT * kWcThreads : DPR_WC_PPT * kWcThreads / 2;
         const size_t lds2 = (size_t)tg.NT * (nb + 1) * 4;
 #define DPR_LAUNCH_WC(GROUP, W3)                                                                  \
     hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S, GROUP, W3>), dim3(pl.nblk),           \
-                       dim3(kBinThreads), lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, \
+                       dim3(kWcThreads), lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, \
                        b, nb, (const uint32_t*)(ws + pl.off_counts),                             \
                        (const uint32_t*)(ws + pl.off_tile_start),                                \
                        (RecT<T, W3>*)(ws + pl.off_rec),                     \
