@@ -785,7 +785,10 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
     uint32_t* lhist = dyn + NTe;   // [NT]
     __shared__ RecT<T, W3> recs[S];
     __shared__ uint32_t dest[S];
-    __shared__ uint32_t wsum[kWcThreads / kWave];
+    // the scan's per-wave sums live in dest[]: they are dead before phase c writes it (two barriers
+    // in between), and dest[] is dead after the write-out of the previous round (barrier)
+    uint32_t* const wsum = dest;
+    static_assert(S >= kWcThreads / kWave, "wave sums fit");
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
     const uint32_t* row = prefix + (size_t)slice * NTe;
     for (int i = threadIdx.x; i < NTe; i += kWcThreads) cursor[i] = tile_start[i] + row[i];
@@ -806,7 +809,10 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
 #ifndef DPR_GROUP_PREFETCH
 #define DPR_GROUP_PREFETCH 0
 #endif
-    constexpr bool kPrefetch = !GROUP || DPR_GROUP_PREFETCH;
+#ifndef DPR_WC_PREFETCH
+#define DPR_WC_PREFETCH 1
+#endif
+    constexpr bool kPrefetch = DPR_WC_PREFETCH && (!GROUP || DPR_GROUP_PREFETCH);
     T nxt_pt[kPrefetch ? PPT : 1][NI], nxt_w[kPrefetch ? PPT : 1];
     if constexpr (kPrefetch) {
 #pragma unroll
