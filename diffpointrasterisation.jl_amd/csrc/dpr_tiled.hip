@@ -82,6 +82,8 @@ constexpr int kWcThreads = DPR_WC_THREADS;  // block of the write-combining scat
 #endif
 constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
 constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
+// (the pullback tile kernels run 4 workgroups = 16 waves per CU: their 40 KB ds_dout tile sets
+// that, not the ~100 VGPRs)
 constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
 constexpr int kSplitChunks = 32;     // k_halo_gather work items per split tile (256 voxels a step)
 constexpr int kSplitGrid = 2048;     // ... and the blocks that walk them (idle blocks cost nothing
