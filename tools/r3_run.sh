@@ -38,6 +38,7 @@ for step in "$@"; do
     fuzz_share) run fuzz_share 900 python tools/fuzz_share.py 60 ;;
     fuzz_co)    run fuzz_co 900 python tools/fuzz_chunkown.py 600 ;;
     fuzz_more)  run fuzz_more 900 python tools/fuzz_more.py ;;
+    timecall_cap*) v=${step#timecall_cap}; DPR_CAP_MIN=$v run timecall_cap$v 600 python tools/time_call.py $SPECS ;;
     timecall)   run timecall 600 python tools/time_call.py $SPECS ;;
     timecall_v) DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$VARIANT.so run timecall_v 600 python tools/time_call.py $SPECS ;;
     regret)     run regret 1000 python tools/auto_regret.py ;;

@@ -1,5 +1,6 @@
-"""Times single calls: python tools/time_call.py "P,grid,B,op,algo[,dtype[,order]]" ...
-grid like 128x128x128; op fwd|bwd; algo auto|atomic|tiled|chunked; dtype f32|f64; order random|sorted.
+"""Times single calls: python tools/time_call.py "P,grid,B,op,algo[,dtype[,order[,cloud]]]" ...
+grid like 128x128x128; op fwd|bwd; algo auto|atomic|tiled|chunked; dtype f32|f64; order random|sorted;
+cloud gauss (0.4 sigma) | tight (0.1 sigma) | uniform.
 Prints one line per spec (median of 9 after a warm-up, hipEvents on the current stream).  A/B against
 another build with DPR_LIB_OVERRIDE=<libdpr variant>."""
 import os, sys
@@ -26,7 +27,11 @@ for spec in sys.argv[1:]:
     npdt = np.float64 if dt == torch.float64 else np.float32
     rng = np.random.default_rng(0)
     n_out = len(grid)
-    pts = (0.4 * rng.standard_normal(size=(P, 3))).astype(npdt)
+    cloud = f[7] if len(f) > 7 else "gauss"
+    if cloud == "uniform":
+        pts = rng.uniform(-0.55, 0.55, size=(P, 3)).astype(npdt)
+    else:
+        pts = ((0.1 if cloud == "tight" else 0.4) * rng.standard_normal(size=(P, 3))).astype(npdt)
     tp = torch.as_tensor(pts, device=dev)
     if order == "sorted":
         tp = dpr_amd.sort_points(tp)[0]
