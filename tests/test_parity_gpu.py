@@ -412,13 +412,16 @@ def test_chunked_on_spatially_sorted_points(oracle, dev, npdt, tdt, n_in, n_out,
 
 
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
-@pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 70), (3, 2, 90), (2, 2, 64)])
+@pytest.mark.parametrize("n_in,n_out,grid_n", [(3, 3, 70), (3, 2, 90), (2, 2, 64), (3, 3, (130, 70, 70))])
 def test_heavy_tiles_are_split(oracle, dev, npdt, tdt, n_in, n_out, grid_n):
     """A tightly clustered cloud puts far more than the split threshold (4096 records) into a
     handful of tiles: the tile kernels then run several work items per tile and the parts are
     combined from overflow slabs.  Forward, pullback and the binning-reuse
-    pairing against the oracle."""
-    d = D.make(n_points=40_000, n_in=n_in, n_out=n_out, batch=2, grid_n=grid_n, seed=27, dtype=npdt)
+    pairing against the oracle.  On the 130 x 70 x 70 grid the cluster sits on a tile corner in all
+    three axes (voxel 65 | 35 | 35 against tile edges at 64 | 32 | 32): split tiles whose x, y, z
+    and diagonal neighbours are split tiles too, two poses in one pose group."""
+    n_points = 150_000 if isinstance(grid_n, tuple) else 40_000
+    d = D.make(n_points=n_points, n_in=n_in, n_out=n_out, batch=2, grid_n=grid_n, seed=27, dtype=npdt)
     d.points = (d.points * npdt(0.12)).astype(npdt)  # ~ +-0.15: a few tiles hold everything
     d.points[::50] *= npdt(8.0)                      # plus some stragglers elsewhere
     _compare(*_run_both(oracle, dev, d, npdt, "tiled"), npdt)
