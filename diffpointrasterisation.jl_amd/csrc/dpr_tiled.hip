@@ -29,7 +29,8 @@
 //
 // Experiment knobs (environment, compiled-in defaults are the measured best):
 //   DPR_SCATTER_WC=0     plain scatter instead of the write-combining one
-//   DPR_SPLAT_BLOCKED=0  lane-adjacent (strided) instead of blocked record assignment
+//   DPR_SPLAT_BLOCKED=0|1  lane-adjacent (strided) / blocked record assignment in k_tile_splat
+//                        (default: chosen on the device from the order of the cloud)
 //   DPR_BWD_UNPERMUTE=0  owner threads store ds_dpoints directly instead of un-permuting
 //   DPR_POSE_GROUP=n     at most n poses per group (1 = per-pose pipeline)
 #include <hip/hip_runtime.h>
@@ -234,10 +235,16 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
                                                        int64_t chunk, const T* __restrict__ points,
                                                        const T* __restrict__ rot,
                                                        const T* __restrict__ trans, int64_t b0,
-                                                       int nb, uint32_t* __restrict__ counts) {
+                                                       int nb, uint32_t* __restrict__ counts,
+                                                       uint32_t* __restrict__ nonzero_bins) {
+    // nonzero_bins[slice] = bins this block's slice of the cloud touches: nearly all of them for
+    // a cloud in random order, a few per cent for a spatially sorted one.  The tile scan turns
+    // the sum into the record assignment of k_tile_splat (strided / blocked).
     extern __shared__ uint32_t hist[];
+    __shared__ uint32_t s_nz;
     const int NTe = tg.NT * nb;  // bins = (pose of the group, tile)
     for (int i = threadIdx.x; i < NTe; i += kBinThreads) hist[i] = 0;
+    if (threadIdx.x == 0) s_nz = 0;
     __syncthreads();
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
     const int64_t lo = (int64_t)slice * chunk;
@@ -294,7 +301,17 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
     }
     __syncthreads();
     uint32_t* row = counts + (size_t)slice * NTe;
-    for (int i = threadIdx.x; i < NTe; i += kBinThreads) row[i] = hist[i];
+    uint32_t nz = 0;
+    for (int i = threadIdx.x; i < NTe; i += kBinThreads) {
+        const uint32_t v = hist[i];
+        row[i] = v;
+        nz += v != 0u;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) nz += __shfl_xor(nz, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && nz) atomicAdd(&s_nz, nz);
+    __syncthreads();
+    if (threadIdx.x == 0) nonzero_bins[slice] = s_nz;
 }
 
 // ------------------------------------------------------------------ K2: scans
@@ -495,6 +512,8 @@ struct TileScanArgs {
     int rot_words;
     const uint32_t* trans;
     int trans_words;
+    const uint32_t* nonzero_bins;  // [nblk] from k_count
+    int nblk;
 };
 // one block of 1024 threads
 __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ totals, int NT,
@@ -508,7 +527,8 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
                                               BinHeader* __restrict__ hdr_out,
                                               const uint32_t* __restrict__ rot, int rot_words,
                                               const uint32_t* __restrict__ trans,
-                                              int trans_words) {
+                                              int trans_words,
+                                              const uint32_t* __restrict__ nonzero_bins, int nblk) {
     // header of this binning (state = kBinValid only for a KEEP_BINNING forward): the last wave
     // copies the pose words, one lane the fixed fields
     if (threadIdx.x >= 1024 - 64) {
@@ -534,11 +554,20 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
         }
     }
     __shared__ uint32_t wsum[16], wslab[16];
-    __shared__ uint32_t s_nsplit;
-    if (threadIdx.x == 0) s_nsplit = 0;
+    __shared__ uint32_t s_nsplit, s_nzsum;
+    if (threadIdx.x == 0) {
+        s_nsplit = 0;
+        s_nzsum = 0;
+    }
     __shared__ uint32_t bcount[33], bstart[33];
     if (threadIdx.x < 33) bcount[threadIdx.x] = 0;
     __syncthreads();
+    {   // how coherent is the cloud's order?  (bins touched per count block, summed)
+        uint32_t v = (threadIdx.x < nblk) ? nonzero_bins[threadIdx.x] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_nzsum, v);
+    }
     const int per = (NT + 1023) / 1024;
     const int i0 = threadIdx.x * per;
     uint32_t s = 0, slabs = 0;
@@ -584,6 +613,12 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
             start += bcount[k];
         }
         *n_items = start;
+        // n_items[1]: record assignment of k_tile_splat.  A cloud in random order (a count block
+        // touches more than 1/8 of the bins) takes lane-adjacent records -- coalesced loads,
+        // lanes land in unrelated voxels anyway; a spatially sorted one takes a contiguous run
+        // per thread (lane-adjacent records would hit the same voxel and same-address LDS
+        // atomics serialise).  88 vs 94 us for the random order at C3.
+        n_items[1] = ((uint64_t)s_nzsum * 8 >= (uint64_t)nblk * (uint64_t)NT) ? 0u : 1u;
     }
     uint32_t wbase = 0, sbase = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
@@ -689,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts,
 __global__ __launch_bounds__(1024) void k_tilescan(TileScanArgs ts) {
     tilescan_body(ts.totals, ts.NT, ts.cap, ts.tile_start, ts.items, ts.n_items, ts.tile_parts,
                   ts.tile_slab, ts.split_list, ts.n_split, ts.hdr, ts.hdr_out, ts.rot,
-                  ts.rot_words, ts.trans, ts.trans_words);
+                  ts.rot_words, ts.trans, ts.trans_words, ts.nonzero_bins, ts.nblk);
 }
 
 // ------------------------------------------------------------------ K3: scatter
@@ -1251,10 +1286,12 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     // the other (count -> item -> pose were three dependent round trips of 1-2 us each on a
     // busy chip).  Only a pose group's later images need a second pose fetch.
     const uint32_t n_it = *n_items;
+    const uint32_t order_flag = n_items[1];  // the tile scan's verdict on the cloud's order
     const WorkItem item = items[blockIdx.x];
     Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
     if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
+    if (blocked == 2) blocked = (int)order_flag;  // (uniform)
     // item.tile = (pose within the group) * NT + tile
     const int tile = (int)(item.tile % (uint32_t)tg.NT);
     const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
@@ -1264,6 +1301,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     // Record assignment: strided (lane-adjacent records, coalesced) or blocked (each thread
     // owns a contiguous run, so lanes are far apart in the list: with spatially sorted input
     // lane-adjacent records hit the same voxel and same-address LDS atomics serialise).
+    // blocked == 2 on entry: whichever the tile scan chose from the order of the cloud.
     uint32_t r1 = item.end;
     uint32_t r = item.begin;
     uint32_t step = kSplatThreads;
@@ -2728,7 +2766,7 @@ static const Knobs& knobs() {
         q.scatter_wc = env_int("DPR_SCATTER_WC", 1, 0, 1);
         q.bwd_unpermute = env_int("DPR_BWD_UNPERMUTE", 1, 0, 1);
         q.compact_records = env_int("DPR_COMPACT_RECORDS", 1, 0, 1);
-        q.splat_blocked = env_int("DPR_SPLAT_BLOCKED", 1, 0, 1);
+        q.splat_blocked = env_int("DPR_SPLAT_BLOCKED", 2, 0, 2);  // 2: decided on the device
         return q;
     }();
     return k;
@@ -2744,7 +2782,7 @@ struct Plan {
     uint32_t cap;    // records per work item above which a tile is split
     int max_items;   // NT + worst-case number of extra parts
     int max_slabs;   // overflow slabs (parts of split tiles)
-    size_t off_hdr, off_counts, off_totals, off_tile_start, off_items, off_nitems, off_tparts, off_tslab,
+    size_t off_hdr, off_counts, off_totals, off_tile_start, off_items, off_nitems, off_nzbins, off_tparts, off_tslab,
         off_split, off_rec, off_idx, off_slot, off_aux, total;
     // Hilbert sort of the cloud inside the call (batched poses on grids with more than 4096
     // tiles, where the plain scatter runs 2.4x faster on coherent input: 50 M points -> 512^3,
@@ -2840,8 +2878,10 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     pl.max_items = NT + pl.max_slabs;
     pl.off_items = o;
     o += align_up((size_t)pl.max_items * sizeof(WorkItem));
-    pl.off_nitems = o;
+    pl.off_nitems = o;  // [0] = items, [1] = record assignment of k_tile_splat
     o += align_up(4);
+    pl.off_nzbins = o;  // bins touched per count block (k_count -> k_tilescan)
+    o += align_up((size_t)kMaxBinBlocks * 4);
     pl.off_tparts = o;
     o += align_up((size_t)NT * 4);
     pl.off_tslab = o;
@@ -3122,11 +3162,13 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     if (nb > 1) {
         if (int rc = allow_big_lds(k_count<T, NI, NO, true>, lds)) return rc;
         hipLaunchKernelGGL((k_count<T, NI, NO, true>), dim3(pl.nblk), dim3(kBinThreads), lds, st,
-                           gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts);
+                           gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts,
+                           (uint32_t*)(ws + pl.off_nzbins));
     } else {
         if (int rc = allow_big_lds(k_count<T, NI, NO, false>, lds)) return rc;
         hipLaunchKernelGGL((k_count<T, NI, NO, false>), dim3(pl.nblk), dim3(kBinThreads), lds, st,
-                           gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts);
+                           gd, tg, P, pl.chunk, points, rot, trans, b, nb, counts,
+                           (uint32_t*)(ws + pl.off_nzbins));
     }
     stage_mark(st);
     int64_t grid64[3] = {1, 1, 1};
@@ -3150,6 +3192,8 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     ts.rot_words = (int)(NO * NI * sizeof(T) / 4);
     ts.trans = (const uint32_t*)(trans + b * NO);
     ts.trans_words = (int)(NO * sizeof(T) / 4);
+    ts.nonzero_bins = (const uint32_t*)(ws + pl.off_nzbins);
+    ts.nblk = pl.nblk;
     hipLaunchKernelGGL(k_colscan, dim3((NTe + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st,
                        counts, pl.nblk, NTe, totals);
     hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, ts);

@@ -24,6 +24,7 @@ for step in "$@"; do
     bench_c2_cap*) v=${step#bench_c2_cap}; DPR_CAP_MIN=$v run bench_c2_cap$v 300 python bench.py --config C2 --steps 30 --warmup 3 --no-cpu-baseline --no-secondary ;;
     fwdonly_*)  v=${step#fwdonly_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run fwdonly_$v 300 python tools/time_call.py 1e7,256x256x256,1,fwd,tiled 1e7,256x256x256,1,fwd,tiled 1e6,128x128x128,1,fwd,tiled 5e6,256x256x256,1,fwd,tiled ;;
     fwdonly)    run fwdonly 300 python tools/time_call.py 1e7,256x256x256,1,fwd,tiled 1e7,256x256x256,1,fwd,tiled 1e6,128x128x128,1,fwd,tiled 5e6,256x256x256,1,fwd,tiled ;;
+    bench_c3_unblocked) DPR_SPLAT_BLOCKED=0 run bench_c3_unblocked 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference ;;
     bench_c3_*) v=${step#bench_c3_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c3_$v 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-reference ;;
     bench_c4_*) v=${step#bench_c4_}; DPR_LIB_OVERRIDE=$PWD/diffpointrasterisation.jl_amd/variants_libdpr_$v.so run bench_c4_$v 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_c2)   run bench_c2 300 python bench.py --config C2 --steps 30 --warmup 3 --no-cpu-baseline ;;
