@@ -83,6 +83,9 @@ constexpr int kWcThreads = DPR_WC_THREADS;  // block of the write-combining scat
 #endif
 constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
 constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
+#ifndef DPR_GATHER_RB
+#define DPR_GATHER_RB 8  // rows of the ds_dout tile a wave requests before it stores the first
+#endif
 // (the pullback tile kernels run 4 workgroups = 16 waves per CU: their 40 KB ds_dout tile sets
 // that, not the ~100 VGPRs)
 constexpr int kMaxBinBlocks = 512;   // rows of the counts table (2 per CU)
@@ -2062,7 +2065,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
         constexpr int ROWS = NVH / (TX + 1);
         constexpr int RPW = kWave / TX;  // rows per wave pass (1 for TX = 64, 2 for TX = 32)
-        constexpr int kRB = 8;           // row passes in flight
+        constexpr int kRB = DPR_GATHER_RB;  // row passes in flight
         static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
         const bool first_part = (item.part_nparts & 0xffffu) == 0;
         const int lane = threadIdx.x & (kWave - 1);
@@ -2336,7 +2339,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
         constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
         constexpr int ROWS = NVH / (TX + 1);
         constexpr int RPW = kWave / TX;  // rows per wave pass (1 for TX = 64, 2 for TX = 32)
-        constexpr int kRB = 8;           // row passes in flight
+        constexpr int kRB = DPR_GATHER_RB;  // row passes in flight
         static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
         const bool first_part = (item.part_nparts & 0xffffu) == 0;
         const int lane = threadIdx.x & (kWave - 1);
