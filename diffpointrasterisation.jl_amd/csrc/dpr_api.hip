@@ -76,9 +76,13 @@ static PairCost other_cost(int n_out, const int64_t* grid, int64_t G, int64_t P,
     a.fwd = 0.01 + (double)B * (0.001 + 0.19 * pm);
     a.bwd = 0.05 + (double)B * (0.0003 + 0.05 * pm);
     if (!tiled_supported(n_out, grid) || P >= ((int64_t)1 << 32)) return a;
-    const double pf = 0.005 + 0.0128 * pm, pb = 0.005 + 0.0207 * pm;
-    t.fwd = 0.03 + (double)B * ((pf > 0.0115 ? pf : 0.0115) + 0.0135 * gm);
-    t.bwd = 0.03 + (double)B * ((pb > 0.0135 ? pb : 0.0135) + 0.016 * gm);
+    // (refitted at the end of round 3: one slice of the cloud per CU and whole sub-chunks made the
+    // tiled path 5-25 % faster below ~3e6 points, most of all with pose groups)
+    const double sq = std::sqrt(pm);
+    const double pf1 = 0.0063 + 0.0062 * sq, pf2 = 0.0025 + 0.0095 * pm;
+    const double pb1 = 0.0076 + 0.0095 * std::pow(pm, 0.7), pb2 = 0.0184 * pm - 0.001;
+    t.fwd = 0.05 + (double)B * ((pf1 > pf2 ? pf1 : pf2) + gm * (0.012 + 0.012 * sq));
+    t.bwd = 0.04 + (double)B * ((pb1 > pb2 ? pb1 : pb2) + gm * (0.014 + 0.0076 * pm));
     PairCost c;
     c.fwd = a.fwd < t.fwd ? a.fwd : t.fwd;
     c.bwd = a.bwd < t.bwd ? a.bwd : t.bwd;
@@ -86,7 +90,7 @@ static PairCost other_cost(int n_out, const int64_t* grid, int64_t G, int64_t P,
 }
 // op < 0: the raster + pullback pair of a KEEP_BINNING / REUSE_BINNING call pair (one sort)
 //
-// The margin is on the chunk-owner side (1.2 from 16 poses on: taken even when modelled 20 % behind): the
+// The margin is on the chunk-owner side (1.2 from 32 poses on: taken even when modelled 20 % behind): the
 // model is fitted to clouds that fill the image, where the alternatives are at their best; on a
 // clustered cloud the chunk-owner footprints shrink and it wins by 2-3x (1e7 points x 64 poses on
 // 1024^2: 3.5 vs 9.6 ms tiled), while nothing makes it lose by more than ~1.2x where the model
@@ -96,7 +100,7 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
     if (n_out != 2 || P >= ((int64_t)1 << 32) || P < 1 || B < 1) return false;
     if (B > 65535 * 64) return false;  // the chunk-owner kernels' grid.y (pose slices of <= 64)
     const PairCost c = chunkown_cost(n_in, G, P, B, coherent), o = other_cost(n_out, grid, G, P, B);
-    const double margin = B >= 16 ? 1.2 : 0.9;
+    const double margin = B >= 32 ? 1.2 : (B >= 16 ? 1.1 : 0.9);
     if (op == DPR_OP_RASTER) return c.fwd < margin * o.fwd;
     if (op == DPR_OP_PULLBACK) return c.bwd < margin * o.bwd;
     const double pm = (double)P * 1e-6;
@@ -121,7 +125,9 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
         return false;
     if (B < 4 || P < 30000 || P >= ((int64_t)1 << 32)) return false;
     if (!chunked_supported(n_out, grid)) return false;
-    return P * 10 <= G;
+    // (fewer than 16 poses: only the very sparse cloud -- on a clustered one the lists lose 2x at
+    // one point per 17-21 voxels and 4 poses, where they win 1.3x on a Gaussian or uniform cloud)
+    return P * (B >= 16 ? 10 : 25) <= G;
 }
 
 // (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both
