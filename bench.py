@@ -465,11 +465,18 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
     step()  # first call: code objects are loaded lazily
     t_one = timed(1)
     n_spin = max(0, min(2000, int(args.spin_up_ms * 1e-3 / max(t_one, 1e-6)))) if args.spin_up else 0
-    for _ in range(n_spin):
-        step()
+    t_ref = timed(n_spin) / n_spin if n_spin > 0 else None  # (the same on every rank: timed() takes the max)
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps)
+    # A stall of tens of ms (host or device, ~3 % of the runs on these boxes) inside a timed region
+    # of a few ms is not a measurement of the path: when the K steps took more than 1.5x what the
+    # spin-up steps just took per step, the K steps are timed again (at most twice) and the line
+    # says so.  Normally exactly one loop of K steps is timed.
+    retimed = 0
+    while t_ref is not None and retimed < 2 and elapsed / args.steps > 1.5 * t_ref:
+        retimed += 1
+        elapsed = min(elapsed, timed(args.steps))
     ms_per_step = elapsed / args.steps * 1e3
     units = (B_global * P) if shard != "points" else P  # (point, pose) pairs per step, whole job
     value = units / (elapsed / args.steps) / 1e6
@@ -566,6 +573,7 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
             "coherent_points_flag": bool(args.coherent),
             "exchange": exchange,
             "value_counts": "points x poses of the whole job per second (a point counts once per pose)",
+            **({"timed_loop_repeated_after_a_stall": retimed} if retimed else {}),
             "untimed_before_the_timed_steps": f"first call + 1 probe step + {n_spin} spin-up steps (~{args.spin_up_ms:.0f} ms of load so that the clocks are up) + {args.warmup} warm-up steps",
             **({"same_job_on_one_gpu": f"python bench.py --config {cfg} --gpus 1"
                                         + (f" --poses {B_global}" if args.poses else "")
