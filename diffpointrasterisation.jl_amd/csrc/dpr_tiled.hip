@@ -79,12 +79,15 @@ constexpr int kWcThreads = DPR_WC_THREADS;  // block of the write-combining scat
 #define DPR_WC_SLICES 1  // 0: the slice rule of the plain scatter for the write-combining one too
 #endif
 #ifndef DPR_SPLAT_THREADS
-#define DPR_SPLAT_THREADS 1024
+#define DPR_SPLAT_THREADS 512
 #endif
 #ifndef DPR_GATHER_THREADS
 #define DPR_GATHER_THREADS 256
 #endif
 constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
+#ifndef DPR_SPLAT_RUNS_OCC
+#define DPR_SPLAT_RUNS_OCC (DPR_SPLAT_THREADS >= 1024 ? 8 : 4)  // waves per SIMD for two blocks per CU
+#endif
 constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
 #ifndef DPR_GATHER_RB
 #define DPR_GATHER_RB 8  // rows of the ds_dout tile a wave requests before it stores the first
@@ -1454,7 +1457,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
 // ------------------------------------------------------------------ forward K4, local binning
 // (k_tile_splat with the record loop walking run descriptors; instantiated with RUNS = true)
 template <typename T, int NI, int NO, bool HAS_PW, bool W3, bool RUNS>
-__global__ __launch_bounds__(kSplatThreads, 8) void k_tile_splat_runs(  // 8 waves / SIMD = 2 blocks / CU
+__global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_splat_runs(  // (2 blocks / CU)
     GridDesc<NO> gd, TileGeom<NO> tg, const RecT<T, W3>* __restrict__ rec,
     const RunDesc* __restrict__ runs, uint32_t max_rec,
     const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
