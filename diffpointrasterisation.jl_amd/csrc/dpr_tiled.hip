@@ -89,6 +89,9 @@ constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
 #define DPR_SPLAT_RUNS_OCC (DPR_SPLAT_THREADS >= 1024 ? 8 : 4)  // waves per SIMD for two blocks per CU
 #endif
 constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
+#ifndef DPR_UPB
+#define DPR_UPB 4  // points per thread of the single-pose un-permute (a block = one scatter sub-chunk)
+#endif
 #ifndef DPR_GATHER_RB
 #define DPR_GATHER_RB 8  // rows of the ds_dout tile a wave requests before it stores the first
 #endif
@@ -3526,8 +3529,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                     else DPR_LAUNCH_UNPERM(false, 1, 0);
                 } else {
                     // one pose: the per-pose reduction rides in the same launch
-                    if (b == 0) DPR_LAUNCH_UNPERM(true, 4, n_reduce);
-                    else DPR_LAUNCH_UNPERM(false, 4, n_reduce);
+                    if (b == 0) DPR_LAUNCH_UNPERM(true, DPR_UPB, n_reduce);
+                    else DPR_LAUNCH_UNPERM(false, DPR_UPB, n_reduce);
                     reduced = true;
                 }
 #undef DPR_LAUNCH_UNPERM
