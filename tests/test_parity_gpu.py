@@ -409,6 +409,10 @@ def test_chunked_on_spatially_sorted_points(oracle, dev, npdt, tdt, n_in, n_out,
     d.points = np.ascontiguousarray(d.points[order])
     d.point_weights = np.ascontiguousarray(d.point_weights[order])
     _compare(*_run_both(oracle, dev, d, npdt, "chunked"), npdt)
+    # the tiled path on the same sorted cloud, NOT flagged coherent: k_count finds few bins per
+    # slice and the tile scan hands k_tile_splat the blocked record assignment (a cloud in random
+    # order, as in most tests here, gets the strided one)
+    _compare(*_run_both(oracle, dev, d, npdt, "tiled"), npdt)
 
 
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
