@@ -48,7 +48,10 @@ constexpr int kCOThreads = 1024;
 #ifndef DPR_CO_PPT
 #define DPR_CO_PPT 4
 #endif
-constexpr int kCOWideBlocks = 512;                // grid of k_co_splat_wide (walks a work list)
+#ifndef DPR_CO_WIDE_BLOCKS
+#define DPR_CO_WIDE_BLOCKS 1024
+#endif
+constexpr int kCOWideBlocks = DPR_CO_WIDE_BLOCKS; // grid of k_co_splat_wide (walks a work list)
 #ifndef DPR_CO_WIDE_GROUP
 #define DPR_CO_WIDE_GROUP 8
 #endif
