@@ -33,6 +33,7 @@
 //                        (default: chosen on the device from the order of the cloud)
 //   DPR_BWD_UNPERMUTE=0  owner threads store ds_dpoints directly instead of un-permuting
 //   DPR_POSE_GROUP=n     at most n poses per group (1 = per-pose pipeline)
+//   DPR_FIXED_POINT=0    f64 LDS accumulators instead of 64-bit fixed point in the fp32 forward
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -242,6 +243,69 @@ __device__ __forceinline__ unsigned xcd_slice(unsigned block, unsigned nblocks) 
 // before this barrier must not be read by other threads of the block after it.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- 64-bit fixed-point LDS accumulators for fp32 data ---------------------------------------
+// ds_add_u64 retires a wave-instruction in 13.6 cycles, ds_add_f64 in 26.3 (ds_add_f32: 193;
+// profiles/r02_microbench_lds_conflicts.txt), and integer sums are EXACT: the forward result no
+// longer depends on the order in which a tile's records are accumulated.  A contribution v (an
+// fp32 value, exactly representable in f64) becomes round(v * 2^sexp) through the magic-number
+// trick: fma(v, 2^sexp, 1.5 * 2^52) has the integer in its low mantissa bits as long as
+// |v * 2^sexp| < 2^51, so the conversion costs one v_fma_f64 and one 32-bit subtract.
+// The scale is chosen per work item from
+//   maxw >= |every contribution|  (|out_weight| * max|point_weight|; the products of the deltas
+//                                  are <= 1 in fp32 as well) and
+//   n    >= contributions to one cell (a record adds to a cell at most once: n = records of the item)
+// such that n * maxw * 2^sexp <= 2^62 (the sum cannot overflow) and maxw * 2^sexp <= 2^50.
+// An item holds at most max(4096, P / 256) < 2^24 records, so a contribution keeps at least 38
+// bits below the largest weight (fp32 carries 24); typical tiles (thousands of records) keep 49.
+// Non-finite weights (NaN / Inf out_weight or point_weight) switch the item to f64 atomics, which
+// propagate them the IEEE way.
+struct FixScale {
+    double mul;  // 2^sexp, 0 = fixed point off (f64 atomics)
+    double inv;  // 2^-sexp
+};
+constexpr double kFixMagic = 6755399441055744.0;  // 1.5 * 2^52
+__device__ __forceinline__ FixScale fix_scale(float maxw, uint32_t n, int enabled) {
+    FixScale fs;
+    fs.mul = 0.0;
+    fs.inv = 0.0;
+    if (!enabled || !(maxw < __builtin_inff())) return fs;
+    int e = 0;
+    if (maxw > 0.f) (void)frexpf(maxw, &e);  // maxw < 2^e
+    const int bits_n = 32 - __clz((int)(n | 1u));  // n < 2^bits_n
+    int sexp = 62 - bits_n;
+    sexp = (sexp > 50 ? 50 : sexp) - e;
+    fs.mul = ldexp(1.0, sexp);
+    fs.inv = ldexp(1.0, -sexp);
+    return fs;
+}
+__device__ __forceinline__ unsigned long long fix_bits(float v, const FixScale& fs) {
+    const double x = fma((double)v, fs.mul, kFixMagic);
+    return (unsigned long long)(__double_as_longlong(x) - __double_as_longlong(kFixMagic));
+}
+__device__ __forceinline__ double fix_value(double cell, const FixScale& fs) {
+    return fs.mul != 0.0 ? (double)__double_as_longlong(cell) * fs.inv : cell;
+}
+// one contribution into an f64-sized LDS cell
+template <bool FIX, typename T>
+__device__ __forceinline__ void cell_add(double* cell, T v, const FixScale& fs) {
+    if constexpr (FIX && sizeof(T) == 4) atomicAdd((unsigned long long*)cell, fix_bits((float)v, fs));
+    else atomicAdd(cell, (double)v);
+}
+// max |point_weight| of the records a binning kernel has seen, as the bit pattern of a
+// non-negative float (unsigned order = float order; NaN sorts above Inf): wave max, one global
+// atomicMax per wave.  All 64 lanes must call.
+__device__ __forceinline__ void publish_max_abs(uint32_t* __restrict__ dst, uint32_t bits) {
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const uint32_t v = __shfl_xor(bits, o, kWave);
+        bits = v > bits ? v : bits;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && bits) atomicMax(dst, bits);
+}
+template <typename T> __device__ __forceinline__ uint32_t abs_bits(T w) {
+    return __float_as_uint(fabsf((float)w));  // (fp64 data does not use the fixed-point path)
 }
 
 // ------------------------------------------------------------------ K1: count
@@ -634,6 +698,7 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
         // per thread (lane-adjacent records would hit the same voxel and same-address LDS
         // atomics serialise).  88 vs 94 us for the random order at C3.
         n_items[1] = ((uint64_t)s_nzsum * 8 >= (uint64_t)nblk * (uint64_t)NT) ? 0u : 1u;
+        n_items[2] = 0u;  // max |point_weight| bits, published by the scatter that follows
     }
     uint32_t wbase = 0, sbase = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
@@ -752,7 +817,8 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
     const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
     Rec4<T>* __restrict__ rec, uint32_t* __restrict__ rec_idx, uint32_t* __restrict__ slot_of,
-    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, int zero_dropped) {
+    T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, int zero_dropped,
+    uint32_t* __restrict__ maxpw) {
     extern __shared__ uint32_t cursor[];
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
     const uint32_t* row = prefix + (size_t)slice * tg.NT;
@@ -765,6 +831,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     // latter to the spare slot P when the point has no in-range voxel) so that the wait for
     // the prefetched point is a counted vmcnt that never covers the scattered store.
     if (lo >= hi) return;
+    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of k_tile_splat's fixed point)
     int64_t p = lo + threadIdx.x;
     T nxt[NI], nxt_w = T(1);
     {
@@ -794,6 +861,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
         const bool valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
         uint32_t pos = (uint32_t)P;  // spare slot
         if (valid) pos = atomicAdd(&cursor[primary_tile<NO>(ref0, tg)], 1u);
+        if (HAS_PW && valid) max_w = abs_bits(w) > max_w ? abs_bits(w) : max_w;
         Rec4<T> r;
 #pragma unroll
         for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[(j < NI) ? j : 0] : T(0);
@@ -808,6 +876,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
             ds_dpw[pc] = T(0);
         }
     }
+    if (HAS_PW) publish_max_abs(maxpw, max_w);
 }
 
 // ------------------------------------------------------------------ K3': write-combining scatter
@@ -823,9 +892,10 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
     int nb, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
     RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, int zero_dropped) {
+    T* __restrict__ ds_dpw, int zero_dropped, uint32_t* __restrict__ maxpw) {
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kWcThreads;  // points per thread per sub-chunk
+    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of k_tile_splat's fixed point)
     // Pose group (nb > 1): the S points of a sub-chunk stay in registers while the poses of the
     // group are binned one after the other, each into its own NT bins -- the runs that are
     // written out stay as long as in the single-pose case, the points are read once per group.
@@ -910,6 +980,7 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
                 tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
                 lrank[k] = 0;
                 if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
+                if (HAS_PW && valid) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
             }
             lds_barrier();
             // b. exclusive scan of lhist (in place)
@@ -980,6 +1051,7 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
             lds_barrier();
         }
     }
+    if (HAS_PW) publish_max_abs(maxpw, max_w);
 }
 
 // ------------------------------------------------------------------ local binning: K1
@@ -996,7 +1068,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
     RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, RunDesc* __restrict__ desc,
     uint32_t* __restrict__ n_desc, uint32_t* __restrict__ tile_ndesc,
     uint32_t* __restrict__ tile_npts, uint32_t spare_slot, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, int zero_dropped) {
+    T* __restrict__ ds_dpw, int zero_dropped, uint32_t* __restrict__ maxpw) {
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kBinThreads;
     constexpr int kMaxBpt = 4096 / kBinThreads;
@@ -1023,6 +1095,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
     // distinct tile and wave.
     int tile[PPT];
     uint32_t lrank[PPT];
+    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of the fixed-point splat)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -1032,6 +1105,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
         const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < P;
         tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
         lrank[k] = 0;
+        if (HAS_PW && valid) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
         unsigned long long todo = __ballot(valid);
         int rounds = 0;
         while (todo && rounds < 8) {  // a few distinct tiles per wave; the rest one by one
@@ -1125,6 +1199,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
     lds_barrier();
     // d. write-out: one contiguous, coalesced run
     for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[base + i] = recs[i];
+    if (HAS_PW) publish_max_abs(maxpw, max_w);
 }
 
 // local binning: K2 -- tile totals -> descriptor offsets, work list (a work item is a range of
@@ -1285,6 +1360,59 @@ __global__ __launch_bounds__(256) void k_place_desc(const RunDesc* __restrict__ 
     }
 }
 
+// One record into the LDS tile of a forward tile kernel (k_tile_splat, k_tile_splat_runs).
+template <bool FIX, typename T, int NI, int NO, bool HAS_PW, typename R>
+__device__ __forceinline__ void splat_record(const R& rc, bool active, const Pose<T, NI, NO>& ps,
+                                             const GridDesc<NO>& gd, const int (&x0)[NO],
+                                             double* __restrict__ acc, const FixScale& fs) {
+    T pt[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
+    const T w = HAS_PW ? ps.ow * rc.v[HAS_PW ? 3 : 0] : ps.ow * T(1);  // src/raster.jl:52
+    int ref0[NO];
+    T dlo[NO];
+    ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
+    // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
+    // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
+    // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
+    int lb[NO];
+    bool low_ok[NO];
+#pragma unroll
+    for (int d = 0; d < NO; ++d) {
+        lb[d] = ref0[d] - x0[d];
+        // records of this tile have lb in [-1, T-1]; the clamp only matters if the
+        // caller breaks the REUSE_BINNING contract (stale workspace): LDS indices
+        // stay legal
+        lb[d] = lb[d] < -1 ? -1 : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
+        low_ok[d] = lb[d] >= 0;
+    }
+    bool interior = true;
+#pragma unroll
+    for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+    if (active && interior) {
+        // common case: one base address, the 2^N neighbours are compile-time offsets
+        // (they fold into the ds_add offset field)
+        double* base = &acc[lds_index<NO>(lb)];
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s)
+            cell_add<FIX, T>(base + nbr_lds_offset<NO>(s), voxel_weight<T, NO>(dlo, s, w), fs);
+    } else if (active) {  // a lower neighbour at -1: only at the low faces of the grid
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) {
+            int l[NO];
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < NO; ++d) {
+                const int sd = (s >> d) & 1;
+                ok = ok && (sd || low_ok[d]);
+                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
+            }
+            const T v = voxel_weight<T, NO>(dlo, s, w);
+            cell_add<FIX, T>(&acc[lds_index<NO>(l)], ok ? v : T(0), fs);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ forward K4
 template <typename T, int NI, int NO, bool HAS_PW, bool W3>
 __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
@@ -1292,7 +1420,8 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
     const uint32_t* __restrict__ tile_slab, const T* __restrict__ rot,
     const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
-    T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
+    T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked,
+    const uint32_t* __restrict__ maxpw, int fixed) {
     constexpr int NVH = tile_voxels_halo<NO>();
     __shared__ double acc[NVH];
     // Everything the block needs from memory before it can touch its records is requested at
@@ -1302,6 +1431,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     // busy chip).  Only a pose group's later images need a second pose fetch.
     const uint32_t n_it = *n_items;
     const uint32_t order_flag = n_items[1];  // the tile scan's verdict on the cloud's order
+    const uint32_t maxpw_bits = HAS_PW ? *maxpw : 0x3f800000u;  // max |point_weight| (1.0f without)
     const WorkItem item = items[blockIdx.x];
     Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
@@ -1342,76 +1472,36 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         nxt[u] = rec[ru < r1 ? ru : (r1 > item.begin ? r1 - 1 : item.begin)];
     }
     lds_barrier();  // LDS phases only: prefetched records stay in flight
-    while (r < r1) {
-        RecT<T, W3> cur[kPF];
+    // fp32 data: exact 64-bit fixed-point sums (see FixScale); fp64 data and non-finite weights: f64
+    const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * __uint_as_float(maxpw_bits)
+                                                 : __builtin_inff(),
+                                  item.end - item.begin, fixed);
+    auto record_loop = [&](auto fix_tag) {
+        constexpr bool FIX = decltype(fix_tag)::value;
+        while (r < r1) {
+            RecT<T, W3> cur[kPF];
 #pragma unroll
-        for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
-        const uint32_t r_cur = r;
-        r += kPF * step;
+            for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
+            const uint32_t r_cur = r;
+            r += kPF * step;
 #pragma unroll
-        for (int u = 0; u < kPF; ++u) {
-            const uint32_t ru = r + u * step;
-            nxt[u] = rec[ru < r1 ? ru : r1 - 1];  // clamped prefetch (branch-free loop body)
-        }
-#pragma unroll
-        for (int u = 0; u < kPF; ++u) {
-            const RecT<T, W3> rc = cur[u];
-            const bool active = r_cur + u * step < r1;
-            T pt[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
-            const T w = HAS_PW ? ps.ow * rc.v[HAS_PW ? 3 : 0] : ps.ow * T(1);  // src/raster.jl:52
-            int ref0[NO];
-            T dlo[NO];
-            ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
-            // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
-            // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
-            // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
-            int lb[NO];
-            bool low_ok[NO];
-#pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                lb[d] = ref0[d] - x0[d];
-                // records of this tile have lb in [-1, T-1]; the clamp only matters if the
-                // caller breaks the REUSE_BINNING contract (stale workspace): LDS indices
-                // stay legal
-                lb[d] = lb[d] < -1 ? -1
-                                   : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
-                low_ok[d] = lb[d] >= 0;
+            for (int u = 0; u < kPF; ++u) {
+                const uint32_t ru = r + u * step;
+                nxt[u] = rec[ru < r1 ? ru : r1 - 1];  // clamped prefetch (branch-free loop body)
             }
-            bool interior = true;
 #pragma unroll
-            for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
-            if (active && interior) {
-                // common case: one base address, the 2^N neighbours are compile-time offsets
-                // (they fold into the ds_add offset field)
-                double* base = &acc[lds_index<NO>(lb)];
-#pragma unroll
-                for (int s = 0; s < (1 << NO); ++s)
-                    atomicAdd(base + nbr_lds_offset<NO>(s), (double)voxel_weight<T, NO>(dlo, s, w));
-            } else if (active) {  // a lower neighbour at -1: only at the low faces of the grid
-#pragma unroll
-                for (int s = 0; s < (1 << NO); ++s) {
-                    int l[NO];
-                    bool ok = true;
-#pragma unroll
-                    for (int d = 0; d < NO; ++d) {
-                        const int sd = (s >> d) & 1;
-                        ok = ok && (sd || low_ok[d]);
-                        l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
-                    }
-                    const T v = voxel_weight<T, NO>(dlo, s, w);
-                    atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
-                }
-            }
+            for (int u = 0; u < kPF; ++u)
+                splat_record<FIX, T, NI, NO, HAS_PW>(cur[u], r_cur + u * step < r1, ps, gd, x0, acc, fs);
         }
-    }
+    };
+    if (fs.mul != 0.0) record_loop(std::true_type{});  // (uniform)
+    else record_loop(std::false_type{});
     lds_barrier();  // LDS phases only: prefetched records stay in flight
     if ((item.part_nparts >> 16) > 1) {
         // part of a split tile: the whole LDS tile goes to this part's overflow slab;
         // k_halo_gather sums the parts
         T* slab = ovf + (size_t)(tile_slab[item.tile] + (item.part_nparts & 0xffffu)) * NVH;
-        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)acc[i];
+        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)fix_value(acc[i], fs);
         return;
     }
     // Flush, one LDS row (TX + 1 cells along x) at a time: the row's y/z coordinates, bounds
@@ -1435,7 +1525,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
         if (row >= ROWS) continue;
         const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
-        const double a = acc[row * (TX + 1) + x];
+        const double a = fix_value(acc[row * (TX + 1) + x], fs);
         const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
         if (owned) {
             const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
@@ -1454,7 +1544,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     }
     // x == TX column: the X-face of the halo buffer is indexed by the row number
     for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
-        hb[row] = (T)acc[row * (TX + 1) + TX];
+        hb[row] = (T)fix_value(acc[row * (TX + 1) + TX], fs);
 }
 
 // ------------------------------------------------------------------ forward K4, local binning
@@ -1466,7 +1556,8 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
     const WorkItem* __restrict__ items, const uint32_t* __restrict__ n_items,
     const uint32_t* __restrict__ tile_slab, const T* __restrict__ rot,
     const T* __restrict__ trans, const T* __restrict__ ow, const T* __restrict__ bg, int64_t b0,
-    T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked) {
+    T* __restrict__ out, T* __restrict__ halo, T* __restrict__ ovf, int blocked,
+    const uint32_t* __restrict__ maxpw, int fixed) {
     constexpr int NVH = tile_voxels_halo<NO>();
     __shared__ double acc[NVH];
     // Everything the block needs from memory before it can touch its records is requested at
@@ -1476,6 +1567,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
     // busy chip).  Only a pose group's later images need a second pose fetch.
     const uint32_t n_it = *n_items;
     const WorkItem item = items[blockIdx.x];
+    const uint32_t maxpw_bits = HAS_PW ? *maxpw : 0x3f800000u;  // max |point_weight| (1.0f without)
     Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
     if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
@@ -1489,6 +1581,13 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
 #define DPR_PF 2
 #endif
     constexpr int kPF = DPR_PF;
+    // fp32 data: exact 64-bit fixed-point sums (see FixScale).  Bound on the records of the item:
+    // a run holds at most one sub-chunk (<= 4096 records).
+    uint32_t n_bound = (item.end - item.begin) < (1u << 19) ? (item.end - item.begin) * 4096u : max_rec;
+    n_bound = n_bound < max_rec ? n_bound : max_rec;
+    const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * __uint_as_float(maxpw_bits)
+                                                 : __builtin_inff(),
+                                  n_bound, fixed);
     {
         // LOCAL BINNING: the item is a range of run descriptors; the records of a run are
         // contiguous.  Each thread takes a contiguous share of the item's records (as in the
@@ -1528,55 +1627,10 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
                     }
 #pragma unroll
                     for (int u = 0; u < kPF; ++u) {
-                        const RecT<T, W3> rc = cur[u];
-                        const bool active = i_cur + u < i1;
-                    T pt[NI];
-            #pragma unroll
-                    for (int j = 0; j < NI; ++j) pt[j] = rc.v[j];
-                    const T w = HAS_PW ? ps.ow * rc.v[HAS_PW ? 3 : 0] : ps.ow * T(1);  // src/raster.jl:52
-                    int ref0[NO];
-                    T dlo[NO];
-                    ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);  // in range by construction
-                    // Individual drop of out-of-range neighbours (src/raster.jl:62) without branches:
-                    // an upper neighbour beyond the grid lands in an LDS cell that is never flushed;
-                    // a lower neighbour at -1 (ref0 == -1) is redirected to cell 0 with weight 0.
-                    int lb[NO];
-                    bool low_ok[NO];
-            #pragma unroll
-                    for (int d = 0; d < NO; ++d) {
-                        lb[d] = ref0[d] - x0[d];
-                        // records of this tile have lb in [-1, T-1]; the clamp only matters if the
-                        // caller breaks the REUSE_BINNING contract (stale workspace): LDS indices
-                        // stay legal
-                        lb[d] = lb[d] < -1 ? -1
-                                           : (lb[d] > TileDims<NO>::T[d] - 1 ? TileDims<NO>::T[d] - 1 : lb[d]);
-                        low_ok[d] = lb[d] >= 0;
-                    }
-                    bool interior = true;
-            #pragma unroll
-                    for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
-                    if (active && interior) {
-                        // common case: one base address, the 2^N neighbours are compile-time offsets
-                        // (they fold into the ds_add offset field)
-                        double* base = &acc[lds_index<NO>(lb)];
-            #pragma unroll
-                        for (int s = 0; s < (1 << NO); ++s)
-                            atomicAdd(base + nbr_lds_offset<NO>(s), (double)voxel_weight<T, NO>(dlo, s, w));
-                    } else if (active) {  // a lower neighbour at -1: only at the low faces of the grid
-            #pragma unroll
-                        for (int s = 0; s < (1 << NO); ++s) {
-                            int l[NO];
-                            bool ok = true;
-            #pragma unroll
-                            for (int d = 0; d < NO; ++d) {
-                                const int sd = (s >> d) & 1;
-                                ok = ok && (sd || low_ok[d]);
-                                l[d] = (sd || low_ok[d]) ? lb[d] + sd : 0;
-                            }
-                            const T v = voxel_weight<T, NO>(dlo, s, w);
-                            atomicAdd(&acc[lds_index<NO>(l)], ok ? (double)v : 0.0);
-                        }
-                    }
+                        if (fs.mul != 0.0)  // (uniform)
+                            splat_record<true, T, NI, NO, HAS_PW>(cur[u], i_cur + u < i1, ps, gd, x0, acc, fs);
+                        else
+                            splat_record<false, T, NI, NO, HAS_PW>(cur[u], i_cur + u < i1, ps, gd, x0, acc, fs);
                     }
                 }
             }
@@ -1588,7 +1642,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
         // part of a split tile: the whole LDS tile goes to this part's overflow slab;
         // k_halo_gather sums the parts
         T* slab = ovf + (size_t)(tile_slab[item.tile] + (item.part_nparts & 0xffffu)) * NVH;
-        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)acc[i];
+        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)fix_value(acc[i], fs);
         return;
     }
     // Flush, one LDS row (TX + 1 cells along x) at a time: the row's y/z coordinates, bounds
@@ -1612,7 +1666,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
         if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
         if (row >= ROWS) continue;
         const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
-        const double a = acc[row * (TX + 1) + x];
+        const double a = fix_value(acc[row * (TX + 1) + x], fs);
         const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
         if (owned) {
             const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
@@ -1631,7 +1685,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
     }
     // x == TX column: the X-face of the halo buffer is indexed by the row number
     for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
-        hb[row] = (T)acc[row * (TX + 1) + TX];
+        hb[row] = (T)fix_value(acc[row * (TX + 1) + TX], fs);
 }
 
 // ------------------------------------------------------------------ forward K5
@@ -2764,7 +2818,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // (function-local static: thread-safe, no getenv on the call path) and clamped to valid ranges.
 struct Knobs {
     int cap3d_div, cap2d_div, cap_min, pose_group, scatter_wc, bwd_unpermute, compact_records,
-        splat_blocked;
+        splat_blocked, fixed_point;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -2782,6 +2836,7 @@ static const Knobs& knobs() {
         q.bwd_unpermute = env_int("DPR_BWD_UNPERMUTE", 1, 0, 1);
         q.compact_records = env_int("DPR_COMPACT_RECORDS", 1, 0, 1);
         q.splat_blocked = env_int("DPR_SPLAT_BLOCKED", 2, 0, 2);  // 2: decided on the device
+        q.fixed_point = env_int("DPR_FIXED_POINT", 1, 0, 1);  // 0: f64 LDS accumulators for fp32 data too
         return q;
     }();
     return k;
@@ -2813,7 +2868,7 @@ struct Plan {
     int sub;               // points per sub-chunk
     int64_t nsub;          // sub-chunks = blocks of k_bin_local
     int64_t max_desc;      // descriptors: worst case min(P, nsub * min(sub, NT))
-    size_t off_ltot, off_dstart, off_dcursor, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | n_desc
+    size_t off_ltot, off_dstart, off_dcursor, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | n_desc | max|pw|
 };
 
 // Pose groups: with few tiles per pose (2-D projections, small 3-D grids) the bins become
@@ -2925,7 +2980,7 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
         if (pl.max_desc < 1) pl.max_desc = 1;
         nrec = pl.nsub * pl.sub;  // every sub-chunk owns a slab of `sub` records
         pl.off_ltot = o;
-        o += align_up((size_t)(2 * NT1 + 1) * 4);
+        o += align_up((size_t)(2 * NT1 + 2) * 4);
         pl.off_dstart = o;
         o += align_up((size_t)(NT1 + 1) * 4);
         pl.off_dcursor = o;
@@ -3144,7 +3199,7 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
                        (const uint32_t*)(ws + pl.off_tile_start),                                \
                        (RecT<T, W3>*)(ws + pl.off_rec),                     \
                        WANT_IDX ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr, d_pts,     \
-                       d_pw, zero_dropped)
+                       d_pw, zero_dropped, (uint32_t*)(ws + pl.off_nitems) + 2)
         if constexpr (!HAS_PW) {
             if (records_are_compact(tg.NT, nb, false, WANT_IDX)) {
                 if (nb > 1) DPR_LAUNCH_WC(true, true);
@@ -3164,7 +3219,7 @@ static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom
                        (const uint32_t*)(ws + pl.off_counts),
                        (const uint32_t*)(ws + pl.off_tile_start), (Rec4<T>*)(ws + pl.off_rec),
                        (uint32_t*)(ws + pl.off_idx), (uint32_t*)(ws + pl.off_slot), d_pts, d_pw,
-                       zero_dropped);
+                       zero_dropped, (uint32_t*)(ws + pl.off_nitems) + 2);
     return DPR_OK;
 }
 
@@ -3259,8 +3314,8 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
         hdr_points = points;
         hdr_pw = pw;
     }
-    uint32_t* ltot = (uint32_t*)(ws + pl.off_ltot);  // ndesc[NT] | npts[NT] | n_desc
-    DPR_HIP(hipMemsetAsync(ltot, 0, (size_t)(2 * tg.NT + 1) * 4, st));
+    uint32_t* ltot = (uint32_t*)(ws + pl.off_ltot);  // ndesc[NT] | npts[NT] | n_desc | max|pw| bits
+    DPR_HIP(hipMemsetAsync(ltot, 0, (size_t)(2 * tg.NT + 2) * 4, st));
     stage_mark(st);
     const uint32_t spare = (uint32_t)(pl.nsub * pl.sub);
     const size_t lds = (size_t)tg.NT * 4;
@@ -3270,7 +3325,7 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
                        dim3((unsigned)pl.nsub), dim3(kBinThreads), lds, st, gd, tg, P, points,   \
                        pw, rot, trans, b, (RecT<T, W3>*)(ws + pl.off_rec), slot,                 \
                        (RunDesc*)(ws + pl.off_desc), ltot + 2 * tg.NT, ltot, ltot + tg.NT,       \
-                       spare, d_pts, d_pw, zero_dropped)
+                       spare, d_pts, d_pw, zero_dropped, ltot + 2 * tg.NT + 1)
     if (pw) DPR_LAUNCH_LOCAL(true, false);
     else if (!want_idx && knobs().compact_records) DPR_LAUNCH_LOCAL(false, true);
     else DPR_LAUNCH_LOCAL(false, false);
@@ -3363,7 +3418,8 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                        (const WorkItem*)(wsb + pl.off_items),                                   \
                        (const uint32_t*)(wsb + pl.off_nitems),                                  \
                        (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
-                       ovf, blocked)
+                       ovf, blocked, (const uint32_t*)(wsb + pl.off_ltot) + 2 * tg.NT + 1,      \
+                       knobs().fixed_point)
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
                        dim3(kSplatThreads), 0, st, gd, tg,                                      \
@@ -3371,7 +3427,8 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                        (const WorkItem*)(wsb + pl.off_items),                                   \
                        (const uint32_t*)(wsb + pl.off_nitems),                                  \
                        (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
-                       ovf, blocked)
+                       ovf, blocked, (const uint32_t*)(wsb + pl.off_nitems) + 2,                \
+                       knobs().fixed_point)
         if (pl.local) {
             if (pw) DPR_LAUNCH_SPLAT_RUNS(true, false);
             else if (!keep && knobs().compact_records) DPR_LAUNCH_SPLAT_RUNS(false, true);
