@@ -32,7 +32,9 @@
 // neighbour outside the footprint bound, goes to / comes from global memory directly.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/dpr.h"
 #include "dpr_device.h"
@@ -159,6 +161,30 @@ __device__ __forceinline__ bool co_load_chunk(const T* __restrict__ points,
     return any;
 }
 
+// max |point_weight| over the chunk (1 without point weights), identical in every thread; NaN
+// and Inf come out non-finite.  `smax`: one float per wave; ends with a barrier.
+template <typename T, bool HAS_PW>
+__device__ __forceinline__ float co_max_abs_weight(const T (&w)[kCOPPT], const bool (&live)[kCOPPT],
+                                                   float* smax) {
+    if (!HAS_PW) return 1.f;
+    uint32_t m = 0;  // bit patterns of non-negative floats: unsigned order, NaN above Inf
+#pragma unroll
+    for (int k = 0; k < kCOPPT; ++k) {
+        const uint32_t bits = __float_as_uint(fabsf((float)w[k]));
+        m = (live[k] && bits > m) ? bits : m;
+    }
+    m = wave_max<uint32_t>(m);
+    if ((threadIdx.x & (kWave - 1)) == 0) smax[threadIdx.x / kWave] = __uint_as_float(m);
+    __syncthreads();
+    uint32_t r = 0;
+#pragma unroll
+    for (int q = 0; q < kCOWaves; ++q) {
+        const uint32_t bits = __float_as_uint(smax[q]);
+        r = bits > r ? bits : r;
+    }
+    return __uint_as_float(r);
+}
+
 // Pixel rectangle [lo, hi] (inclusive, clipped to the grid) that bounds every in-grid neighbour
 // of every point of the chunk under pose `ps`, with one cell of slack for rounding.  Returns the
 // number of cells (0: nothing lands in the grid; > kCOCap: does not fit the LDS tile).
@@ -202,18 +228,29 @@ __device__ __forceinline__ int64_t co_footprint(const T (&c)[NI], const T (&h)[N
 // Footprints of the block's poses, computed ONCE per pose by one thread each and parked in LDS
 // (every thread recomputing them cost ~50 VALU per pose: a tenth of the pose loop's instructions).
 // Ends with a barrier.  foot[j] = {lo0, lo1, hi0, hi1} of pose b_lo + j.
+// fexp (forward, fp32 data): exponent of the pose's fixed-point scale, from |out_weight| times the
+// chunk's max |point_weight|; kFixOff = f64 atomics for this pose (non-finite weights, fp64 data).
+constexpr int kFixOff = -(1 << 30);
 template <typename T, int NI>
 __device__ __forceinline__ void co_fill_footprints(int (*foot)[4], const T (&c)[NI], const T (&h)[NI],
                                                    const GridDesc<2>& gd, const T* __restrict__ rot,
-                                                   const T* __restrict__ trans, int64_t b_lo, int nbs) {
+                                                   const T* __restrict__ trans, int64_t b_lo, int nbs,
+                                                   int* fexp = nullptr, const T* __restrict__ ow = nullptr,
+                                                   float maxpw = 1.f, int fixed = 0) {
     if ((int)threadIdx.x < nbs) {
-        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, nullptr, b_lo + threadIdx.x);
+        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b_lo + threadIdx.x);
         int lo[2], hi[2];
         (void)co_footprint<T, NI>(c, h, ps, gd, lo, hi);
         foot[threadIdx.x][0] = lo[0];
         foot[threadIdx.x][1] = lo[1];
         foot[threadIdx.x][2] = hi[0];
         foot[threadIdx.x][3] = hi[1];
+        if (fexp) {
+            // a cell collects at most one contribution per point of the chunk
+            const int e = fix_exponent(sizeof(T) == 4 ? fabsf((float)ps.ow) * maxpw : __builtin_inff(),
+                                       (uint32_t)kCOChunk, fixed);
+            fexp[threadIdx.x] = e == kFixNone ? kFixOff : e;
+        }
     }
     __syncthreads();
 }
@@ -252,6 +289,15 @@ __device__ __forceinline__ bool sort_header_ok(const SortHeader* hdr, const Sort
            hdr->pw == want.pw;
 }
 
+// DPR_FIXED_POINT=0 (experiment knob, read once): f64 LDS accumulators for fp32 data too
+static int co_fixed_point() {
+    static const int v = [] {
+        const char* e = getenv("DPR_FIXED_POINT");
+        return (e && atoi(e) == 0) ? 0 : 1;
+    }();
+    return v;
+}
+
 // ------------------------------------------------------------------ forward
 // Two kernels.  k_co_splat covers every (chunk, pose) whose footprint fits the LDS tile in one
 // pass -- nearly all of them on a sorted cloud -- with a short inner loop (at most 64 VGPRs for
@@ -267,15 +313,17 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     GridDesc<2> gd, int64_t P, int64_t B, int poses_per_slice, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans,
     const T* __restrict__ ow, T* __restrict__ out, uint32_t* __restrict__ wide_count,
-    uint4* __restrict__ wide_items) {
+    uint4* __restrict__ wide_items, int fixed) {
     __shared__ double acc[kCOCap];
     __shared__ T sbox[kCOWaves][6];
+    __shared__ float smaxw[kCOWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     for (int i = threadIdx.x; i < kCOCap; i += kCOThreads) acc[i] = 0.0;
     T pt[kCOPPT][NI], w[kCOPPT], c[NI], h[NI];
     bool live[kCOPPT];
     const bool any = co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P,
                                           (int64_t)blockIdx.x * kCOChunk, pt, w, live, c, h, sbox);
+    const float maxpw = co_max_abs_weight<T, HAS_PW>(w, live, smaxw);
     const int64_t b_lo = (int64_t)blockIdx.y * poses_per_slice;
     const int64_t b_hi = (b_lo + poses_per_slice < B) ? b_lo + poses_per_slice : B;
     const int nbs = any ? (int)(b_hi - b_lo) : 0;  // no finite point in this chunk: nothing to do
@@ -285,7 +333,8 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     const int rot0 = nbs > 0 ? (int)(blockIdx.x % (unsigned)nbs) : 0;
 #ifndef DPR_CO_NO_FOOT_TABLE
     __shared__ int foot[kCOMaxSlice][4];
-    co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, nbs);
+    __shared__ int fexp[kCOMaxSlice];
+    co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, nbs, fexp, ow, maxpw, fixed);
 #endif
     unsigned long long wide_mask = 0;  // poses of this slice whose footprint outgrows the tile
     static_assert(kCOMaxSlice <= 64, "one bit per pose of a slice");
@@ -308,61 +357,61 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
         // unsigned compares per neighbour; whatever falls outside the bound takes the cold path
         const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
         T* o = out + b * gd.G;
+        // fp32 data: exact 64-bit fixed-point sums in the LDS tile (FixScale, dpr_device.h): the
+        // kernel was bound by ds_add_f64 (2.56 G atomics / 1544 G/s = 1.66 of its 2.11 ms at C4's
+        // share); ds_add_u64 retires twice as fast
+#ifndef DPR_CO_NO_FOOT_TABLE
+        const int fe = fexp[(int)(b - b_lo)];
+#else
+        const int fe0 = fix_exponent(sizeof(T) == 4 ? fabsf((float)ps.ow) * maxpw : __builtin_inff(),
+                                     (uint32_t)kCOChunk, fixed);
+        const int fe = fe0 == kFixNone ? kFixOff : fe0;
+#endif
+        const FixScale fs = fix_scale_from_exponent(fe == kFixOff ? kFixNone : fe);
+        auto pose_points = [&](auto fix_tag) {
+            constexpr bool FIX = decltype(fix_tag)::value;
 #pragma unroll
-        for (int k = 0; k < kCOPPT; ++k) {
-            int ref0[2];
-            T dlo[2];
-            const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo);  // (NaN beyond the cloud)
-            const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
-            const int lx0 = ref0[0] - lo[0], ly0 = ref0[1] - lo[1];
-#ifndef DPR_CO_SPLAT_PER_NEIGHBOUR
-            // one range test for all four neighbours (the footprint is clipped to the grid; round 3:
-            // C4 forward 4.04 -> 4.00 ms; the same change in the gather kernel: 4.69 -> 4.16 ms)
-            if (ok && (unsigned)lx0 < (unsigned)(W - 1) && (unsigned)ly0 < (unsigned)(H - 1)) {
-                double* b0 = &acc[ly0 * W + lx0];
-                atomicAdd(b0, (double)voxel_weight<T, 2>(dlo, 0, wk));
-                atomicAdd(b0 + 1, (double)voxel_weight<T, 2>(dlo, 1, wk));
-                atomicAdd(b0 + W, (double)voxel_weight<T, 2>(dlo, 2, wk));
-                atomicAdd(b0 + W + 1, (double)voxel_weight<T, 2>(dlo, 3, wk));
-            } else if (ok) {
+            for (int k = 0; k < kCOPPT; ++k) {
+                int ref0[2];
+                T dlo[2];
+                const bool ok = ref_and_deltas<T, NI, 2>(pt[k], ps, gd, ref0, dlo);  // (NaN beyond the cloud)
+                const T wk = HAS_PW ? ps.ow * w[k] : ps.ow * T(1);  // src/raster.jl:52
+                const int lx0 = ref0[0] - lo[0], ly0 = ref0[1] - lo[1];
+                // one range test for all four neighbours (the footprint is clipped to the grid; round 3:
+                // C4 forward 4.04 -> 4.00 ms; the same change in the gather kernel: 4.69 -> 4.16 ms)
+                if (ok && (unsigned)lx0 < (unsigned)(W - 1) && (unsigned)ly0 < (unsigned)(H - 1)) {
+                    double* b0 = &acc[ly0 * W + lx0];
+                    cell_add<FIX, T>(b0, voxel_weight<T, 2>(dlo, 0, wk), fs);
+                    cell_add<FIX, T>(b0 + 1, voxel_weight<T, 2>(dlo, 1, wk), fs);
+                    cell_add<FIX, T>(b0 + W, voxel_weight<T, 2>(dlo, 2, wk), fs);
+                    cell_add<FIX, T>(b0 + W + 1, voxel_weight<T, 2>(dlo, 3, wk), fs);
+                } else if (ok) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    int lx = lx0 + (s & 1), ly = ly0 + (s >> 1);
-                    asm volatile("" : "+v"(lx), "+v"(ly));  // keep this path out of the hot one
-                    const T v = voxel_weight<T, 2>(dlo, s, wk);
-                    if ((unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)H) {
-                        atomicAdd(&acc[ly * W + lx], (double)v);
-                    } else {
-                        const int ix = lx + lo[0], iy = ly + lo[1];
-                        if (ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1])
-                            atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
+                    for (int s = 0; s < 4; ++s) {
+                        int lx = lx0 + (s & 1), ly = ly0 + (s >> 1);
+                        asm volatile("" : "+v"(lx), "+v"(ly));  // keep this path out of the hot one
+                        const T v = voxel_weight<T, 2>(dlo, s, wk);
+                        if ((unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)H) {
+                            cell_add<FIX, T>(&acc[ly * W + lx], v, fs);
+                        } else {
+                            const int ix = lx + lo[0], iy = ly + lo[1];
+                            if (ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1])
+                                atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
+                        }
                     }
                 }
             }
-#else
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int lx = lx0 + (s & 1), ly = ly0 + (s >> 1);
-                const T v = voxel_weight<T, 2>(dlo, s, wk);
-                if (ok && (unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)H) {
-                    atomicAdd(&acc[ly * W + lx], (double)v);
-                } else if (ok) {  // outside the bound (rounding): straight to the image
-                    int ix = lx + lo[0], iy = ly + lo[1];
-                    asm volatile("" : "+v"(ix), "+v"(iy));  // keep the address math in here
-                    if (ix >= 0 && ix < gd.n[0] && iy >= 0 && iy < gd.n[1])
-                        atomic_add<T>(o + (size_t)iy * gd.n[0] + ix, v);
-                }
-            }
-#endif
-        }
+        };
+        if (fs.mul != 0.0) pose_points(std::true_type{});  // (uniform)
+        else pose_points(std::false_type{});
         lds_barrier();
         // flush + re-zero: one wave per image row segment, contiguous x across the lanes
         for (int r = wave; r < H; r += kCOWaves) {
             T* orow = o + (size_t)(lo[1] + r) * gd.n[0] + lo[0];
             for (int x = lane; x < W; x += kWave) {
                 const double a = acc[r * W + x];
-                if (a != 0.0) {
-                    atomic_add<T>(orow + x, (T)a);
+                if (__double_as_longlong(a) != 0) {
+                    atomic_add<T>(orow + x, (T)fix_value(a, fs));
                     acc[r * W + x] = 0.0;
                 }
             }
@@ -388,10 +437,11 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
     GridDesc<2> gd, int64_t P, const T* __restrict__ points, const T* __restrict__ pw,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow,
     T* __restrict__ out, const uint32_t* __restrict__ wide_count,
-    const uint4* __restrict__ wide_items) {
+    const uint4* __restrict__ wide_items, int fixed) {
     // one workgroup per CU here (the register budget of the general path): twice the tile
     __shared__ double acc[kCOWideCap];
     __shared__ T sbox[kCOWaves][6];
+    __shared__ float smaxw[kCOWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t n_items = *wide_count;  // 0 in the usual case
     if (blockIdx.x >= n_items) return;
@@ -405,6 +455,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
         bool live[kCOPPT];
         co_load_chunk<T, NI>(points, HAS_PW ? pw : nullptr, P, (int64_t)item.x * kCOChunk, pt, w,
                              live, c, h, sbox);
+        const float maxpw = co_max_abs_weight<T, HAS_PW>(w, live, smaxw);
         const int64_t b_first = (int64_t)item.y | ((int64_t)item.w << 32);
         for (unsigned pm = item.z; pm; pm &= pm - 1) {  // the wide poses of the group (uniform)
         const int64_t b = b_first + (__ffs((int)pm) - 1);
@@ -419,6 +470,8 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
         const bool direct = W > kCOWideCap;
         const int band = direct ? H : kCOWideCap / W;
         T* o = out + b * gd.G;
+        const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * maxpw : __builtin_inff(),
+                                      (uint32_t)kCOChunk, fixed);
         int lx0[kCOPPT], ly0[kCOPPT];
         T v[kCOPPT][4];
 #pragma unroll
@@ -451,8 +504,10 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int lx = lx0[k] + (s & 1), ly = ly0[k] + (s >> 1) - y0;
-                    if ((unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)rows)
-                        atomicAdd(&acc[ly * W + lx], (double)v[k][s]);
+                    if ((unsigned)lx < (unsigned)W && (unsigned)ly < (unsigned)rows) {
+                        if (fs.mul != 0.0) cell_add<true, T>(&acc[ly * W + lx], v[k][s], fs);  // (uniform)
+                        else cell_add<false, T>(&acc[ly * W + lx], v[k][s], fs);
+                    }
                 }
             }
             lds_barrier();
@@ -461,8 +516,8 @@ __global__ __launch_bounds__(kCOThreads) void k_co_splat_wide(
                 T* orow = o + (size_t)(lo[1] + y0 + r) * gd.n[0] + lo[0];
                 for (int x = lane; x < W; x += kWave) {
                     const double a = acc[r * W + x];
-                    if (a != 0.0) {
-                        atomic_add<T>(orow + x, (T)a);
+                    if (__double_as_longlong(a) != 0) {
+                        atomic_add<T>(orow + x, (T)fix_value(a, fs));
                         acc[r * W + x] = 0.0;
                     }
                 }
@@ -881,17 +936,17 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
         if (pws) {
             hipLaunchKernelGGL((k_co_splat<T, NI, true>), gg, dim3(kCOThreads), 0, st, gd, P, B,
                                pl.poses_per_slice, pts, pws, rot, trans, ow, out, wide_count,
-                               wide_items);
+                               wide_items, co_fixed_point());
             hipLaunchKernelGGL((k_co_splat_wide<T, NI, true>), dim3(kCOWideBlocks),
                                dim3(kCOThreads), 0, st, gd, P, pts, pws, rot, trans, ow, out,
-                               wide_count, wide_items);
+                               wide_count, wide_items, co_fixed_point());
         } else {
             hipLaunchKernelGGL((k_co_splat<T, NI, false>), gg, dim3(kCOThreads), 0, st, gd, P, B,
                                pl.poses_per_slice, pts, pws, rot, trans, ow, out, wide_count,
-                               wide_items);
+                               wide_items, co_fixed_point());
             hipLaunchKernelGGL((k_co_splat_wide<T, NI, false>), dim3(kCOWideBlocks),
                                dim3(kCOThreads), 0, st, gd, P, pts, pws, rot, trans, ow, out,
-                               wide_count, wide_items);
+                               wide_count, wide_items, co_fixed_point());
         }
     }
     stage_mark(st);

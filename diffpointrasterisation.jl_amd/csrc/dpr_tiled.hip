@@ -245,54 +245,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// ---- 64-bit fixed-point LDS accumulators for fp32 data ---------------------------------------
-// ds_add_u64 retires a wave-instruction in 13.6 cycles, ds_add_f64 in 26.3 (ds_add_f32: 193;
-// profiles/r02_microbench_lds_conflicts.txt), and integer sums are EXACT: the forward result no
-// longer depends on the order in which a tile's records are accumulated.  A contribution v (an
-// fp32 value, exactly representable in f64) becomes round(v * 2^sexp) through the magic-number
-// trick: fma(v, 2^sexp, 1.5 * 2^52) has the integer in its low mantissa bits as long as
-// |v * 2^sexp| < 2^51, so the conversion costs one v_fma_f64 and one 32-bit subtract.
-// The scale is chosen per work item from
-//   maxw >= |every contribution|  (|out_weight| * max|point_weight|; the products of the deltas
-//                                  are <= 1 in fp32 as well) and
-//   n    >= contributions to one cell (a record adds to a cell at most once: n = records of the item)
-// such that n * maxw * 2^sexp <= 2^62 (the sum cannot overflow) and maxw * 2^sexp <= 2^50.
-// An item holds at most max(4096, P / 256) < 2^24 records, so a contribution keeps at least 38
-// bits below the largest weight (fp32 carries 24); typical tiles (thousands of records) keep 49.
-// Non-finite weights (NaN / Inf out_weight or point_weight) switch the item to f64 atomics, which
-// propagate them the IEEE way.
-struct FixScale {
-    double mul;  // 2^sexp, 0 = fixed point off (f64 atomics)
-    double inv;  // 2^-sexp
-};
-constexpr double kFixMagic = 6755399441055744.0;  // 1.5 * 2^52
-__device__ __forceinline__ FixScale fix_scale(float maxw, uint32_t n, int enabled) {
-    FixScale fs;
-    fs.mul = 0.0;
-    fs.inv = 0.0;
-    if (!enabled || !(maxw < __builtin_inff())) return fs;
-    int e = 0;
-    if (maxw > 0.f) (void)frexpf(maxw, &e);  // maxw < 2^e
-    const int bits_n = 32 - __clz((int)(n | 1u));  // n < 2^bits_n
-    int sexp = 62 - bits_n;
-    sexp = (sexp > 50 ? 50 : sexp) - e;
-    fs.mul = ldexp(1.0, sexp);
-    fs.inv = ldexp(1.0, -sexp);
-    return fs;
-}
-__device__ __forceinline__ unsigned long long fix_bits(float v, const FixScale& fs) {
-    const double x = fma((double)v, fs.mul, kFixMagic);
-    return (unsigned long long)(__double_as_longlong(x) - __double_as_longlong(kFixMagic));
-}
-__device__ __forceinline__ double fix_value(double cell, const FixScale& fs) {
-    return fs.mul != 0.0 ? (double)__double_as_longlong(cell) * fs.inv : cell;
-}
-// one contribution into an f64-sized LDS cell
-template <bool FIX, typename T>
-__device__ __forceinline__ void cell_add(double* cell, T v, const FixScale& fs) {
-    if constexpr (FIX && sizeof(T) == 4) atomicAdd((unsigned long long*)cell, fix_bits((float)v, fs));
-    else atomicAdd(cell, (double)v);
-}
 // max |point_weight| of the records a binning kernel has seen, as the bit pattern of a
 // non-negative float (unsigned order = float order; NaN sorts above Inf): wave max, one global
 // atomicMax per wave.  All 64 lanes must call.

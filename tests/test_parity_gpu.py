@@ -1074,3 +1074,68 @@ def test_random_configurations_against_oracle(oracle, dev, seed):
         assert_close(rp.rotation, ref_rp.rotation, tol(npdt, "pose"), "residual ds_drotation")
         assert_close(rp.out_weight, ref_rp.out_weight, tol(npdt, "pose"), "residual ds_dout_weight")
         assert_close(loss, ref_loss.astype(npdt).reshape(loss.shape), tol(npdt, "out"), "loss")
+
+
+# ------------------------------------------------------------------ fixed-point LDS accumulators
+def test_tiled_fp32_forward_is_independent_of_the_point_order(dev):
+    """The fp32 tile kernels accumulate in 64-bit fixed point: the sums are exact integers, so a
+    permutation of the cloud gives the same `out` BIT FOR BIT (no tile of this cloud is split
+    into parts -- parts are added in floating point)."""
+    d = D.make(n_points=200_000, n_in=3, n_out=3, batch=1, grid_n=96, seed=5, dtype=np.float32)
+    # uniform in a cube: ~2500 points per tile, below the 4096 records at which a tile is split
+    d.points = np.random.default_rng(5).uniform(-0.9, 0.9, size=d.points.shape).astype(np.float32)
+    pts, pw = T(d.points, dev), T(d.point_weights, dev)
+    R, t = T(d.rotations, dev), T(d.translations, dev)
+    ow = T(d.weights, dev)
+    perm = torch.randperm(pts.shape[0], device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    for weights in (None, pw):
+        a = dpr_amd.raster(d.grid, pts, R, t, None, ow, weights, algo="tiled")
+        b = dpr_amd.raster(d.grid, pts[perm].contiguous(), R, t, None, ow,
+                           None if weights is None else weights[perm].contiguous(), algo="tiled")
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("coherent", [False, True])
+def test_tiled_fp32_point_weights_over_many_orders_of_magnitude(oracle, dev, coherent):
+    """Fixed-point scale = 2^k / max|weight|: weights 2^-14 and more below the largest lose low
+    bits of THEIR mantissa, never more than 2^-38 of the largest weight -- norm-wise parity and a
+    max-abs bound relative to the largest weight."""
+    d = D.make(n_points=200_000, n_in=3, n_out=3, batch=1, grid_n=64, seed=6, dtype=np.float32)
+    rng = np.random.default_rng(7)
+    pw = (10.0 ** rng.uniform(-12, 3, size=d.n_points)).astype(np.float32)
+    pw[::2] *= -1  # signed
+    pts = d.points
+    if coherent:
+        pts = pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))]  # any coherent order will do
+    ref64 = oracle.raster(d.grid, pts, d.rotations, d.translations, None, d.weights, pw, dtype=np.float64)
+    ref32 = oracle.raster(d.grid, pts, d.rotations, d.translations, None, d.weights, pw, dtype=np.float32)
+    out = dpr_amd.raster(d.grid, T(pts, dev), T(d.rotations, dev), T(d.translations, dev), None,
+                         T(d.weights, dev), T(pw, dev), algo="tiled", coherent_points=coherent)
+    assert_close(out, ref64.astype(np.float32), 5e-5, "out vs fp64 oracle")
+    # against the fp32 oracle (identical contributions, sequential fp32 sums): a few ulp of the
+    # largest values
+    err = np.abs(out.cpu().numpy().astype(np.float64) - ref32.astype(np.float64)).max()
+    assert err <= 2e-6 * np.abs(ref32).max(), err
+
+
+@pytest.mark.parametrize("bad", [np.inf, np.nan])
+@pytest.mark.parametrize("where", ["point_weight", "out_weight"])
+def test_tiled_fp32_non_finite_weights_fall_back_to_ieee_sums(oracle, dev, bad, where):
+    """A NaN / Inf weight switches the tile kernels from fixed point to f64 atomics: NaN and Inf
+    land where the reference's arithmetic puts them, finite voxels stay right."""
+    d = D.make(n_points=50_000, n_in=3, n_out=3, batch=1, grid_n=48, seed=8, dtype=np.float32)
+    pw, ow = d.point_weights.copy(), d.weights.copy()
+    if where == "point_weight":
+        pw[123] = bad
+    else:
+        ow[0] = bad
+    ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, None, ow, pw, dtype=np.float32)
+    out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), None,
+                         T(ow, dev), T(pw, dev), algo="tiled").cpu().numpy()
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    assert np.array_equal(np.isposinf(out), np.isposinf(ref))
+    assert np.array_equal(np.isneginf(out), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    assert fin.any() or where == "out_weight"
+    if fin.any():
+        assert_close(out[fin], ref[fin], 5e-5)
