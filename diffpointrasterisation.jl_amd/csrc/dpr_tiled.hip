@@ -431,10 +431,11 @@ template <typename R> __device__ __forceinline__ void pin_record(R& r) {
 // many descriptors as points and runs slowly, which is why the caller has to ask for it.
 struct alignas(8) RunDesc {
     uint32_t start;       // first record of the run
-    uint32_t tile_count;  // tile | count << 16   (tile < 4096 on this path, count <= S <= 4096)
-    __host__ __device__ uint32_t tile() const { return tile_count & 0xffffu; }
-    __host__ __device__ uint32_t count() const { return tile_count >> 16; }
+    uint32_t tile_count;  // tile | count << 15   (tile < 32768, count <= S <= 4096)
+    __host__ __device__ uint32_t tile() const { return tile_count & 0x7fffu; }
+    __host__ __device__ uint32_t count() const { return tile_count >> 15; }
 };
+constexpr int kMaxLocalTiles = 16384;  // tiles per pose local binning supports (its LDS histogram)
 constexpr int kMaxRuns = 256;        // descriptors per round of a work item in k_tile_splat ...
 constexpr int kMaxRunsGather = 64;   // ... and in k_tile_gather (their tables live in LDS: 4
                                      // gather blocks per CU leave room for 64 runs)
@@ -759,6 +760,10 @@ __global__ __launch_bounds__(1024) void k_tilescan(TileScanArgs ts) {
                   ts.rot_words, ts.trans, ts.trans_words, ts.nonzero_bins, ts.nblk);
 }
 
+}  // namespace dpr
+#include "dpr_coarse.h"
+namespace dpr {
+
 // ------------------------------------------------------------------ K3: scatter
 // WANT_IDX: the binning will feed a pullback (original indices needed).
 // The next point is fetched before the current record is stored so that the wait for
@@ -1007,31 +1012,43 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
 }
 
 // ------------------------------------------------------------------ local binning: K1
-// One block per sub-chunk of S consecutive points (see "LOCAL BINNING" above).
-//   LDS: lhist[NT] (dynamic) | recs[S]
-// Outputs: records rec[sub * S ...] in tile order (rejected points leave holes at the end of the
-// sub-chunk's slab), slot_of[p] for the pullback, the sub-chunk's descriptors appended to
-// `desc` (position from one global atomic per block) and the per-tile totals tile_ndesc /
-// tile_npts (global atomics, two per descriptor).
+// One block per sub-chunk of S consecutive points (see "LOCAL BINNING" above), ALL poses of a
+// batch in one launch: the sub-chunk's points are read once and stay in registers while they are
+// binned pose after pose, each pose into its own copy of the per-pose workspace (copies are
+// `pose_stride` bytes apart).
+//   LDS: lhist[NT] (dynamic) | recs[S] | touched[kTouchCap]
+// A coherent sub-chunk touches a handful of tiles (13 of 2048 at C3, ~50 of 16 384 at C5 after the
+// coarse cell sort), so nothing here is proportional to NT: the wave that first adds to a bin of
+// the histogram appends the tile to `touched`, and the offsets, the descriptors and the clean-up of
+// the round walk that list.  A sub-chunk that touches more than kTouchCap tiles (incoherent
+// input) takes the full scan over all bins instead -- slow, still correct.
+// Outputs per pose: records rec[sub * S ...] in tile order (rejected points leave holes at the
+// end of the sub-chunk's slab), slot_of[p] for the pullback, the sub-chunk's descriptors in ITS
+// OWN slots desc[sub * S ...] with their number in blk_ndesc[sub] (no global cursor), and the
+// per-tile totals tile_ndesc / tile_npts (fire-and-forget global atomics, two per descriptor).
+struct LocalBinArgs {
+    char* ws;            // pose copy 0 of the per-pose workspace
+    size_t pose_stride;  // distance between the copies
+    size_t off_rec, off_slot, off_desc, off_bdesc, off_ltot;  // ltot: ndesc[NT] | npts[NT] | - | max|pw|
+};
+constexpr int kTouchCap = 1024;
 template <typename T, int NI, int NO, bool HAS_PW, int S, bool W3>
 __global__ __launch_bounds__(kBinThreads) void k_bin_local(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, const T* __restrict__ points,
-    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b,
-    RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, RunDesc* __restrict__ desc,
-    uint32_t* __restrict__ n_desc, uint32_t* __restrict__ tile_ndesc,
-    uint32_t* __restrict__ tile_npts, uint32_t spare_slot, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, int zero_dropped, uint32_t* __restrict__ maxpw) {
+    const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
+    int nb, LocalBinArgs la, int want_slot, uint32_t spare_slot, T* __restrict__ ds_dpoints,
+    T* __restrict__ ds_dpw, int zero_dropped) {
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kBinThreads;
-    constexpr int kMaxBpt = 4096 / kBinThreads;
     const int NT = tg.NT;
     extern __shared__ uint32_t lhist[];  // [NT]
     __shared__ RecT<T, W3> recs[S];
+    __shared__ uint16_t touched[kTouchCap];
     __shared__ uint32_t wsum[kBinThreads / kWave];
-    __shared__ uint32_t s_dbase;
+    __shared__ uint32_t s_ntouch, s_nvalid;
     for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
+    if (threadIdx.x == 0) s_ntouch = 0;
     const int64_t base = (int64_t)blockIdx.x * S;
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b);
     T pt[PPT][NI], w[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -1041,136 +1058,207 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
         w[k] = HAS_PW ? pw[pl] : T(1);
     }
     __syncthreads();
-    // a. classify; rank inside (sub-chunk, tile).  Neighbouring lanes of a coherent cloud fall
-    // into the same tile, and same-address returning LDS atomics serialise: each wave first
-    // ranks the lanes that share the tile of its first unranked lane (ballot), one atomic per
-    // distinct tile and wave.
-    int tile[PPT];
-    uint32_t lrank[PPT];
-    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of the fixed-point splat)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of the fixed-point splat)
+    for (int jp = 0; jp < nb; ++jp) {
+        const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
+        char* const wsp = la.ws + (size_t)jp * la.pose_stride;
+        RecT<T, W3>* const rec = (RecT<T, W3>*)(wsp + la.off_rec);
+        uint32_t* const slot_of = want_slot ? (uint32_t*)(wsp + la.off_slot) : (uint32_t*)nullptr;
+        RunDesc* const desc = (RunDesc*)(wsp + la.off_desc) + (size_t)blockIdx.x * S;
+        uint32_t* const ltot = (uint32_t*)(wsp + la.off_ltot);
+        // a. classify; rank inside (sub-chunk, tile).  Neighbouring lanes of a coherent cloud fall
+        // into the same tile, and same-address returning LDS atomics serialise: each wave first
+        // ranks the lanes that share the tile of its first unranked lane (ballot), one atomic per
+        // distinct tile and wave.
+        int tile[PPT];
+        uint32_t lrank[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
-        int ref0[NO];
-        T dlo[NO];
-        const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < P;
-        tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
-        lrank[k] = 0;
-        if (HAS_PW && valid) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
-        unsigned long long todo = __ballot(valid);
-        int rounds = 0;
-        while (todo && rounds < 8) {  // a few distinct tiles per wave; the rest one by one
-            const int leader = __ffsll((long long)todo) - 1;
-            const int t = __shfl(tile[k], leader, kWave);
-            const unsigned long long same = __ballot(tile[k] == t) & todo;
-            uint32_t b0 = 0;
-            if (lane == leader) b0 = atomicAdd(&lhist[t], (uint32_t)__popcll(same));
-            b0 = __shfl(b0, leader, kWave);
-            if ((same >> lane) & 1ull) lrank[k] = b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            todo &= ~same;
-            ++rounds;
-        }
-        if ((todo >> lane) & 1ull) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
-    }
-    lds_barrier();
-    // b. exclusive scan of lhist (in place); the same pass counts the non-empty bins (packed
-    // into the upper half: at most 4096 of each)
-    const int bpt = (NT + kBinThreads - 1) / kBinThreads;
-    const int bin0 = threadIdx.x * bpt;
-    uint32_t cnt[kMaxBpt], packed = 0;
-#pragma unroll
-    for (int q = 0; q < kMaxBpt; ++q) {
-        const int i = bin0 + q;
-        cnt[q] = (q < bpt && i < NT) ? lhist[i] : 0u;
-        packed += cnt[q] + (cnt[q] ? (1u << 16) : 0u);
-    }
-    uint32_t incl = packed;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += v;
-    }
-    if (lane == kWave - 1) wsum[wave] = incl;
-    lds_barrier();
-    uint32_t run = incl - packed;
-    for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
-    uint32_t total = 0;
-#pragma unroll
-    for (int wv = 0; wv < kBinThreads / kWave; ++wv) total += wsum[wv];
-    const uint32_t n_valid = total & 0xffffu, n_runs = total >> 16;
-    if (threadIdx.x == 0) s_dbase = n_runs ? atomicAdd(n_desc, n_runs) : 0u;
-    {
-        uint32_t r2 = run;
-#pragma unroll
-        for (int q = 0; q < kMaxBpt; ++q) {
-            const int i = bin0 + q;
-            if (q < bpt && i < NT) lhist[i] = r2 & 0xffffu;  // exclusive offset inside the sub-chunk
-            r2 += cnt[q] + (cnt[q] ? (1u << 16) : 0u);
-        }
-    }
-    lds_barrier();
-    // descriptors of this sub-chunk + per-tile totals
-    {
-        uint32_t r2 = run;
-#pragma unroll
-        for (int q = 0; q < kMaxBpt; ++q) {
-            const int i = bin0 + q;
-            if (q < bpt && i < NT && cnt[q]) {
-                RunDesc d;
-                d.start = (uint32_t)base + (r2 & 0xffffu);
-                d.tile_count = (uint32_t)i | (cnt[q] << 16);
-                desc[s_dbase + (r2 >> 16)] = d;
-                atomicAdd(&tile_ndesc[i], 1u);
-                atomicAdd(&tile_npts[i], cnt[q]);
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+            int ref0[NO];
+            T dlo[NO];
+            const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < P;
+            tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+            lrank[k] = 0;
+            if (HAS_PW && valid && jp == 0) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
+            unsigned long long todo = __ballot(valid);
+            int rounds = 0;
+            while (todo && rounds < 8) {  // a few distinct tiles per wave; the rest one by one
+                const int leader = __ffsll((long long)todo) - 1;
+                const int t = __shfl(tile[k], leader, kWave);
+                const unsigned long long same = __ballot(tile[k] == t) & todo;
+                uint32_t r0 = 0;
+                if (lane == leader) {
+                    r0 = atomicAdd(&lhist[t], (uint32_t)__popcll(same));
+                    if (r0 == 0) {  // first into this bin: the tile joins the list
+                        const uint32_t pos = atomicAdd(&s_ntouch, 1u);
+                        if (pos < (uint32_t)kTouchCap) touched[pos] = (uint16_t)t;
+                    }
+                }
+                r0 = __shfl(r0, leader, kWave);
+                if ((same >> lane) & 1ull) lrank[k] = r0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                todo &= ~same;
+                ++rounds;
             }
-            r2 += cnt[q] + (cnt[q] ? (1u << 16) : 0u);
-        }
-    }
-    // c. place into LDS in tile order
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
-        if (tile[k] >= 0) {
-            const uint32_t sidx = lhist[tile[k]] + lrank[k];
-            RecT<T, W3> r;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
-            if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
-            recs[sidx] = r;
-            if (slot_of) __builtin_nontemporal_store((uint32_t)base + sidx, &slot_of[p]);
-        } else if (p < P) {
-            if (slot_of) __builtin_nontemporal_store(spare_slot, &slot_of[p]);
-            if (zero_dropped) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-                ds_dpw[p] = T(0);
+            if ((todo >> lane) & 1ull) {
+                lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
+                if (lrank[k] == 0) {
+                    const uint32_t pos = atomicAdd(&s_ntouch, 1u);
+                    if (pos < (uint32_t)kTouchCap) touched[pos] = (uint16_t)tile[k];
+                }
             }
         }
+        lds_barrier();
+        // b. counts -> exclusive offsets inside the sub-chunk (in place), descriptors, tile totals
+        const uint32_t n_t = s_ntouch;  // distinct tiles of this sub-chunk under this pose
+        const bool listed = n_t <= (uint32_t)kTouchCap;  // (uniform)
+        if (listed) {
+            if (wave == 0) {
+                uint32_t carry = 0;
+                for (uint32_t i0 = 0; i0 < n_t; i0 += kWave) {
+                    const uint32_t i = i0 + lane;
+                    const uint32_t t = i < n_t ? touched[i] : 0u;
+                    const uint32_t c = i < n_t ? lhist[t] : 0u;
+                    uint32_t incl = c;
+#pragma unroll
+                    for (int o = 1; o < kWave; o <<= 1) {
+                        const uint32_t v = __shfl_up(incl, o, kWave);
+                        if (lane >= o) incl += v;
+                    }
+                    const uint32_t off = carry + incl - c;
+                    if (i < n_t) {
+                        lhist[t] = off;
+                        RunDesc d;
+                        d.start = (uint32_t)base + off;
+                        d.tile_count = t | (c << 15);
+                        desc[i] = d;
+                        atomicAdd(&ltot[t], 1u);
+                        atomicAdd(&ltot[NT + t], c);
+                    }
+                    carry += __shfl(incl, kWave - 1, kWave);
+                }
+                if (lane == 0) {
+                    s_nvalid = carry;
+                    ((uint32_t*)(wsp + la.off_bdesc))[blockIdx.x] = n_t;
+                }
+            }
+        } else {
+            // every bin: (count, non-empty) packed as count + (1 << 16) per non-empty bin (<= 4096 each)
+            const int bpt = (NT + kBinThreads - 1) / kBinThreads;
+            const int bin0 = threadIdx.x * bpt;
+            uint32_t packed = 0;
+            for (int q = 0; q < bpt; ++q) {
+                const int i = bin0 + q;
+                const uint32_t c = i < NT ? lhist[i] : 0u;
+                packed += c + (c ? (1u << 16) : 0u);
+            }
+            uint32_t incl = packed;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o, kWave);
+                if (lane >= o) incl += v;
+            }
+            if (lane == kWave - 1) wsum[wave] = incl;
+            lds_barrier();
+            uint32_t run = incl - packed;
+            for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
+            uint32_t total = 0;
+#pragma unroll
+            for (int wv = 0; wv < kBinThreads / kWave; ++wv) total += wsum[wv];
+            for (int q = 0; q < bpt; ++q) {
+                const int i = bin0 + q;
+                if (i >= NT) break;
+                const uint32_t c = lhist[i];
+                if (c) {
+                    RunDesc d;
+                    d.start = (uint32_t)base + (run & 0xffffu);
+                    d.tile_count = (uint32_t)i | (c << 15);
+                    desc[run >> 16] = d;
+                    atomicAdd(&ltot[i], 1u);
+                    atomicAdd(&ltot[NT + i], c);
+                }
+                lhist[i] = run & 0xffffu;
+                run += c + (c ? (1u << 16) : 0u);
+            }
+            if (threadIdx.x == 0) {
+                s_nvalid = total & 0xffffu;
+                ((uint32_t*)(wsp + la.off_bdesc))[blockIdx.x] = total >> 16;
+            }
+        }
+        lds_barrier();
+        // c. place into LDS in tile order
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+            if (tile[k] >= 0) {
+                const uint32_t sidx = lhist[tile[k]] + lrank[k];
+                RecT<T, W3> r;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
+                if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+                recs[sidx] = r;
+                if (slot_of) __builtin_nontemporal_store((uint32_t)base + sidx, &slot_of[p]);
+            } else if (p < P) {
+                if (slot_of) __builtin_nontemporal_store(spare_slot, &slot_of[p]);
+                if (zero_dropped && jp == 0) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
+                    ds_dpw[p] = T(0);
+                }
+            }
+        }
+        lds_barrier();
+        // d. write-out: one contiguous, coalesced run; clean the histogram for the next pose
+        const uint32_t n_valid = s_nvalid;
+        for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[base + i] = recs[i];
+        if (listed) {
+            for (uint32_t i = threadIdx.x; i < n_t; i += kBinThreads) lhist[touched[i]] = 0;
+        } else {
+            for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
+        }
+        if (threadIdx.x == 0) s_ntouch = 0;
+        lds_barrier();
     }
-    lds_barrier();
-    // d. write-out: one contiguous, coalesced run
-    for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[base + i] = recs[i];
-    if (HAS_PW) publish_max_abs(maxpw, max_w);
+    if (HAS_PW) publish_max_abs((uint32_t*)(la.ws + la.off_ltot) + 2 * NT + 1, max_w);
 }
 
 // local binning: K2 -- tile totals -> descriptor offsets, work list (a work item is a range of
-// a tile's descriptors holding about `cap` records at most), heaviest first.  Single block.
-// Also clears the cursors K3 uses.
-__global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ tile_ndesc,
-                                                  const uint32_t* __restrict__ tile_npts, int NT,
-                                                  uint32_t cap, uint32_t* __restrict__ tile_dstart,
-                                                  uint32_t* __restrict__ tile_cursor,
-                                                  WorkItem* __restrict__ items,
-                                                  uint32_t* __restrict__ n_items,
-                                                  uint32_t* __restrict__ tile_parts,
-                                                  uint32_t* __restrict__ tile_slab,
-                                                  uint32_t* __restrict__ split_list,
-                                                  uint32_t* __restrict__ n_split, int max_items,
-                                                  BinHeader hdr, BinHeader* __restrict__ hdr_out,
-                                                  const uint32_t* __restrict__ rot, int rot_words,
-                                                  const uint32_t* __restrict__ trans,
-                                                  int trans_words) {
+// a tile's descriptors holding about `cap` records at most), heaviest first.  One block per pose
+// of the batch (blockIdx.x = pose copy).  Also clears the cursors K3 uses.
+struct RunScanArgs {
+    char* ws;
+    size_t pose_stride;
+    size_t off_ltot, off_dstart, off_dcursor, off_items, off_nitems, off_tparts, off_tslab, off_split,
+        off_hdr;
+    int NT;
+    uint32_t cap;
+    int max_items;
+    BinHeader hdr;
+    const uint32_t* rot;  // pose b0 (words)
+    int rot_words;
+    const uint32_t* trans;
+    int trans_words;
+};
+__global__ __launch_bounds__(1024) void k_runscan(RunScanArgs a) {
+    char* const wsp = a.ws + (size_t)blockIdx.x * a.pose_stride;
+    const uint32_t* __restrict__ tile_ndesc = (const uint32_t*)(wsp + a.off_ltot);
+    const uint32_t* __restrict__ tile_npts = tile_ndesc + a.NT;
+    uint32_t* __restrict__ tile_dstart = (uint32_t*)(wsp + a.off_dstart);
+    uint32_t* __restrict__ tile_cursor = (uint32_t*)(wsp + a.off_dcursor);
+    WorkItem* __restrict__ items = (WorkItem*)(wsp + a.off_items);
+    uint32_t* __restrict__ n_items = (uint32_t*)(wsp + a.off_nitems);
+    uint32_t* __restrict__ tile_parts = (uint32_t*)(wsp + a.off_tparts);
+    uint32_t* __restrict__ tile_slab = (uint32_t*)(wsp + a.off_tslab);
+    uint32_t* __restrict__ n_split = (uint32_t*)(wsp + a.off_split);
+    uint32_t* __restrict__ split_list = n_split + 1;
+    BinHeader* __restrict__ hdr_out = (BinHeader*)(wsp + a.off_hdr);
+    const BinHeader& hdr = a.hdr;
+    const int NT = a.NT, max_items = a.max_items;
+    const uint32_t cap = a.cap;
+    const uint32_t* rot = a.rot + (size_t)blockIdx.x * a.rot_words;
+    const uint32_t* trans = a.trans + (size_t)blockIdx.x * a.trans_words;
+    const int rot_words = a.rot_words, trans_words = a.trans_words;
     if (threadIdx.x >= 1024 - 64) {  // binning header, as in the tile scan
         const int i = threadIdx.x - (1024 - 64);
         uint32_t* pose = (uint32_t*)hdr_out->pose;
@@ -1299,16 +1387,27 @@ __global__ __launch_bounds__(1024) void k_runscan(const uint32_t* __restrict__ t
     if (threadIdx.x == 0) *n_split = s_nsplit;
 }
 
-// local binning: K3 -- descriptors into tile order (any order inside a tile)
-__global__ __launch_bounds__(256) void k_place_desc(const RunDesc* __restrict__ desc,
-                                                    const uint32_t* __restrict__ n_desc,
-                                                    const uint32_t* __restrict__ tile_dstart,
-                                                    uint32_t* __restrict__ tile_cursor,
-                                                    RunDesc* __restrict__ sorted) {
-    const uint32_t n = *n_desc;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const RunDesc d = desc[i];
-        sorted[tile_dstart[d.tile()] + atomicAdd(&tile_cursor[d.tile()], 1u)] = d;
+// local binning: K3 -- descriptors into tile order (any order inside a tile).  A wave per
+// sub-chunk slot; blockIdx.y = pose copy.
+__global__ __launch_bounds__(256) void k_place_desc(char* ws, size_t pose_stride, size_t off_desc,
+                                                    size_t off_bdesc, size_t off_dstart,
+                                                    size_t off_dcursor, size_t off_sdesc,
+                                                    int64_t nsub, int S) {
+    char* const wsp = ws + (size_t)blockIdx.y * pose_stride;
+    const RunDesc* __restrict__ desc = (const RunDesc*)(wsp + off_desc);
+    const uint32_t* __restrict__ blk_ndesc = (const uint32_t*)(wsp + off_bdesc);
+    const uint32_t* __restrict__ tile_dstart = (const uint32_t*)(wsp + off_dstart);
+    uint32_t* __restrict__ tile_cursor = (uint32_t*)(wsp + off_dcursor);
+    RunDesc* __restrict__ sorted = (RunDesc*)(wsp + off_sdesc);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    const int64_t nwaves = (int64_t)gridDim.x * (256 / kWave);
+    for (int64_t sub = wave0; sub < nsub; sub += nwaves) {
+        const uint32_t n = blk_ndesc[sub] < (uint32_t)S ? blk_ndesc[sub] : (uint32_t)S;
+        for (uint32_t i = lane; i < n; i += kWave) {
+            const RunDesc d = desc[(size_t)sub * S + i];
+            sorted[tile_dstart[d.tile()] + atomicAdd(&tile_cursor[d.tile()], 1u)] = d;
+        }
     }
 }
 
@@ -2815,12 +2914,15 @@ struct Plan {
     // layout (header ... slot map), pose_stride bytes apart, so that the pullback finds the binning
     // of EVERY pose of the forward call; 0 when the poses share one copy (nothing is kept)
     size_t pose_stride;
-    // local binning (DPR_FLAG_COHERENT_POINTS, NT <= 4096)
+    // local binning (DPR_FLAG_COHERENT_POINTS, or the cloud cell-sorted inside the call; NT <= 16384)
     bool local;
+    int lb;                // poses binned per k_bin_local launch (each into its own copy of the
+                           // per-pose workspace: `copies` of them, pose_stride bytes apart)
+    int64_t copies;
     int sub;               // points per sub-chunk
     int64_t nsub;          // sub-chunks = blocks of k_bin_local
-    int64_t max_desc;      // descriptors: worst case min(P, nsub * min(sub, NT))
-    size_t off_ltot, off_dstart, off_dcursor, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | n_desc | max|pw|
+    int64_t max_desc;      // descriptor slots: `sub` per sub-chunk
+    size_t off_ltot, off_dstart, off_dcursor, off_bdesc, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | - | max|pw|
 };
 
 // Pose groups: with few tiles per pose (2-D projections, small 3-D grids) the bins become
@@ -2843,12 +2945,6 @@ static int pose_group(int NT, int64_t P, int64_t B, int max_group) {
     return bg;
 }
 
-size_t sort_workspace_bytes(int64_t P);
-template <typename T>
-int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
-                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes,
-                     uint32_t* inv_perm);
-
 static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group,
                       bool coherent = false, int n_in = 3, bool share_batch = false) {
     Plan pl;
@@ -2862,7 +2958,19 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     // grouped pipeline, which reads the points once per group (10 M points -> 512^2, 4 poses:
     // 0.56 ms grouped, 0.63 ms pose by pose on local bins)
     pl.bg = pose_group(NT1, P1, B, max_group);
-    pl.local = coherent && NT1 <= 4096 && knobs().bwd_unpermute && pl.bg == 1;
+    pl.local = (coherent || pl.sort_inside) && NT1 <= kMaxLocalTiles && knobs().bwd_unpermute && pl.bg == 1;
+    // poses binned by one k_bin_local launch (the points are read once for all of them): every
+    // pose of a kept batch, else up to 8 -- each needs its own records, P * lb <= 2^29
+    pl.lb = 1;
+    if (pl.local && B > 1) {
+        if (share_batch) {
+            pl.lb = B < 16 ? (int)B : 16;  // (the B copies exist anyway)
+        } else {
+            pl.lb = B < 8 ? (int)B : 8;
+            while (pl.lb > 1 && P1 * pl.lb > ((int64_t)1 << 29)) --pl.lb;
+        }
+    }
+    pl.copies = share_batch ? B : pl.lb;
     const int NT = NT1 * pl.bg;          // bins
     const int64_t P = P1 * pl.bg;        // records
     // Slices of the cloud = blocks of k_count / the scatter = rows of the counts table.
@@ -2927,16 +3035,16 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     pl.max_desc = 0;
     int64_t nrec = P;  // records (+ spare slot for rejected points)
     if (pl.local) {
-        const int64_t per = pl.sub < NT1 ? pl.sub : NT1;
-        pl.max_desc = pl.nsub * per < P1 ? pl.nsub * per : P1;
-        if (pl.max_desc < 1) pl.max_desc = 1;
-        nrec = pl.nsub * pl.sub;  // every sub-chunk owns a slab of `sub` records
+        pl.max_desc = pl.nsub * pl.sub;  // every sub-chunk owns `sub` descriptor slots ...
+        nrec = pl.nsub * pl.sub;         // ... and a slab of `sub` records
         pl.off_ltot = o;
         o += align_up((size_t)(2 * NT1 + 2) * 4);
         pl.off_dstart = o;
         o += align_up((size_t)(NT1 + 1) * 4);
         pl.off_dcursor = o;
         o += align_up((size_t)NT1 * 4);
+        pl.off_bdesc = o;
+        o += align_up((size_t)pl.nsub * 4);
         pl.off_desc = o;
         o += align_up((size_t)pl.max_desc * sizeof(RunDesc));
         pl.off_sdesc = o;
@@ -2949,9 +3057,9 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     pl.off_slot = o;
     o += align_up((size_t)(P + 1) * 4);
     (void)nrec;
-    if (share_batch) {  // everything up to here exists once per pose
+    if (pl.copies > 1) {  // everything up to here exists once per pose (of a kept batch / a local batch)
         pl.pose_stride = o;
-        o += (size_t)(B - 1) * pl.pose_stride;
+        o += (size_t)(pl.copies - 1) * pl.pose_stride;
     }
     pl.off_spts = pl.off_spw = pl.off_perm = pl.off_iperm = pl.off_sgrad = pl.off_sgradw = pl.off_sorttmp = o;
     if (pl.sort_inside) {
@@ -2959,8 +3067,7 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
         o += align_up((size_t)P1 * n_in * elem);
         pl.off_spw = o;
         o += align_up((size_t)P1 * elem);
-        pl.off_perm = o;
-        o += align_up((size_t)P1 * 4);
+        pl.off_perm = o;  // (unused since the coarse cell sort: only the inverse is needed)
         pl.off_iperm = o;  // inverse permutation: the un-sort of the gradients gathers through it
         o += align_up((size_t)P1 * 4);
         pl.off_sgrad = o;
@@ -2968,7 +3075,7 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
         pl.off_sgradw = o;
         o += align_up((size_t)P1 * elem);
         pl.off_sorttmp = o;
-        o += align_up(sort_workspace_bytes(P1));
+        o += align_up(coarse_workspace_bytes(elem, P1));
     }
     pl.off_aux = o;
     // aux: forward = halo buffer | overflow slabs ; pullback = per-item partials
@@ -3006,6 +3113,7 @@ static uint32_t plan_layout_id(const Plan& pl) {
     mix(pl.local ? pl.off_sdesc : 0);
     mix(pl.pose_stride);
     mix(pl.off_iperm);
+    mix((uint64_t)pl.lb);
     const uint32_t id = (uint32_t)(h ^ (h >> 32));
     return id ? id : 1u;
 }
@@ -3253,31 +3361,57 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     return rc;
 }
 
-// Local binning for one pose (DPR_FLAG_COHERENT_POINTS): clear the tile totals, k_bin_local,
-// k_runscan, k_place_desc.  Same stage marks as bin_points (count | scan | scatter become
+// Local binning of the poses [b, b + nb) (coherent cloud): clear the tile totals of the nb pose
+// copies, k_bin_local (all nb poses, the points read once), k_runscan, k_place_desc.  `ws` is pose
+// copy 0 of the batch.  Same stage marks as bin_points (count | scan | scatter become
 // clear | bin_local | runscan + place).
+template <typename K> static int allow_lds_bytes(K kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return DPR_OK;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    DPR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({(const void*)kernel, dev})) return DPR_OK;
+    DPR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kMaxLocalTiles * 4));
+    done.insert({(const void*)kernel, dev});
+    return DPR_OK;
+}
 template <typename T, int NI, int NO>
 static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                             const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
-                            const T* rot, const T* trans, int64_t b, bool want_idx, T* d_pts,
+                            const T* rot, const T* trans, int64_t b, int nb, bool want_idx, T* d_pts,
                             T* d_pw, int zero_dropped, bool keep_valid,
                             const T* hdr_points = nullptr, const T* hdr_pw = nullptr) {
     if (!hdr_points) {  // the header names the caller's buffers
         hdr_points = points;
         hdr_pw = pw;
     }
-    uint32_t* ltot = (uint32_t*)(ws + pl.off_ltot);  // ndesc[NT] | npts[NT] | n_desc | max|pw| bits
-    DPR_HIP(hipMemsetAsync(ltot, 0, (size_t)(2 * tg.NT + 2) * 4, st));
+    const size_t ltot_bytes = (size_t)(2 * tg.NT + 2) * 4;  // ndesc[NT] | npts[NT] | - | max|pw| bits
+    if (nb > 1)
+        DPR_HIP(hipMemset2DAsync(ws + pl.off_ltot, pl.pose_stride, 0, ltot_bytes, (size_t)nb, st));
+    else
+        DPR_HIP(hipMemsetAsync(ws + pl.off_ltot, 0, ltot_bytes, st));
     stage_mark(st);
     const uint32_t spare = (uint32_t)(pl.nsub * pl.sub);
     const size_t lds = (size_t)tg.NT * 4;
-    uint32_t* slot = want_idx ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr;
+    LocalBinArgs la;
+    la.ws = ws;
+    la.pose_stride = pl.pose_stride;
+    la.off_rec = pl.off_rec;
+    la.off_slot = pl.off_slot;
+    la.off_desc = pl.off_desc;
+    la.off_bdesc = pl.off_bdesc;
+    la.off_ltot = pl.off_ltot;
 #define DPR_LAUNCH_LOCAL(HAS_PW, W3)                                                              \
-    hipLaunchKernelGGL((k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3>),     \
-                       dim3((unsigned)pl.nsub), dim3(kBinThreads), lds, st, gd, tg, P, points,   \
-                       pw, rot, trans, b, (RecT<T, W3>*)(ws + pl.off_rec), slot,                 \
-                       (RunDesc*)(ws + pl.off_desc), ltot + 2 * tg.NT, ltot, ltot + tg.NT,       \
-                       spare, d_pts, d_pw, zero_dropped, ltot + 2 * tg.NT + 1)
+    do {                                                                                          \
+        auto kern = k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3>;          \
+        if (int rc = allow_lds_bytes(kern, lds)) return rc;                                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)pl.nsub), dim3(kBinThreads), lds, st, gd, tg, P,  \
+                           points, pw, rot, trans, b, nb, la, want_idx ? 1 : 0, spare, d_pts,     \
+                           d_pw, zero_dropped);                                                   \
+    } while (0)
     if (pw) DPR_LAUNCH_LOCAL(true, false);
     else if (!want_idx && knobs().compact_records) DPR_LAUNCH_LOCAL(false, true);
     else DPR_LAUNCH_LOCAL(false, false);
@@ -3285,24 +3419,34 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     stage_mark(st);
     int64_t grid64[3] = {1, 1, 1};
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
-    BinHeader hdr = make_header<T, NI, NO>(grid64, P, hdr_points, hdr_pw);
-    hdr.state = keep_valid ? kBinValid : 0u;
-    hdr.layout = plan_layout_id(pl);
-    hipLaunchKernelGGL(k_runscan, dim3(1), dim3(1024), 0, st, (const uint32_t*)ltot,
-                       (const uint32_t*)(ltot + tg.NT), tg.NT, pl.cap,
-                       (uint32_t*)(ws + pl.off_dstart), (uint32_t*)(ws + pl.off_dcursor),
-                       (WorkItem*)(ws + pl.off_items), (uint32_t*)(ws + pl.off_nitems),
-                       (uint32_t*)(ws + pl.off_tparts), (uint32_t*)(ws + pl.off_tslab),
-                       (uint32_t*)(ws + pl.off_split) + 1, (uint32_t*)(ws + pl.off_split),
-                       pl.max_items, hdr, (BinHeader*)(ws + pl.off_hdr),
-                       (const uint32_t*)(rot + b * (NO * NI)), (int)(NO * NI * sizeof(T) / 4),
-                       (const uint32_t*)(trans + b * NO), (int)(NO * sizeof(T) / 4));
-    int64_t pblocks = (pl.max_desc + 255) / 256;
+    RunScanArgs ra;
+    ra.ws = ws;
+    ra.pose_stride = pl.pose_stride;
+    ra.off_ltot = pl.off_ltot;
+    ra.off_dstart = pl.off_dstart;
+    ra.off_dcursor = pl.off_dcursor;
+    ra.off_items = pl.off_items;
+    ra.off_nitems = pl.off_nitems;
+    ra.off_tparts = pl.off_tparts;
+    ra.off_tslab = pl.off_tslab;
+    ra.off_split = pl.off_split;
+    ra.off_hdr = pl.off_hdr;
+    ra.NT = tg.NT;
+    ra.cap = pl.cap;
+    ra.max_items = pl.max_items;
+    ra.hdr = make_header<T, NI, NO>(grid64, P, hdr_points, hdr_pw);
+    ra.hdr.state = keep_valid ? kBinValid : 0u;
+    ra.hdr.layout = plan_layout_id(pl);
+    ra.rot = (const uint32_t*)(rot + b * (NO * NI));
+    ra.rot_words = (int)(NO * NI * sizeof(T) / 4);
+    ra.trans = (const uint32_t*)(trans + b * NO);
+    ra.trans_words = (int)(NO * sizeof(T) / 4);
+    hipLaunchKernelGGL(k_runscan, dim3((unsigned)nb), dim3(1024), 0, st, ra);
+    int64_t pblocks = (pl.nsub + 3) / 4;  // a wave per sub-chunk slot
     if (pblocks > 2048) pblocks = 2048;
-    hipLaunchKernelGGL(k_place_desc, dim3((unsigned)pblocks), dim3(256), 0, st,
-                       (const RunDesc*)(ws + pl.off_desc), (const uint32_t*)(ltot + 2 * tg.NT),
-                       (const uint32_t*)(ws + pl.off_dstart), (uint32_t*)(ws + pl.off_dcursor),
-                       (RunDesc*)(ws + pl.off_sdesc));
+    hipLaunchKernelGGL(k_place_desc, dim3((unsigned)pblocks, (unsigned)nb), dim3(256), 0, st, ws,
+                       pl.pose_stride, pl.off_desc, pl.off_bdesc, pl.off_dstart, pl.off_dcursor,
+                       pl.off_sdesc, pl.nsub, pl.sub);
     stage_mark(st);
     return DPR_OK;
 }
@@ -3336,11 +3480,11 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     const T* const user_points = points;  // what the binning header names
     const T* const user_pw = pw;
     if (pl.sort_inside) {
+        // coarse cell sort of the cloud (dpr_coarse.h): what local binning needs, a third of the
+        // cost of the full Hilbert sort; the inverse permutation brings gradients back
         T* spw = pw ? (T*)(ws + pl.off_spw) : (T*)nullptr;
-        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
-                                         (uint32_t*)(ws + pl.off_perm), pw, spw,
-                                         ws + pl.off_sorttmp, sort_workspace_bytes(P),
-                                         keep ? (uint32_t*)(ws + pl.off_iperm) : (uint32_t*)nullptr))
+        if (int rc = coarse_sort_points<T, NI>(st, P, points, pw, (T*)(ws + pl.off_spts), spw,
+                                               (uint32_t*)(ws + pl.off_iperm), ws + pl.off_sorttmp))
             return rc;
         points = (const T*)(ws + pl.off_spts);
         pw = spw;
@@ -3349,15 +3493,22 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     T* ovf = (T*)(ws + pl.off_aux +
                   align_up((size_t)tg.NT * pl.bg * halo_count<NO>() * sizeof(T)));
     const int blocked = knobs().splat_blocked;
+    // copy of the per-pose workspace pose b lives in: its own when the binning is kept, else its
+    // place in the local batch
+    auto copy_of = [&](int64_t b) { return (flags & 3u) && B > 1 ? b : (pl.local ? b % pl.lb : 0); };
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
         // per-pose part of the workspace (one copy, or one per pose when the binning is kept)
-        char* const wsb = ws + (size_t)b * pl.pose_stride;
+        char* const wsb = ws + (size_t)copy_of(b) * pl.pose_stride;
+        char* const ws0 = pl.local ? ws + (size_t)copy_of(b - b % pl.lb) * pl.pose_stride : wsb;  // copy 0 of the local batch
         if (pl.local) {
-            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
-                                                     b, keep, (T*)nullptr, (T*)nullptr, 0, keep,
-                                                     user_points, user_pw))
-                return rc;
+            if (b % pl.lb == 0) {  // first pose of a local batch: bin all its poses
+                const int nlb = (int)((B - b < pl.lb) ? B - b : pl.lb);
+                if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
+                                                         b, nlb, keep, (T*)nullptr, (T*)nullptr, 0,
+                                                         keep, user_points, user_pw))
+                    return rc;
+            }
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans, b,
                                                   (int)nb, keep, (T*)nullptr, (T*)nullptr, 0, keep,
                                                   user_points, user_pw))
@@ -3370,7 +3521,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                        (const WorkItem*)(wsb + pl.off_items),                                   \
                        (const uint32_t*)(wsb + pl.off_nitems),                                  \
                        (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
-                       ovf, blocked, (const uint32_t*)(wsb + pl.off_ltot) + 2 * tg.NT + 1,      \
+                       ovf, blocked, (const uint32_t*)(ws0 + pl.off_ltot) + 2 * tg.NT + 1,      \
                        knobs().fixed_point)
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
@@ -3433,10 +3584,9 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         // REUSE_BINNING: the sorted copy and its permutation are the KEEP forward's (the per-pose
         // headers, checked on the device, vouch for the call pair)
         if (!reuse)
-            if (int rc = sort_points_impl<T>((void*)st, NI, P, points, (T*)(ws + pl.off_spts),
-                                             (uint32_t*)(ws + pl.off_perm), pw, spw,
-                                             ws + pl.off_sorttmp, sort_workspace_bytes(P),
-                                             (uint32_t*)(ws + pl.off_iperm)))
+            if (int rc = coarse_sort_points<T, NI>(st, P, points, pw, (T*)(ws + pl.off_spts), spw,
+                                                   (uint32_t*)(ws + pl.off_iperm),
+                                                   ws + pl.off_sorttmp))
                 return rc;
         points = (const T*)(ws + pl.off_spts);
         pw = spw;
@@ -3451,11 +3601,17 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     if (!reuse) want.magic = 0;  // own binning: nothing to validate
     // every pose of the batch has its own gradient records (kept binning): one un-permute pass
     // over all of them at the end instead of a read-modify-write of the gradients per pose
-    const bool batch_unperm = reuse && pl.pose_stride > 0 && B > 1 && unperm1 && pl.bg == 1 && P > 0;
+    // (the same for the poses of a local batch, which were binned together into their own copies:
+    // one pass per batch, the first one overwriting, the later ones accumulating)
+    const bool batch_unperm = pl.pose_stride > 0 && B > 1 && unperm1 && pl.bg == 1 && P > 0 &&
+                              (reuse || pl.local);
+    // poses whose gradient records are summed by one un-permute pass
+    const int64_t ub = !batch_unperm ? 1 : ((flags & 3u) ? B : pl.lb);
+    auto copy_of = [&](int64_t b) { return (flags & 3u) && B > 1 ? b : (pl.local ? b % pl.lb : 0); };
     for (int64_t b = 0, nb = 1; b < B; b += nb) {
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
         // per-pose part of the workspace (one copy, or one per pose when the binning was kept)
-        char* const wsb = ws + (size_t)b * pl.pose_stride;
+        char* const wsb = ws + (size_t)copy_of(b) * pl.pose_stride;
         BinHeader* hdr = reuse ? (BinHeader*)(wsb + pl.off_hdr) : (BinHeader*)nullptr;
         PoseReduceArgs<T> pr;
         pr.partials = partials;
@@ -3489,11 +3645,18 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             stage_mark(st);
             stage_mark(st);
         } else if (pl.local) {
-            if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
-                                                     b, true, d_pts, d_pw,
-                                                     (b == 0 && !unperm) ? 1 : 0, false,
-                                                     user_points, user_pw))
-                return rc;
+            if (b % pl.lb == 0) {  // first pose of a local batch: bin all its poses
+                const int nlb = (int)((B - b < pl.lb) ? B - b : pl.lb);
+                if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
+                                                         b, nlb, true, d_pts, d_pw,
+                                                         (b == 0 && !unperm) ? 1 : 0, false,
+                                                         user_points, user_pw))
+                    return rc;
+            } else {
+                stage_mark(st);
+                stage_mark(st);
+                stage_mark(st);
+            }
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans, b,
                                                   (int)nb, true, d_pts, d_pw,
                                                   (b == 0 && !unperm) ? 1 : 0, false, user_points,
@@ -3562,13 +3725,23 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             hipLaunchKernelGGL((k_pose_reduce<T>), dim3(n_reduce, (unsigned)nb), dim3(1024), 0, st,
                                pr);
         stage_mark(st);
-    }
-    if (batch_unperm) {
-        PoseReduceArgs<T> none{};
-        hipLaunchKernelGGL((k_unpermute<T, NI, true, 1>), dim3((unsigned)((P + 1023) / 1024)),
-                           dim3(1024), 0, st, P, (int)B, (const Rec4<T>*)(ws + pl.off_rec),
-                           (const uint32_t*)(ws + pl.off_slot), d_pts, d_pw,
-                           (const BinHeader*)(ws + pl.off_hdr), 0, none, pl.pose_stride);
+        if (batch_unperm && ((b + 1) % ub == 0 || b + 1 == B)) {
+            // the gradient records of the batch that ends with pose b: summed per point in one pass
+            const int64_t bs = b - b % ub;  // first pose of the batch
+            char* const wsu = ws + (size_t)copy_of(bs) * pl.pose_stride;
+            const BinHeader* uh = reuse ? (const BinHeader*)(wsu + pl.off_hdr) : (const BinHeader*)nullptr;
+            PoseReduceArgs<T> none{};
+            if (bs == 0)
+                hipLaunchKernelGGL((k_unpermute<T, NI, true, 1>), dim3((unsigned)((P + 1023) / 1024)),
+                                   dim3(1024), 0, st, P, (int)(b + 1 - bs),
+                                   (const Rec4<T>*)(wsu + pl.off_rec), (const uint32_t*)(wsu + pl.off_slot),
+                                   d_pts, d_pw, uh, 0, none, pl.pose_stride);
+            else
+                hipLaunchKernelGGL((k_unpermute<T, NI, false, 1>), dim3((unsigned)((P + 1023) / 1024)),
+                                   dim3(1024), 0, st, P, (int)(b + 1 - bs),
+                                   (const Rec4<T>*)(wsu + pl.off_rec), (const uint32_t*)(wsu + pl.off_slot),
+                                   d_pts, d_pw, uh, 0, none, pl.pose_stride);
+        }
     }
     if (pl.sort_inside && P > 0)
         hipLaunchKernelGGL((k_unsort<T, NI>), dim3((unsigned)((P + 1023) / 1024)), dim3(256), 0, st, P,
