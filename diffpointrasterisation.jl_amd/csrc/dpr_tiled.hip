@@ -1073,6 +1073,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
         // distinct tile and wave.
         int tile[PPT];
         uint32_t lrank[PPT];
+        unsigned long long todo[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
@@ -1082,12 +1083,20 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
             tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
             lrank[k] = 0;
             if (HAS_PW && valid && jp == 0) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
-            unsigned long long todo = __ballot(valid);
+            todo[k] = __ballot(valid);
+        }
+        // (a fully sorted cloud: a wave's 64 points share one or two tiles -- a few ballot rounds
+        // rank them all.  A cell-sorted cloud, random inside its cell: nearly every lane has its own
+        // tile, and each ballot round is a dependent LDS round trip for one lane's worth of
+        // progress -- those lanes go to the per-lane atomics at once.)
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
             int rounds = 0;
-            while (todo && rounds < 8) {  // a few distinct tiles per wave; the rest one by one
-                const int leader = __ffsll((long long)todo) - 1;
+            while (todo[k] && rounds < 8) {
+                const int leader = __ffsll((long long)todo[k]) - 1;
                 const int t = __shfl(tile[k], leader, kWave);
-                const unsigned long long same = __ballot(tile[k] == t) & todo;
+                const unsigned long long same = __ballot(tile[k] == t) & todo[k];
+                if (__popcll(same) < 4) break;  // (uniform) not worth a round of its own
                 uint32_t r0 = 0;
                 if (lane == leader) {
                     r0 = atomicAdd(&lhist[t], (uint32_t)__popcll(same));
@@ -1098,12 +1107,22 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
                 }
                 r0 = __shfl(r0, leader, kWave);
                 if ((same >> lane) & 1ull) lrank[k] = r0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                todo &= ~same;
+                todo[k] &= ~same;
                 ++rounds;
             }
-            if ((todo >> lane) & 1ull) {
-                lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
-                if (lrank[k] == 0) {
+        }
+        // the rest one by one: all PPT returning atomics of a thread are in flight together
+        uint32_t r1[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            r1[k] = 1u;
+            if ((todo[k] >> lane) & 1ull) r1[k] = atomicAdd(&lhist[tile[k]], 1u);
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if ((todo[k] >> lane) & 1ull) {
+                lrank[k] = r1[k];
+                if (r1[k] == 0) {
                     const uint32_t pos = atomicAdd(&s_ntouch, 1u);
                     if (pos < (uint32_t)kTouchCap) touched[pos] = (uint16_t)tile[k];
                 }
@@ -1649,9 +1668,14 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
             const uint32_t d1 = (d0 + kMaxRuns < item.end) ? d0 + kMaxRuns : item.end;
             const int nruns = (int)(d1 - d0);
             const uint32_t n = load_runs(rt, runs, d0, d1, max_rec);  // barrier inside
+            // Record assignment.  blocked: a contiguous share per thread (a fully sorted cloud:
+            // neighbouring records hit the same voxels, lanes far apart in the list do not
+            // collide); strided: lane-adjacent records, coalesced loads (a cloud that is only
+            // cell-sorted, random inside its cell: no collisions to avoid).
             const uint32_t per = (n + kSplatThreads - 1) / kSplatThreads;
-            uint32_t i = threadIdx.x * per;
-            const uint32_t i1 = (i + per < n) ? i + per : n;
+            const uint32_t step = blocked ? 1u : (uint32_t)kSplatThreads;
+            uint32_t i = blocked ? threadIdx.x * per : threadIdx.x;
+            const uint32_t i1 = blocked ? ((i + per < n) ? i + per : n) : n;
             if (i < i1) {
                 RunCursor cu;
                 cu.seek(rt, i, nruns);
@@ -1660,28 +1684,28 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
 #pragma unroll
                 for (int u = 0; u < kPF; ++u) {
                     // past the end the last record is requested again (branch-free loop body)
-                    const bool adv = fetched + 1 < i1;
-                    nxt[u] = rec[cu.next(rt, adv ? 1u : 0u, nruns, adv)];
-                    fetched += adv ? 1u : 0u;
+                    const bool adv = fetched + step < i1;
+                    nxt[u] = rec[cu.next(rt, adv ? step : 0u, nruns, adv)];
+                    fetched += adv ? step : 0u;
                 }
                 while (i < i1) {
                     RecT<T, W3> cur[kPF];
 #pragma unroll
                     for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
                     const uint32_t i_cur = i;
-                    i += kPF;
+                    i += kPF * step;
 #pragma unroll
                     for (int u = 0; u < kPF; ++u) {
-                        const bool adv = fetched + 1 < i1;
-                        nxt[u] = rec[cu.next(rt, adv ? 1u : 0u, nruns, adv)];
-                        fetched += adv ? 1u : 0u;
+                        const bool adv = fetched + step < i1;
+                        nxt[u] = rec[cu.next(rt, adv ? step : 0u, nruns, adv)];
+                        fetched += adv ? step : 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < kPF; ++u) {
                         if (fs.mul != 0.0)  // (uniform)
-                            splat_record<true, T, NI, NO, HAS_PW>(cur[u], i_cur + u < i1, ps, gd, x0, acc, fs);
+                            splat_record<true, T, NI, NO, HAS_PW>(cur[u], i_cur + u * step < i1, ps, gd, x0, acc, fs);
                         else
-                            splat_record<false, T, NI, NO, HAS_PW>(cur[u], i_cur + u < i1, ps, gd, x0, acc, fs);
+                            splat_record<false, T, NI, NO, HAS_PW>(cur[u], i_cur + u * step < i1, ps, gd, x0, acc, fs);
                     }
                 }
             }
@@ -3521,7 +3545,8 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                        (const WorkItem*)(wsb + pl.off_items),                                   \
                        (const uint32_t*)(wsb + pl.off_nitems),                                  \
                        (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
-                       ovf, blocked, (const uint32_t*)(ws0 + pl.off_ltot) + 2 * tg.NT + 1,      \
+                       ovf, pl.sort_inside ? 0 : 1,                                              \
+                       (const uint32_t*)(ws0 + pl.off_ltot) + 2 * tg.NT + 1,                    \
                        knobs().fixed_point)
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \
