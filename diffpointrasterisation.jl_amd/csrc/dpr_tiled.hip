@@ -1032,14 +1032,19 @@ struct LocalBinArgs {
     size_t off_rec, off_slot, off_desc, off_bdesc, off_ltot;  // ltot: ndesc[NT] | npts[NT] | - | max|pw|
 };
 constexpr int kTouchCap = 1024;
-template <typename T, int NI, int NO, bool HAS_PW, int S, bool W3>
-__global__ __launch_bounds__(kBinThreads) void k_bin_local(
+// (fp32: 74 KB of LDS, two workgroups per CU when the kernel stays within 64 VGPRs; fp64 grids
+// with their larger histograms run one workgroup per CU anyway)
+// ONE: a single pose (nb == 1) -- the points die after the placement instead of living across a pose
+// loop, which is what lets the fp32 kernel fit 64 VGPRs.
+template <typename T, int NI, int NO, bool HAS_PW, int S, bool W3, bool ONE>
+__global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_local(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
     int nb, LocalBinArgs la, int want_slot, uint32_t spare_slot, T* __restrict__ ds_dpoints,
     T* __restrict__ ds_dpw, int zero_dropped) {
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kBinThreads;
+    if (ONE) nb = 1;
     const int NT = tg.NT;
     extern __shared__ uint32_t lhist[];  // [NT]
     __shared__ RecT<T, W3> recs[S];
@@ -1048,23 +1053,30 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
     __shared__ uint32_t s_ntouch, s_nvalid;
     for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
     if (threadIdx.x == 0) s_ntouch = 0;
+    // Everything per point is addressed as (block base: uniform, 64-bit) + (index inside the
+    // sub-chunk: 32-bit): with 64-bit per-point addresses the compiler hoists a dozen of them out
+    // of the pose loop and spills them (128 VGPRs + scratch instead of < 64).
     const int64_t base = (int64_t)blockIdx.x * S;
+    const uint32_t nloc = (uint32_t)((P - base < S) ? P - base : S);  // points of this sub-chunk
+    const T* const pts_blk = points + base * NI;
+    const T* const pw_blk = HAS_PW ? pw + base : nullptr;
     T pt[PPT][NI], w[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
-        const int64_t pl = p < P ? p : P - 1;
-        load_point<T, NI>(points, pl, pt[k]);
-        w[k] = HAS_PW ? pw[pl] : T(1);
+        const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
+        const uint32_t ll = lp < nloc ? lp : nloc - 1;
+        load_point<T, NI>(pts_blk, (int64_t)ll, pt[k]);
+        w[k] = HAS_PW ? pw_blk[ll] : T(1);
     }
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of the fixed-point splat)
+#pragma unroll 1
     for (int jp = 0; jp < nb; ++jp) {
         const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
         char* const wsp = la.ws + (size_t)jp * la.pose_stride;
-        RecT<T, W3>* const rec = (RecT<T, W3>*)(wsp + la.off_rec);
-        uint32_t* const slot_of = want_slot ? (uint32_t*)(wsp + la.off_slot) : (uint32_t*)nullptr;
+        RecT<T, W3>* const rec_blk = (RecT<T, W3>*)(wsp + la.off_rec) + base;
+        uint32_t* const slot_blk = want_slot ? (uint32_t*)(wsp + la.off_slot) + base : (uint32_t*)nullptr;
         RunDesc* const desc = (RunDesc*)(wsp + la.off_desc) + (size_t)blockIdx.x * S;
         uint32_t* const ltot = (uint32_t*)(wsp + la.off_ltot);
         // a. classify; rank inside (sub-chunk, tile).  Neighbouring lanes of a coherent cloud fall
@@ -1073,29 +1085,26 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
         // distinct tile and wave.
         int tile[PPT];
         uint32_t lrank[PPT];
-        unsigned long long todo[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
-            int ref0[NO];
-            T dlo[NO];
-            const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < P;
-            tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
-            lrank[k] = 0;
-            if (HAS_PW && valid && jp == 0) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
-            todo[k] = __ballot(valid);
-        }
+        uint32_t left = 0;  // bit k: this lane's point k still has to be ranked
         // (a fully sorted cloud: a wave's 64 points share one or two tiles -- a few ballot rounds
         // rank them all.  A cell-sorted cloud, random inside its cell: nearly every lane has its own
         // tile, and each ballot round is a dependent LDS round trip for one lane's worth of
         // progress -- those lanes go to the per-lane atomics at once.)
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
+            const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
+            int ref0[NO];
+            T dlo[NO];
+            const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && lp < nloc;
+            tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+            lrank[k] = 0;
+            if (HAS_PW && valid && jp == 0) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
+            unsigned long long todo = __ballot(valid);
             int rounds = 0;
-            while (todo[k] && rounds < 8) {
-                const int leader = __ffsll((long long)todo[k]) - 1;
+            while (todo && rounds < 8) {
+                const int leader = __ffsll((long long)todo) - 1;
                 const int t = __shfl(tile[k], leader, kWave);
-                const unsigned long long same = __ballot(tile[k] == t) & todo[k];
+                const unsigned long long same = __ballot(tile[k] == t) & todo;
                 if (__popcll(same) < 4) break;  // (uniform) not worth a round of its own
                 uint32_t r0 = 0;
                 if (lane == leader) {
@@ -1107,22 +1116,19 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
                 }
                 r0 = __shfl(r0, leader, kWave);
                 if ((same >> lane) & 1ull) lrank[k] = r0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                todo[k] &= ~same;
+                todo &= ~same;
                 ++rounds;
             }
+            if ((todo >> lane) & 1ull) left |= 1u << k;
         }
-        // the rest one by one: all PPT returning atomics of a thread are in flight together
-        uint32_t r1[PPT];
+        // the rest one by one: all returning atomics of a thread are in flight together
+        if (__ballot(left != 0)) {  // (uniform)
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            r1[k] = 1u;
-            if ((todo[k] >> lane) & 1ull) r1[k] = atomicAdd(&lhist[tile[k]], 1u);
-        }
+            for (int k = 0; k < PPT; ++k)
+                if ((left >> k) & 1u) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            if ((todo[k] >> lane) & 1ull) {
-                lrank[k] = r1[k];
-                if (r1[k] == 0) {
+            for (int k = 0; k < PPT; ++k) {
+                if (((left >> k) & 1u) && lrank[k] == 0) {
                     const uint32_t pos = atomicAdd(&s_ntouch, 1u);
                     if (pos < (uint32_t)kTouchCap) touched[pos] = (uint16_t)tile[k];
                 }
@@ -1209,28 +1215,29 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_local(
         // c. place into LDS in tile order
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base + threadIdx.x + (int64_t)k * kBinThreads;
+            const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
             if (tile[k] >= 0) {
                 const uint32_t sidx = lhist[tile[k]] + lrank[k];
                 RecT<T, W3> r;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
-                if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+                if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)base + lp, T(0));
                 recs[sidx] = r;
-                if (slot_of) __builtin_nontemporal_store((uint32_t)base + sidx, &slot_of[p]);
-            } else if (p < P) {
-                if (slot_of) __builtin_nontemporal_store(spare_slot, &slot_of[p]);
+                if (slot_blk) __builtin_nontemporal_store((uint32_t)base + sidx, &slot_blk[lp]);
+            } else if (lp < nloc) {
+                if (slot_blk) __builtin_nontemporal_store(spare_slot, &slot_blk[lp]);
                 if (zero_dropped && jp == 0) {
+                    T* const dp_blk = ds_dpoints + base * NI;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-                    ds_dpw[p] = T(0);
+                    for (int j = 0; j < NI; ++j) dp_blk[lp * NI + j] = T(0);
+                    (ds_dpw + base)[lp] = T(0);
                 }
             }
         }
         lds_barrier();
         // d. write-out: one contiguous, coalesced run; clean the histogram for the next pose
         const uint32_t n_valid = s_nvalid;
-        for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec[base + i] = recs[i];
+        for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec_blk[i] = recs[i];
         if (listed) {
             for (uint32_t i = threadIdx.x; i < n_t; i += kBinThreads) lhist[touched[i]] = 0;
         } else {
@@ -3428,18 +3435,24 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     la.off_desc = pl.off_desc;
     la.off_bdesc = pl.off_bdesc;
     la.off_ltot = pl.off_ltot;
-#define DPR_LAUNCH_LOCAL(HAS_PW, W3)                                                              \
+#define DPR_LAUNCH_LOCAL1(HAS_PW, W3, ONE)                                                        \
     do {                                                                                          \
-        auto kern = k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3>;          \
+        auto kern = k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3, ONE>;     \
         if (int rc = allow_lds_bytes(kern, lds)) return rc;                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)pl.nsub), dim3(kBinThreads), lds, st, gd, tg, P,  \
                            points, pw, rot, trans, b, nb, la, want_idx ? 1 : 0, spare, d_pts,     \
                            d_pw, zero_dropped);                                                   \
     } while (0)
+#define DPR_LAUNCH_LOCAL(HAS_PW, W3)                    \
+    do {                                                \
+        if (nb == 1) DPR_LAUNCH_LOCAL1(HAS_PW, W3, true); \
+        else DPR_LAUNCH_LOCAL1(HAS_PW, W3, false);      \
+    } while (0)
     if (pw) DPR_LAUNCH_LOCAL(true, false);
     else if (!want_idx && knobs().compact_records) DPR_LAUNCH_LOCAL(false, true);
     else DPR_LAUNCH_LOCAL(false, false);
 #undef DPR_LAUNCH_LOCAL
+#undef DPR_LAUNCH_LOCAL1
     stage_mark(st);
     int64_t grid64[3] = {1, 1, 1};
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
