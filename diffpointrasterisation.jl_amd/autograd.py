@@ -37,6 +37,15 @@ class _RasterFn(torch.autograd.Function):
             if isinstance(opt, torch.Tensor):
                 dtype = torch.promote_types(dtype, opt.dtype)
         out = empty_grid(grid_size, batch, dtype, points.device)
+        # The device-side check of a REUSE_BINNING pullback compares the ADDRESSES of the point /
+        # point_weight buffers with the forward's: canonicalise them ONCE here (promoted dtype,
+        # contiguous) and hand the same tensors to both calls -- raster_ and raster_pullback_
+        # would otherwise each make their own temporary for mixed dtypes or strided views, the
+        # header would not match and every gradient would come back NaN.
+        points_in, pw_in = points, point_weight
+        points = points.detach().to(dtype).contiguous()
+        if isinstance(point_weight, torch.Tensor):
+            point_weight = point_weight.detach().to(dtype).contiguous()
         ws = None
         P, n_in = points.shape
         B = 1 if single else int(batch)
@@ -66,6 +75,8 @@ class _RasterFn(torch.autograd.Function):
         ctx.opt_is_tensor = tuple(isinstance(t, torch.Tensor)
                                   for t in (background, out_weight, point_weight))
         ctx.algo, ctx.ws = algo, ws
+        ctx.points_dtype = points_in.dtype
+        ctx.pw_like = (pw_in.shape, pw_in.dtype) if isinstance(pw_in, torch.Tensor) else None
         return out
 
     @staticmethod
@@ -81,12 +92,14 @@ class _RasterFn(torch.autograd.Function):
                               algo=ctx.algo, workspace=ws, reuse_binning=ws is not None)
         need = ctx.needs_input_grad  # (grid_size, algo, points, rotation, translation, bg, ow, pw)
         grads = [None, None,
-                 pb.points.to(points.dtype) if need[2] else None,
+                 pb.points.to(ctx.points_dtype) if need[2] else None,
                  pb.rotation.to(rotation.dtype) if need[3] else None,
                  pb.translation.to(translation.dtype) if need[4] else None]
         for k, g in enumerate((pb.background, pb.out_weight, pb.point_weight)):
             given = ctx.opt_is_tensor[k] and need[5 + k]
-            if given:
+            if given and k == 2:  # (the saved point_weight is the canonical copy)
+                grads.append(g.reshape(ctx.pw_like[0]).to(ctx.pw_like[1]))
+            elif given:
                 ref = saved[3 + sum(ctx.opt_is_tensor[:k])]
                 grads.append(g.reshape(ref.shape).to(ref.dtype))
             else:

@@ -110,8 +110,19 @@ static int sharded_exchange(dpr_comm_t* comm, hipStream_t st, int rc_local, int 
                         "%s -- this rank cannot join the all-reduce (gradient buffers are NULL): "
                         "the other ranks block in it; destroy the communicator on every rank",
                         local_msg.c_str());
-        (void)hipMemsetAsync(ds_dpoints, 0xff, sizeof(T) * (size_t)P * n_in, st);
-        (void)hipMemsetAsync(ds_dpoint_weight, 0xff, sizeof(T) * (size_t)P, st);
+        // The NaN fill is sized by n_in: an argument error may be ABOUT n_in, so it is validated
+        // here before it sizes a write (the library accepts 1 <= n_in <= 3).  A rank with an
+        // unusable n_in cannot know how large its peers' buffers are: it cannot join.
+        if (n_in < 1 || n_in > 3)
+            return fail(rc_local,
+                        "%s -- this rank cannot join the all-reduce (n_in = %d does not size the "
+                        "gradient buffer): the other ranks block in it; destroy the communicator "
+                        "on every rank", local_msg.c_str(), n_in);
+        const hipError_t e1 = hipMemsetAsync(ds_dpoints, 0xff, sizeof(T) * (size_t)P * n_in, st);
+        const hipError_t e2 = hipMemsetAsync(ds_dpoint_weight, 0xff, sizeof(T) * (size_t)P, st);
+        if (e1 != hipSuccess || e2 != hipSuccess)  // joins all the same (peers must not block); said below
+            local_msg += std::string(" [the NaN fill of the gradient buffers failed too: ") +
+                         hipGetErrorString(e1 != hipSuccess ? e1 : e2) + "]";
     }
     ncclResult_t r = ncclSuccess;
     if (ds_dpoint_weight == ds_dpoints + (size_t)P * n_in) {

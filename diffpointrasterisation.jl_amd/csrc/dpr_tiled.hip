@@ -3200,7 +3200,7 @@ int tiled_tiles(int n_out, const int64_t* grid) {
 // May a KEEP_BINNING / REUSE_BINNING pair with B > 1 poses share on the tiled path when
 // DPR_ALGO_AUTO decides?  Every pose then keeps its own records (Plan::pose_stride): only where
 // pose groups are not an option anyway (more than 2048 tiles per pose) and the kept records stay
-// below ~17 GB (P * B <= 2^29; independent of the element type, so that dpr_resolve_algo_ex needs
+// below ~21 GB at fp64, ~13 GB at fp32 (P * B <= 2^29: a 4-word record, a slot and an index per point and pose; independent of the element type, so that dpr_resolve_algo_ex needs
 // none).  An explicit DPR_ALGO_TILED shares for any B.
 bool tiled_batch_share_ok(int n_out, const int64_t* grid, int64_t P, int64_t B) {
     if (B < 2 || P < 1 || P * B > ((int64_t)1 << 29)) return false;
@@ -3558,7 +3558,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                        (const WorkItem*)(wsb + pl.off_items),                                   \
                        (const uint32_t*)(wsb + pl.off_nitems),                                  \
                        (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
-                       ovf, pl.sort_inside ? 0 : 1,                                              \
+                       ovf, (pl.sort_inside || knobs().splat_blocked == 0) ? 0 : 1,                 \
                        (const uint32_t*)(ws0 + pl.off_ltot) + 2 * tg.NT + 1,                    \
                        knobs().fixed_point)
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
@@ -3675,7 +3675,8 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             // The binning of the preceding raster call (same points / pose / grid) is in the
             // workspace.  Direct-store mode: points without an in-range voxel are in no tile,
             // clear the outputs first (the un-permute mode reads zeros from the spare slot).
-            if (P > 0 && !unperm) {
+            // (once, before the first pose: the later poses of a kept batch accumulate)
+            if (P > 0 && !unperm && b == 0) {
                 DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * NI), st));
                 DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
             }

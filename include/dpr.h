@@ -84,8 +84,10 @@ extern "C" {
                               unless DPR_FLAG_COHERENT_POINTS says they already are.
                               3-D grids: chunks of 64 points are listed per voxel tile, tiles
                               read the points in place, all poses in one launch (what AUTO
-                              picks for a forward call over >= 4 poses of a cloud flagged
-                              DPR_FLAG_COHERENT_POINTS on a grid of more than 4096 tiles).
+                              picks for a FORWARD call without KEEP / REUSE flags over >= 4
+                              poses of a cloud flagged DPR_FLAG_COHERENT_POINTS that is SPARSE
+                              on the grid: P >= 30000 and P * 10 <= G from 16 poses on,
+                              P * 25 <= G for 4..15 poses; G = voxels per pose).
                               Correct for any point order; fast only for coherent input. */
 
 /* flags (the *_ex entry points).  DPR_ALGO_TILED: any B -- with B > 1 every pose keeps its own

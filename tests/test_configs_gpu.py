@@ -762,3 +762,8 @@ def test_bench_default_line_carries_the_scaling_reference():
     assert ref["poses_global"] == 512 and ref["value"] > 0 and ref["ms_per_step"] > 0
     assert ref["algo"]["raster"] == "chunked"
     assert line["roofline"]["frac"] > 0 and line["roofline"]["ms"] > 0
+    # the ceiling of the 8-GPU curve from one-GPU measurements, and both step figures of the headline
+    assert ref["share_of_one_gpu_of_8"]["poses"] == 64 and ref["share_of_one_gpu_of_8"]["ms_per_step"] > 0
+    assert 1.0 < ref["predicted_speedup_at_8_gpus_before_exchange"] <= 8.5
+    assert line["ms_per_step_cold"] > 0 and len(line["ms_per_step_loops"]) == 3
+    assert isinstance(line["config"]["untimed_steps"], int) and line["config"]["untimed_steps"] >= 3 + 1 + 2

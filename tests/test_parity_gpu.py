@@ -1139,3 +1139,29 @@ def test_tiled_fp32_non_finite_weights_fall_back_to_ieee_sums(oracle, dev, bad, 
     assert fin.any() or where == "out_weight"
     if fin.any():
         assert_close(out[fin], ref[fin], 5e-5)
+
+
+def test_autograd_rule_with_mixed_dtypes_and_strided_views(dev):
+    """raster_ad keeps the forward's binning for its backward pass; the device-side check of that
+    pairing compares buffer addresses, so the rule must hand the SAME canonical tensors to both
+    calls when points / point_weight need a dtype promotion or are non-contiguous views."""
+    torch.manual_seed(3)
+    P = 400_000  # AUTO -> tiled: the pair shares
+    base = (0.4 * torch.randn(P, 6, device=dev, dtype=torch.float32))
+    pts32 = base[:, ::2].detach().requires_grad_(True)           # strided view, fp32
+    pw_all = torch.rand(2 * P, device=dev, dtype=torch.float32)
+    pw32 = pw_all[::2].detach().requires_grad_(True)             # strided view, fp32
+    R = torch.eye(3, device=dev, dtype=torch.float64).requires_grad_(True)   # fp64 pose: promotion
+    t = torch.zeros(3, device=dev, dtype=torch.float64).requires_grad_(True)
+    out = dpr_amd.raster_ad((64, 64, 64), pts32, R, t, 0.0, 1.0, pw32)
+    assert out.dtype == torch.float64
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    for name, x in (("points", pts32), ("rotation", R), ("translation", t), ("point_weight", pw32)):
+        assert x.grad is not None and torch.isfinite(x.grad).all(), name
+    assert pts32.grad.dtype == torch.float32 and pw32.grad.shape == pw32.shape
+    # same numbers as the explicit pullback on canonical inputs
+    pb = dpr_amd.raster_pullback_(g, pts32.detach().double().contiguous(), R.detach(), t.detach(), None,
+                                  None, pw32.detach().double().contiguous())
+    assert_close(pts32.grad, pb.points.float().cpu().numpy(), 1e-6, "points.grad")
+    assert_close(R.grad, pb.rotation.cpu().numpy(), 1e-9, "rotation.grad")
