@@ -767,3 +767,93 @@ def test_bench_default_line_carries_the_scaling_reference():
     assert 1.0 < ref["predicted_speedup_at_8_gpus_before_exchange"] <= 8.5
     assert line["ms_per_step_cold"] > 0 and len(line["ms_per_step_loops"]) == 3
     assert isinstance(line["config"]["untimed_steps"], int) and line["config"]["untimed_steps"] >= 3 + 1 + 2
+
+
+# ------------------------------------------------------------------ the FULL jobs, checked once
+def test_c4_full_job_512_poses_against_the_oracle(oracle, dev):
+    """BASELINE.json configs[3] as ONE GPU runs it for the N > 1 curve's one-GPU point
+    (`scaling_reference` of bench.py): 10 M points -> 512^2, ALL 512 poses, fp32, AUTO (the
+    chunk-owner path in pose slices of 64).  Three poses -- the first, the first of the second
+    slice, the last -- against single-pose oracle calls on the whole cloud, forward and per-pose
+    gradients; the point gradients (sums over all 512 poses) against the batched oracle on a
+    10^5-point subsample of the cloud (a point's gradient depends on no other point)."""
+    import bench
+
+    P, n, B = 10_000_000, 512, 512
+    assert dpr_amd.resolve_algo("raster", (n, n), P, B, 3) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (n, n), P, B, 3) == "chunked"
+    np_pts = bench.synth_points("C4")
+    np_R, np_t = bench.synth_poses("C4", B, seed=1)
+    pts, R, t = T(np_pts, dev), T(np_R, dev), T(np_t, dev)
+    rng = np.random.default_rng(11)
+    np_ow = rng.uniform(0.5, 2.0, B).astype(np.float32)
+    ow = T(np_ow, dev)
+    check = [0, 64, B - 1]
+    out = dpr_amd.raster((n, n), pts, R, t, None, ow)
+    g = torch.randn(B, n, n, device=dev, dtype=torch.float32,
+                    generator=torch.Generator(device=dev).manual_seed(2)).permute(2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, None, ow)
+    np_g = g.cpu().numpy()  # [i1, i2, b]
+    for b in check:
+        ref = oracle.raster((n, n), np_pts, np_R[b:b + 1], np_t[b:b + 1], None, np_ow[b:b + 1],
+                            dtype=np.float32)
+        assert_close(out[..., b], ref[..., 0], 5e-5, f"out, pose {b}")
+        # the fp32 oracle: identical arithmetic per contribution, hence identical cell choice (against
+        # fp64 arithmetic ~2000 of the 10^7 points sit within rounding of a cell boundary and pick
+        # the other cell, where the gradient of the piecewise-bilinear interpolant is another one:
+        # 1 % of these sums -- SURVEY.md section 7, "cell-selection discontinuity")
+        rp = oracle.raster_pullback(np_g[..., b:b + 1], np_pts, np_R[b:b + 1], np_t[b:b + 1],
+                                    np_ow[b:b + 1], dtype=np.float32)
+        assert_close(pb.rotation[b], rp.rotation[0], 1e-3, f"ds_drotation, pose {b}")
+        assert_close(pb.translation[b], rp.translation[0], 1e-3, f"ds_dtranslation, pose {b}")
+        assert abs(float(pb.out_weight[b]) - rp.out_weight[0]) <= 1e-3 * max(abs(rp.out_weight[0]), np.sqrt(P))
+        assert abs(float(pb.background[b]) - rp.background[0]) <= 1e-3 * n
+    sub = rng.choice(P, 100_000, replace=False)
+    rs = oracle.raster_pullback(np_g, np_pts[sub], np_R, np_t, np_ow, dtype=np.float32, threaded=True)
+    assert_close(pb.points[T(sub, dev)], rs.points, 1e-4, "ds_dpoints of the subsample (512 poses summed)")
+    assert_close(pb.point_weight[T(sub, dev)], rs.point_weight, 1e-4, "ds_dpoint_weight of the subsample")
+
+
+def test_c5_full_batch_64_poses_against_the_oracle(oracle, dev):
+    """BASELINE.json configs[4] with its FULL batch on one GPU: 64 poses of a 512^3 fp64 grid
+    (68.7 GB each for `out` and `ds_dout`), AUTO -> the tiled path with the cloud cell-sorted
+    inside the call and the poses binned in batches of 8.  The cloud is a 5 M-point subsample of
+    the config's 50 M (the grids are what is large here; the share of one GPU of 8 runs the full
+    cloud in test_c5_share_8_poses).  Three poses -- the first, the first of the second batch,
+    the last -- against single-pose oracle calls, forward and pullback; `ds_dout` is non-zero
+    on those three poses only, so the summed point gradients are the oracle's over three poses."""
+    import bench
+
+    P, n, B = 5_000_000, 512, 64
+    assert dpr_amd.resolve_algo("raster", (n, n, n), P, B, 3) == "tiled"
+    np_pts = bench.synth_points("C5")[:P]
+    np_R, np_t = bench.synth_poses("C5", B, seed=1)
+    pts, R, t = T(np_pts, dev), T(np_R, dev), T(np_t, dev)
+    check = [0, 8, B - 1]
+    out = dpr_amd.raster((n, n, n), pts, R, t)
+    for b in check:
+        ref = oracle.raster((n, n, n), np_pts, np_R[b:b + 1], np_t[b:b + 1], threaded=True)
+        assert_close(out[..., b], ref[..., 0], 1e-10, f"out, pose {b}")
+        del ref
+    mass = out.sum(dim=(0, 1, 2)).cpu().numpy()
+    in_grid = float(out[..., 0].sum())
+    np.testing.assert_allclose(mass, np.full(B, in_grid), rtol=0.1)  # (every pose holds about the same mass)
+    del out
+    torch.cuda.empty_cache()
+    g = torch.zeros(B, n, n, n, device=dev, dtype=torch.float64)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    for b in check:
+        g[b].normal_(generator=gen)
+    g = g.permute(3, 2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t)
+    np_g = np.asfortranarray(np.stack([g[..., b].cpu().numpy() for b in check], axis=-1))
+    rp = oracle.raster_pullback(np_g, np_pts, np_R[check], np_t[check], threaded=True)
+    assert_close(pb.points, rp.points, 1e-10, "ds_dpoints (three poses carry sensitivity)")
+    assert_close(pb.point_weight, rp.point_weight, 1e-10, "ds_dpoint_weight")
+    for k, b in enumerate(check):
+        assert_close(pb.rotation[b], rp.rotation[k], 1e-9, f"ds_drotation, pose {b}")
+        assert_close(pb.translation[b], rp.translation[k], 1e-9, f"ds_dtranslation, pose {b}")
+        assert abs(float(pb.out_weight[b]) - rp.out_weight[k]) <= 1e-9 * max(abs(rp.out_weight[k]), 1.0)
+        assert abs(float(pb.background[b]) - rp.background[k]) <= 1e-8 * float(np.abs(np_g[..., k]).sum())
+    others = [b for b in range(B) if b not in check]
+    assert float(pb.rotation[others].abs().max()) == 0.0 and float(pb.out_weight[others].abs().max()) == 0.0
