@@ -90,6 +90,34 @@ extern "C" {
                               P * 25 <= G for 4..15 poses; G = voxels per pose).
                               Correct for any point order; fast only for coherent input. */
 
+/* SUMMATION ORDER.  The reference promises none for its float atomics (src/raster.jl:64) and sums
+ * serially per pose on the CPU (src/raster_pullback.jl:39-72).  Here, per algorithm and output:
+ *
+ *   algorithm            forward `out`                           ds_dpoints / ds_dpoint_weight         per-pose sums (ds_drotation, ds_dtranslation,
+ *                                                                                                       ds_dout_weight, ds_dbackground)
+ *   DPR_ALGO_ATOMIC      global float atomics: depends on the    one thread per point, poses in        wave -> block -> one float atomic per block:
+ *                        execution order (varies run to run,     index order: bit-reproducible         varies run to run at rounding level
+ *                        rounding level)
+ *   DPR_ALGO_TILED       fp32: 64-bit fixed-point sums per       one gradient record per (point,       per-thread sums in T over the tile's records
+ *                        tile, EXACT -- independent of the       pose), poses added in index order:    (their order in the tile's list varies), then
+ *                        order of the points and of execution;   bit-reproducible                      f64 across threads and tiles in a fixed order:
+ *                        tiles split into parts (> max(4096,                                           rounding level of T within a tile
+ *                        P/256) records) add their parts in
+ *                        fp32 in a fixed order, the records
+ *                        of a part vary: rounding level.
+ *                        fp64: f64 LDS atomics, order-dependent
+ *                        at 1e-16 relative
+ *   DPR_ALGO_CHUNKED     2-D: exact fixed-point sums per chunk   registers across the poses, fixed      per-thread in T, f64 across threads, partials
+ *                        (fp32), then float atomics into the     order: bit-reproducible for a given    per (chunk, pose) reduced in a fixed order:
+ *                        image across chunks: run to run,        point order (2-D); 3-D lists: read-    bit-reproducible for a given point order (2-D)
+ *                        rounding level.  3-D lists: f64 LDS     modify-write per pose in index order
+ *                        atomics + diverted global atomics
+ *
+ * "Rounding level" = the differences any two summation orders of the same terms show in the
+ * accumulation type; no output depends on the order beyond that.  The contributions themselves
+ * (cell choice, weights) are computed with the reference's operation order in T and do not depend
+ * on any order. */
+
 /* flags (the *_ex entry points).  DPR_ALGO_TILED: any B -- with B > 1 every pose keeps its own
  * binning (the per-pose part of the workspace is laid out B times; pose groups are off);
  * DPR_ALGO_CHUNKED on 2-D grids: any B (what is kept there is the sorted copy of the cloud and its
