@@ -19,6 +19,7 @@ size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int 
                              const int64_t* grid, int64_t P, int64_t B);
 bool tiled_batch_share_ok(int n_out, const int64_t* grid, int64_t P, int64_t B);
 int tiled_tiles(int n_out, const int64_t* grid);
+int tiled_slabs(int n_out, const int64_t* grid);  // 1: one piece; > 1: slabs along the last axis; 0: unsupported
 
 template <typename T, int NI, int NO>
 int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B, T* out,

@@ -106,9 +106,18 @@ constexpr int kSplitChunks = 32;     // k_halo_gather work items per split tile 
 constexpr int kSplitGrid = 2048;     // ... and the blocks that walk them (idle blocks cost nothing
                                      // measurable: a grid limited to the live items changed no kernel time)
 
+// Tile geometry of one launch sequence.  Grids of up to kMaxTiles tiles are one piece; larger
+// ones are processed in SLABS along the last axis: `nt[NO-1]` tile layers starting at global layer
+// `tz0`, the rest of the grid is invisible to the launch (points whose primary tile lies outside
+// are treated like points outside the grid).  A forward slab other than the first starts with a
+// GHOST layer (ghost = 1): the top layer of the slab below, binned and accumulated once more only
+// for its upper halo -- the first real layer's low faces need it, and the slab below has long
+// overwritten its halo buffer; ghost tiles flush no owned voxel and receive no halo.
 template <int NO> struct TileGeom {
-    int nt[NO];  // tiles per axis
-    int NT;      // tiles per pose
+    int nt[NO];  // tiles per axis (of this slab)
+    int NT;      // tiles per pose (of this slab)
+    int tz0;     // first tile layer along the last axis
+    int ghost;   // 1: local layer 0 is a ghost layer
 };
 
 template <int NO> __host__ __device__ constexpr int tile_voxels() {
@@ -125,30 +134,86 @@ template <int NO> __host__ __device__ constexpr int halo_count() {
     return tile_voxels_halo<NO>() - tile_voxels<NO>();
 }
 
-template <int NO> static bool make_geom(const int64_t* grid, TileGeom<NO>* tg) {
-    int64_t NT = 1;
-    for (int d = 0; d < NO; ++d) {
-        tg->nt[d] = (int)((grid[d] + TileDims<NO>::T[d] - 1) / TileDims<NO>::T[d]);
-        NT *= tg->nt[d];
+// How a grid is cut into slabs: `per_layer` tiles in a layer of the last axis, `layers` layers,
+// at most `lps` real layers per slab (a slab's tile count incl. a ghost layer stays <= kMaxTiles).
+struct SlabCut {
+    int per_layer, layers, lps, nslab;
+};
+// tiles one launch sequence may hold: kMaxTiles, or less through DPR_MAX_TILES (read once; lets a
+// test walk slabs on a small grid)
+static int max_tiles() {
+    static const int v = [] {
+        const char* e = getenv("DPR_MAX_TILES");
+        int x = e ? atoi(e) : kMaxTiles;
+        return x < 16 ? 16 : (x > kMaxTiles ? kMaxTiles : x);
+    }();
+    return v;
+}
+template <int NO> static bool make_slab_cut(const int64_t* grid, SlabCut* sc) {
+    const int kMaxTiles = max_tiles();  // (shadows the compile-time bound in this function)
+    int64_t per = 1;
+    for (int d = 0; d + 1 < NO; ++d) per *= (grid[d] + TileDims<NO>::T[d] - 1) / TileDims<NO>::T[d];
+    const int64_t layers = (grid[NO - 1] + TileDims<NO>::T[NO - 1] - 1) / TileDims<NO>::T[NO - 1];
+    if (per > kMaxTiles / 2 || layers > (1 << 20)) return false;  // (a real + a ghost layer must fit)
+    sc->per_layer = (int)per;
+    sc->layers = (int)layers;
+    if (per * layers <= kMaxTiles) {
+        sc->lps = (int)layers;
+        sc->nslab = 1;
+    } else {
+        sc->lps = (int)(kMaxTiles / per) - 1;
+        sc->nslab = (int)((layers + sc->lps - 1) / sc->lps);
     }
-    if (NT > kMaxTiles) return false;
-    tg->NT = (int)NT;
+    return true;
+}
+// geometry of slab `s` (forward: with the ghost layer for s > 0)
+template <int NO>
+static TileGeom<NO> slab_geom(const int64_t* grid, const SlabCut& sc, int s, bool forward) {
+    TileGeom<NO> tg;
+    for (int d = 0; d + 1 < NO; ++d)
+        tg.nt[d] = (int)((grid[d] + TileDims<NO>::T[d] - 1) / TileDims<NO>::T[d]);
+    const int first = s * sc.lps;
+    const int real = (sc.layers - first < sc.lps) ? sc.layers - first : sc.lps;
+    tg.ghost = (forward && s > 0) ? 1 : 0;
+    tg.tz0 = first - tg.ghost;
+    tg.nt[NO - 1] = real + tg.ghost;
+    tg.NT = sc.per_layer * tg.nt[NO - 1];
+    return tg;
+}
+// the largest tile count any slab of the cut has (what the workspace is planned for)
+static int slab_max_tiles(const SlabCut& sc) {
+    return sc.nslab == 1 ? sc.per_layer * sc.layers : sc.per_layer * (sc.lps + 1);
+}
+
+// single-piece geometry (false: the grid needs slabs, or is beyond them)
+template <int NO> static bool make_geom(const int64_t* grid, TileGeom<NO>* tg) {
+    SlabCut sc;
+    if (!make_slab_cut<NO>(grid, &sc) || sc.nslab != 1) return false;
+    *tg = slab_geom<NO>(grid, sc, 0, true);
     return true;
 }
 
-// primary tile of a point: tile of max(ref0, 0) per axis (ref0 in [-1, n-1])
+// primary tile of a point: tile of max(ref0, 0) per axis (ref0 in [-1, n-1]); -1 when that tile
+// lies outside the slab of this launch
 template <int NO>
 __device__ __forceinline__ int primary_tile(const int (&ref0)[NO], const TileGeom<NO>& tg) {
     int t = 0, stride = 1;
+    bool in = true;
 #pragma unroll
     for (int d = 0; d < NO; ++d) {
         const int r = ref0[d] < 0 ? 0 : ref0[d];
-        t += (r / TileDims<NO>::T[d]) * stride;
+        int c = r / TileDims<NO>::T[d];
+        if (d == NO - 1) {
+            c -= tg.tz0;
+            in = (unsigned)c < (unsigned)tg.nt[d];
+        }
+        t += c * stride;
         stride *= tg.nt[d];
     }
-    return t;
+    return in ? t : -1;
 }
 
+// tile -> local tile coordinates tc (neighbour bookkeeping) and GLOBAL voxel origin x0
 template <int NO>
 __device__ __forceinline__ void tile_origin(int tile, const TileGeom<NO>& tg, int (&x0)[NO],
                                             int (&tc)[NO]) {
@@ -156,7 +221,7 @@ __device__ __forceinline__ void tile_origin(int tile, const TileGeom<NO>& tg, in
     for (int d = 0; d < NO; ++d) {
         tc[d] = tile % tg.nt[d];
         tile /= tg.nt[d];
-        x0[d] = tc[d] * TileDims<NO>::T[d];
+        x0[d] = (tc[d] + (d == NO - 1 ? tg.tz0 : 0)) * TileDims<NO>::T[d];
     }
 }
 
@@ -301,8 +366,10 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
             for (int u = 0; u < kCU; ++u) {
                 int ref0[NO];
                 T dlo[NO];
-                if (ref_and_deltas<T, NI, NO>(pt[u], ps, gd, ref0, dlo) && live[u])
-                    atomicAdd(&hist[primary_tile<NO>(ref0, tg)], 1u);
+                if (ref_and_deltas<T, NI, NO>(pt[u], ps, gd, ref0, dlo) && live[u]) {
+                    const int tl = primary_tile<NO>(ref0, tg);
+                    if (tl >= 0) atomicAdd(&hist[tl], 1u);
+                }
             }
         }
     } else {
@@ -324,8 +391,10 @@ __global__ __launch_bounds__(kBinThreads) void k_count(GridDesc<NO> gd, TileGeom
                 for (int k = 0; k < kPB; ++k) {
                     int ref0[NO];
                     T dlo[NO];
-                    if (ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && live[k])
-                        atomicAdd(&hist[j * tg.NT + primary_tile<NO>(ref0, tg)], 1u);
+                    if (ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && live[k]) {
+                        const int tl = primary_tile<NO>(ref0, tg);
+                        if (tl >= 0) atomicAdd(&hist[j * tg.NT + tl], 1u);
+                    }
                 }
             }
         }
@@ -815,9 +884,11 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
         }
         int ref0[NO];
         T dlo[NO];
-        const bool valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        bool valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
+        const int tl = valid ? primary_tile<NO>(ref0, tg) : -1;
+        valid = tl >= 0;  // (a point of another slab is no point of this launch)
         uint32_t pos = (uint32_t)P;  // spare slot
-        if (valid) pos = atomicAdd(&cursor[primary_tile<NO>(ref0, tg)], 1u);
+        if (valid) pos = atomicAdd(&cursor[tl], 1u);
         if (HAS_PW && valid) max_w = abs_bits(w) > max_w ? abs_bits(w) : max_w;
         Rec4<T> r;
 #pragma unroll
@@ -933,8 +1004,9 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
                 const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
                 int ref0[NO];
                 T dlo[NO];
-                const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
+                bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
                 tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+                valid = tile[k] >= 0;
                 lrank[k] = 0;
                 if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
                 if (HAS_PW && valid) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
@@ -1095,8 +1167,9 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
             const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
             int ref0[NO];
             T dlo[NO];
-            const bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && lp < nloc;
+            bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && lp < nloc;
             tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
+            valid = tile[k] >= 0;
             lrank[k] = 0;
             if (HAS_PW && valid && jp == 0) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
             unsigned long long todo = __ballot(valid);
@@ -1594,6 +1667,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     const double bgv = bg ? (double)bg[b] : 0.0;
     T* o = out + b * gd.G;
     T* hb = halo + (size_t)item.tile * halo_count<NO>();
+    const bool ghost_tile = tg.ghost && tc[NO - 1] == 0;  // (only its upper halo is wanted)
     const int lane = threadIdx.x & (kWave - 1);
     const int x = lane % TX;
     const bool x_ok = x0[0] + x < gd.n[0];
@@ -1607,7 +1681,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
         if (owned) {
             const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
             const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
-            if (in && x_ok)
+            if (in && x_ok && !ghost_tile)
                 __builtin_nontemporal_store(
                     (T)(bgv + a),
                     &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
@@ -1740,6 +1814,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
     const double bgv = bg ? (double)bg[b] : 0.0;
     T* o = out + b * gd.G;
     T* hb = halo + (size_t)item.tile * halo_count<NO>();
+    const bool ghost_tile = tg.ghost && tc[NO - 1] == 0;  // (only its upper halo is wanted)
     const int lane = threadIdx.x & (kWave - 1);
     const int x = lane % TX;
     const bool x_ok = x0[0] + x < gd.n[0];
@@ -1753,7 +1828,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
         if (owned) {
             const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
             const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
-            if (in && x_ok)
+            if (in && x_ok && !ghost_tile)
                 __builtin_nontemporal_store(
                     (T)(bgv + a),
                     &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
@@ -1836,6 +1911,7 @@ __device__ __forceinline__ void halo_gather_tile(const GridDesc<NO>& gd, const T
     const int i_step = split ? 256 * CH : 256;
     int x0[NO], tc[NO];
     tile_origin<NO>(tile, tg, x0, tc);
+    if (tg.ghost && tc[NO - 1] == 0) return;  // a ghost tile owns nothing in this launch
     T* o = out + b * gd.G;
     // The 2^N - 1 lower neighbours (combination m: bit d = one tile down along axis d): which exist,
     // which are split tiles and where their slabs start is block-uniform and fetched ONCE, up
@@ -2712,6 +2788,7 @@ template <typename T> struct PoseReduceArgs {
     T* ds_dout_weight;
     T* loss;
     BinHeader* hdr;
+    int accumulate;  // 1: add to the outputs (a later slab of the same pose)
 };
 template <typename T>
 __device__ __forceinline__ void pose_reduce_body(int k, uint32_t j, bool grouped,
@@ -2738,16 +2815,18 @@ __device__ __forceinline__ void pose_reduce_body(int k, uint32_t j, bool grouped
         for (int w = 0; w < 16; ++w) tot += wsum[w];
         if (stale) tot = __builtin_nan("");
         const int nr = a.n_out * a.n_in;
+        T* dst = nullptr;
         if (k < nr)
-            a.ds_drotation[b * nr + k] = (T)tot;
+            dst = &a.ds_drotation[b * nr + k];
         else if (k < nr + a.n_out)
-            a.ds_dtranslation[b * a.n_out + (k - nr)] = (T)tot;
+            dst = &a.ds_dtranslation[b * a.n_out + (k - nr)];
         else if (k == nr + a.n_out)
-            a.ds_dout_weight[b] = (T)tot;
+            dst = &a.ds_dout_weight[b];
         else if (k == nr + a.n_out + 1)
-            a.ds_dbackground[b] = (T)tot;
+            dst = &a.ds_dbackground[b];
         else if (a.loss)
-            a.loss[b] = (T)tot;
+            dst = &a.loss[b];
+        if (dst) *dst = a.accumulate ? (T)((double)*dst + tot) : (T)tot;
     }
 }
 
@@ -2977,8 +3056,10 @@ static int pose_group(int NT, int64_t P, int64_t B, int max_group) {
 }
 
 static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group,
-                      bool coherent = false, int n_in = 3, bool share_batch = false) {
+                      bool coherent = false, int n_in = 3, bool share_batch = false,
+                      bool slabbed = false) {
     Plan pl;
+    if (slabbed) coherent = false;  // local binning keeps a batch's bins: one slab at a time cannot
     share_batch = share_batch && B > 1;
     if (share_batch) max_group = 1;  // a kept binning is per pose
     pl.pose_stride = 0;
@@ -2989,7 +3070,8 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     // grouped pipeline, which reads the points once per group (10 M points -> 512^2, 4 poses:
     // 0.56 ms grouped, 0.63 ms pose by pose on local bins)
     pl.bg = pose_group(NT1, P1, B, max_group);
-    pl.local = (coherent || pl.sort_inside) && NT1 <= kMaxLocalTiles && knobs().bwd_unpermute && pl.bg == 1;
+    pl.local = (coherent || pl.sort_inside) && !slabbed && NT1 <= kMaxLocalTiles &&
+               knobs().bwd_unpermute && pl.bg == 1;
     // poses binned by one k_bin_local launch (the points are read once for all of them): every
     // pose of a kept batch, else up to 8 -- each needs its own records, P * lb <= 2^29
     pl.lb = 1;
@@ -3149,28 +3231,35 @@ static uint32_t plan_layout_id(const Plan& pl) {
     return id ? id : 1u;
 }
 
+static bool grid_cut(int n_out, const int64_t* grid, SlabCut* sc) {
+    return n_out == 3 ? make_slab_cut<3>(grid, sc) : make_slab_cut<2>(grid, sc);
+}
+
 bool tiled_supported(int n_out, const int64_t* grid) {
-    if (n_out == 3) {
-        TileGeom<3> tg;
-        return make_geom<3>(grid, &tg);
-    }
-    TileGeom<2> tg;
-    return make_geom<2>(grid, &tg);
+    SlabCut sc;
+    return grid_cut(n_out, grid, &sc);
+}
+
+// slabs the tiled path cuts the grid into (1: one piece; 0: not supported)
+int tiled_slabs(int n_out, const int64_t* grid) {
+    SlabCut sc;
+    return grid_cut(n_out, grid, &sc) ? sc.nslab : 0;
 }
 
 bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B, int64_t G) {
     (void)G;
     if (P >= (int64_t)1 << 32) return false;
-    int NT;
-    if (n_out == 3) {
-        TileGeom<3> tg;
-        if (!make_geom<3>(grid, &tg)) return false;
-        NT = tg.NT;
-    } else {
-        TileGeom<2> tg;
-        if (!make_geom<2>(grid, &tg)) return false;
-        NT = tg.NT;
+    SlabCut sc;
+    if (!grid_cut(n_out, grid, &sc)) return false;
+    if (sc.nslab > 1) {
+        // More than 32768 tiles (e.g. 1024^3): every slab re-reads the cloud, and the tile kernels
+        // write the whole grid -- which the direct path's background fill does as well.  Forward:
+        // the LDS tiles beat scattered global atomics from ~1e6 points on (1e7 points -> 1024^3:
+        // measured in profiles/r04_experiments.md); the pullback's gathers are reads, the direct
+        // kernel keeps them.
+        return op == DPR_OP_RASTER && P >= 1000000;
     }
+    const int NT = sc.per_layer * sc.layers;
     // Measured crossovers (profiles/r01_algo_sweep.txt: one pose; r01_algo_sweep_batched.txt:
     // 4-64 poses; 64^3 ... 256^3 and 128^2 / 512^2 grids).  One pose: the tiled pipeline's fixed
     // cost (6-7 launches) is repaid from ~2-3e5 points on, forward and backward alike.  Batched
@@ -3187,52 +3276,35 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
     return P >= 250000;
 }
 
-// tiles per pose of the tiled path's geometry (-1: more than it supports)
+// tiles per pose of the tiled path's geometry (of its largest slab; -1: not supported)
 int tiled_tiles(int n_out, const int64_t* grid) {
-    if (n_out == 3) {
-        TileGeom<3> tg;
-        return make_geom<3>(grid, &tg) ? tg.NT : -1;
-    }
-    TileGeom<2> tg;
-    return make_geom<2>(grid, &tg) ? tg.NT : -1;
+    SlabCut sc;
+    return grid_cut(n_out, grid, &sc) ? slab_max_tiles(sc) : -1;
 }
 
 // May a KEEP_BINNING / REUSE_BINNING pair with B > 1 poses share on the tiled path when
 // DPR_ALGO_AUTO decides?  Every pose then keeps its own records (Plan::pose_stride): only where
 // pose groups are not an option anyway (more than 2048 tiles per pose) and the kept records stay
-// below ~21 GB at fp64, ~13 GB at fp32 (P * B <= 2^29: a 4-word record, a slot and an index per point and pose; independent of the element type, so that dpr_resolve_algo_ex needs
-// none).  An explicit DPR_ALGO_TILED shares for any B.
+// below ~21 GB at fp64, ~13 GB at fp32 (P * B <= 2^29: a 4-word record, a slot and an index per
+// point and pose; independent of the element type, so that dpr_resolve_algo_ex needs none).  An
+// explicit DPR_ALGO_TILED shares for any B.  Never on a grid that is processed in slabs (a slab's
+// binning is overwritten by the next one).
 bool tiled_batch_share_ok(int n_out, const int64_t* grid, int64_t P, int64_t B) {
     if (B < 2 || P < 1 || P * B > ((int64_t)1 << 29)) return false;
-    int NT;
-    if (n_out == 3) {
-        TileGeom<3> tg;
-        if (!make_geom<3>(grid, &tg)) return false;
-        NT = tg.NT;
-    } else {
-        TileGeom<2> tg;
-        if (!make_geom<2>(grid, &tg)) return false;
-        NT = tg.NT;
-    }
-    return NT * 2 > 4096;
+    SlabCut sc;
+    if (!grid_cut(n_out, grid, &sc) || sc.nslab != 1) return false;
+    return sc.per_layer * sc.layers * 2 > 4096;
 }
 
 size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int n_out,
                              const int64_t* grid, int64_t P, int64_t B) {
     (void)op;
     if (P >= (int64_t)1 << 32) return (size_t)-1;  // refused by raster_tiled / pullback_tiled
-    int NT;
-    if (n_out == 3) {
-        TileGeom<3> tg;
-        if (!make_geom<3>(grid, &tg)) return (size_t)-1;
-        NT = tg.NT;
-    } else {
-        TileGeom<2> tg;
-        if (!make_geom<2>(grid, &tg)) return (size_t)-1;
-        NT = tg.NT;
-    }
-    return make_plan(elem, n_out, NT, P, B, (int)((flags >> 8) & 0xffu),
-                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in, (flags & 3u) != 0).total;
+    SlabCut sc;
+    if (!grid_cut(n_out, grid, &sc)) return (size_t)-1;
+    if (sc.nslab > 1 && (flags & 3u)) return (size_t)-1;
+    return make_plan(elem, n_out, slab_max_tiles(sc), P, B, (int)((flags >> 8) & 0xffu),
+                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in, (flags & 3u) != 0, sc.nslab > 1).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -3499,16 +3571,22 @@ template <typename T, int NI, int NO>
 int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
                  int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
                  const T* ow, const T* pw, void* ws_, size_t ws_bytes) {
-    TileGeom<NO> tg;
-    if (!make_geom<NO>(grid, &tg))
-        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
-                    kMaxTiles);
+    SlabCut sc;
+    if (!make_slab_cut<NO>(grid, &sc))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO,
+                    "DPR_ALGO_TILED: a tile layer of the grid has more than %d tiles", kMaxTiles / 2);
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
+    if (sc.nslab > 1 && (flags & 3u))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO,
+                    "DPR_ALGO_TILED: a grid of more than %d tiles is processed in slabs, whose "
+                    "binning cannot be kept (DPR_FLAG_KEEP_BINNING)", kMaxTiles);
+    const int NTmax = slab_max_tiles(sc);
     const bool keep = flags & DPR_FLAG_KEEP_BINNING;
     // KEEP_BINNING with B > 1: every pose keeps its own binning (Plan::pose_stride)
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
-                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0);
+    const Plan pl = make_plan(sizeof(T), NO, NTmax, P, B, (int)((flags >> 8) & 0xffu),
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0,
+                              sc.nslab > 1);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
@@ -3528,7 +3606,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     }
     T* halo = (T*)(ws + pl.off_aux);
     T* ovf = (T*)(ws + pl.off_aux +
-                  align_up((size_t)tg.NT * pl.bg * halo_count<NO>() * sizeof(T)));
+                  align_up((size_t)NTmax * pl.bg * halo_count<NO>() * sizeof(T)));
     const int blocked = knobs().splat_blocked;
     // copy of the per-pose workspace pose b lives in: its own when the binning is kept, else its
     // place in the local batch
@@ -3538,6 +3616,10 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
         // per-pose part of the workspace (one copy, or one per pose when the binning is kept)
         char* const wsb = ws + (size_t)copy_of(b) * pl.pose_stride;
         char* const ws0 = pl.local ? ws + (size_t)copy_of(b - b % pl.lb) * pl.pose_stride : wsb;  // copy 0 of the local batch
+        // slabs of a grid beyond kMaxTiles tiles, bottom to top (one iteration otherwise): slab s + 1
+        // re-bins the top layer of slab s as its ghost layer
+        for (int slab = 0; slab < sc.nslab; ++slab) {
+        const TileGeom<NO> tg = slab_geom<NO>(grid, sc, slab, true);
         if (pl.local) {
             if (b % pl.lb == 0) {  // first pose of a local batch: bin all its poses
                 const int nlb = (int)((B - b < pl.lb) ? B - b : pl.lb);
@@ -3588,6 +3670,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                            (const uint32_t*)(wsb + pl.off_split) + 1,
                            (const uint32_t*)(wsb + pl.off_split), bg, b, (int)nb, out);
         stage_mark(st);
+        }  // slabs
     }
     DPR_HIP(hipGetLastError());
     return DPR_OK;
@@ -3598,15 +3681,21 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                    int64_t B, const T* g, const T* points, const T* rot, const T* trans,
                    const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
                    T* d_pw, void* ws_, size_t ws_bytes, Residual<T> rs) {
-    TileGeom<NO> tg;
-    if (!make_geom<NO>(grid, &tg))
-        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: grid needs more than %d tiles",
-                    kMaxTiles);
+    SlabCut sc;
+    if (!make_slab_cut<NO>(grid, &sc))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO,
+                    "DPR_ALGO_TILED: a tile layer of the grid has more than %d tiles", kMaxTiles / 2);
     if (P >= (int64_t)1 << 32)
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_TILED: P must be < 2^32");
+    if (sc.nslab > 1 && (flags & 3u))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO,
+                    "DPR_ALGO_TILED: a grid of more than %d tiles is processed in slabs, whose "
+                    "binning cannot be kept (DPR_FLAG_REUSE_BINNING)", kMaxTiles);
+    const int NTmax = slab_max_tiles(sc);
     const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
-    const Plan pl = make_plan(sizeof(T), NO, tg.NT, P, B, (int)((flags >> 8) & 0xffu),
-                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0);
+    const Plan pl = make_plan(sizeof(T), NO, NTmax, P, B, (int)((flags >> 8) & 0xffu),
+                              (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0,
+                              sc.nslab > 1);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE,
                     "DPR_ALGO_TILED pullback needs %zu workspace bytes, got %zu", pl.total,
@@ -3650,6 +3739,11 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         for (nb = 1; nb * 2 <= pl.bg && b + nb * 2 <= B;) nb *= 2;  // poses of this group
         // per-pose part of the workspace (one copy, or one per pose when the binning was kept)
         char* const wsb = ws + (size_t)copy_of(b) * pl.pose_stride;
+        // slabs of a grid beyond kMaxTiles tiles (one iteration otherwise): every slab bins the
+        // cloud again, gathers its tiles, and ADDS its share of the point gradients and per-pose sums
+        for (int slab = 0; slab < sc.nslab; ++slab) {
+        const TileGeom<NO> tg = slab_geom<NO>(grid, sc, slab, false);
+        const bool first_acc = b == 0 && slab == 0;  // the pass that overwrites ds_dpoints / ds_dpoint_weight
         BinHeader* hdr = reuse ? (BinHeader*)(wsb + pl.off_hdr) : (BinHeader*)nullptr;
         PoseReduceArgs<T> pr;
         pr.partials = partials;
@@ -3666,6 +3760,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         pr.ds_dout_weight = d_ow;
         pr.loss = rs.target ? rs.loss : nullptr;
         pr.hdr = hdr;
+        pr.accumulate = slab > 0 ? 1 : 0;
         const unsigned n_reduce = (unsigned)(rs.target ? NVAL + 1 : NVAL);
         bool reduced = false;
         // a pose group always goes through the gradient records (several (pose, tile) blocks
@@ -3688,7 +3783,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                 const int nlb = (int)((B - b < pl.lb) ? B - b : pl.lb);
                 if (int rc = bin_points_local<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans,
                                                          b, nlb, true, d_pts, d_pw,
-                                                         (b == 0 && !unperm) ? 1 : 0, false,
+                                                         (first_acc && !unperm) ? 1 : 0, false,
                                                          user_points, user_pw))
                     return rc;
             } else {
@@ -3698,7 +3793,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             }
         } else if (int rc = bin_points<T, NI, NO>(st, gd, tg, pl, wsb, P, points, pw, rot, trans, b,
                                                   (int)nb, true, d_pts, d_pw,
-                                                  (b == 0 && !unperm) ? 1 : 0, false, user_points,
+                                                  (first_acc && !unperm) ? 1 : 0, false, user_points,
                                                   user_pw))
             return rc;
 #define DPR_LAUNCH_GATHER_RUNS(HAS_PW, FIRST, UNP)                                               \
@@ -3736,11 +3831,11 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                 if (batch_unperm) {
                     // a kept batch: the records of all poses are summed once, after the loop
                 } else if (nb > 1) {
-                    if (b == 0) DPR_LAUNCH_UNPERM(true, 1, 0);
+                    if (first_acc) DPR_LAUNCH_UNPERM(true, 1, 0);
                     else DPR_LAUNCH_UNPERM(false, 1, 0);
                 } else {
                     // one pose: the per-pose reduction rides in the same launch
-                    if (b == 0) DPR_LAUNCH_UNPERM(true, DPR_UPB, n_reduce);
+                    if (first_acc) DPR_LAUNCH_UNPERM(true, DPR_UPB, n_reduce);
                     else DPR_LAUNCH_UNPERM(false, DPR_UPB, n_reduce);
                     reduced = true;
                 }
@@ -3764,6 +3859,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             hipLaunchKernelGGL((k_pose_reduce<T>), dim3(n_reduce, (unsigned)nb), dim3(1024), 0, st,
                                pr);
         stage_mark(st);
+        }  // slabs
         if (batch_unperm && ((b + 1) % ub == 0 || b + 1 == B)) {
             // the gradient records of the batch that ends with pose b: summed per point in one pass
             const int64_t bs = b - b % ub;  // first pose of the batch

@@ -176,8 +176,14 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3, sharing=True) == "chunked"
     # pre-sorted clouds skip the sort: the chunk-owner path pays off from a single pose on
     assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 1, 3, coherent_points=True) == "chunked"
-    # more tiles than the tiled path supports -> direct kernels
-    assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "atomic"
+    # more than 32768 tiles: the tiled path works in slabs -- the forward from 1e6 points on, the
+    # pullback stays with the direct kernel; a tile layer beyond 16384 tiles -> direct kernels
+    assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 500_000, 1, 3) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (4096, 4096, 64), 10_000_000, 1, 3) == "atomic"
+    assert dpr_amd.resolve_algo("raster", (8192, 4096, 32), 10_000_000, 1, 3) == "atomic"
+    # ... and a sharing pair there drops its flags (a slab's binning is not kept)
+    assert not dpr_amd.sharing_effective((1024,) * 3, 10_000_000, 1, 3)
     assert dpr_amd.workspace_bytes("raster", (8, 8), 100, 1, 2, torch.float64, "atomic") == 0
     small = dpr_amd.workspace_bytes("raster", (256,) * 3, 1_000_000, 1, 3, torch.float32, "tiled")
     big = dpr_amd.workspace_bytes("raster", (256,) * 3, 10_000_000, 1, 3, torch.float32, "tiled")
@@ -222,8 +228,15 @@ def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
     # a workspace query for a call that TILED would refuse fails too
     wsq = getattr(L, f"dpr_workspace_bytes_{suf}")
     assert wsq(0, dpr_amd._lib.ALGO_TILED, 3, 3, gp, 1 << 32, 1) == ctypes.c_size_t(-1).value
+    # more than 32768 tiles: processed in slabs of tile layers (supported, no binning to keep);
+    # a single tile LAYER beyond 16384 tiles is not
     big = np.array([4096, 4096, 64], dtype=np.int64)
-    assert wsq(0, dpr_amd._lib.ALGO_TILED, 3, 3, big.ctypes.data_as(ctypes.c_void_p), 1000, 1) == ctypes.c_size_t(-1).value
+    bigp = big.ctypes.data_as(ctypes.c_void_p)
+    assert 0 < wsq(0, dpr_amd._lib.ALGO_TILED, 3, 3, bigp, 1000, 1) < ctypes.c_size_t(-1).value
+    assert getattr(L, f"dpr_workspace_bytes_ex_{suf}")(
+        0, dpr_amd._lib.ALGO_TILED, dpr_amd._lib.FLAG_KEEP_BINNING, 3, 3, bigp, 1000, 1) == ctypes.c_size_t(-1).value
+    huge = np.array([8192, 4096, 32], dtype=np.int64)
+    assert wsq(0, dpr_amd._lib.ALGO_TILED, 3, 3, huge.ctypes.data_as(ctypes.c_void_p), 1000, 1) == ctypes.c_size_t(-1).value
     # pose-group cap: smaller workspace, same call otherwise
     wsx = getattr(L, f"dpr_workspace_bytes_ex_{suf}")
     g2 = np.array([512, 512], dtype=np.int64)

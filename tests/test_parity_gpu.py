@@ -1165,3 +1165,105 @@ def test_autograd_rule_with_mixed_dtypes_and_strided_views(dev):
                                   None, pw32.detach().double().contiguous())
     assert_close(pts32.grad, pb.points.float().cpu().numpy(), 1e-6, "points.grad")
     assert_close(R.grad, pb.rotation.cpu().numpy(), 1e-9, "rotation.grad")
+
+
+# ------------------------------------------------------------------ grids beyond 32768 tiles: slabs
+def _assert_close_on_device(a, e, rtol, what):
+    """norm-wise comparison of two large device tensors without float64 copies on the host"""
+    err2 = na2 = ne2 = 0.0
+    af, ef = a.reshape(-1), e.reshape(-1)
+    step = 1 << 26
+    for i in range(0, af.numel(), step):
+        x, y = af[i:i + step].double(), ef[i:i + step].double()
+        err2 += float(((x - y) ** 2).sum())
+        na2 += float((x * x).sum())
+        ne2 += float((y * y).sum())
+    assert err2 ** 0.5 <= rtol * max(na2, ne2) ** 0.5, f"{what}: |a-e|={err2 ** 0.5:.3e} vs {max(na2, ne2) ** 0.5:.3e}"
+
+
+_SLAB_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import dpr_amd
+from oracle import oracle
+from tests import data as D
+from tests.test_parity_gpu import T, assert_close, grid_to_dev, tol
+dev = torch.device("cuda:0")
+cases = [(3, 3, (100, 40, 90), 3), (3, 3, (64, 64, 200), 1), (2, 2, (300, 400), 2), (3, 2, (260, 500), 3)]
+for npdt in (np.float64, np.float32):
+    for n_in, n_out, grid, B in cases:
+        d = D.make(n_points=60_000, n_in=n_in, n_out=n_out, batch=B, grid_n=grid, seed=21, dtype=npdt)
+        d.points[:30_000] *= 0.05     # a dense blob: tiles above the split threshold (4096 records)
+        d.points[:, n_in - 1] *= 2.0  # spread along the slab axis (some points leave the grid)
+        ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                            d.point_weights, dtype=npdt)
+        rp = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                    d.point_weights, dtype=npdt)
+        args = [T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+                T(d.weights, dev), T(d.point_weights, dev)]
+        for coherent in (False, True):
+            out = dpr_amd.raster(d.grid, *args, algo="tiled", coherent_points=coherent)
+            assert_close(out, ref, tol(npdt, "out"), f"out {grid} {npdt.__name__}")
+            pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), *args, algo="tiled",
+                                          coherent_points=coherent)
+            for name, kind in (("points", "points"), ("point_weight", "points"), ("rotation", "pose"),
+                               ("translation", "pose"), ("background", "pose"), ("out_weight", "pose")):
+                assert_close(getattr(pb, name), getattr(rp, name), tol(npdt, kind), f"{name} {grid}")
+print("SLABS_OK")
+"""
+
+
+def test_tiled_on_grids_processed_in_slabs(dev):
+    """More than kMaxTiles tiles: the tiled path walks slabs of tile layers along the last axis
+    (forward: each slab re-bins the top layer of the slab below as a ghost layer for its halo;
+    pullback: the slabs add up point gradients and per-pose sums).  With DPR_MAX_TILES=24 (read
+    once per process, hence the child process) small grids are cut into 3-13 slabs: forward +
+    pullback against the oracle in both element types, batches, a split tile, the coherent flag."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    env = dict(os.environ, DPR_MAX_TILES="24")
+    r = subprocess.run([sys.executable, "-c", _SLAB_SCRIPT, ROOT], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "SLABS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("n_in,n_out,grid", [(2, 2, (8192, 4100)), (3, 2, (8192, 4100))])
+def test_tiled_on_a_2d_grid_of_more_than_32768_tiles(oracle, dev, n_in, n_out, grid):
+    """256 x 129 = 33 024 tiles of 32 x 32 pixels: two slabs at the library's own bound."""
+    npdt = np.float32
+    d = D.make(n_points=300_000, n_in=n_in, n_out=n_out, batch=2, grid_n=grid, seed=21, dtype=npdt)
+    d.points[:, n_in - 1] *= 2.2  # spread along the slab axis
+    ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, d.backgrounds, d.weights,
+                        d.point_weights, dtype=npdt)
+    out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev),
+                         T(d.backgrounds, dev), T(d.weights, dev), T(d.point_weights, dev), algo="tiled")
+    _assert_close_on_device(out, grid_to_dev(ref, dev), tol(npdt, "out"), "out")
+    rp = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights,
+                                d.point_weights, dtype=npdt)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), T(d.points, dev), T(d.rotations, dev),
+                                  T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev),
+                                  T(d.point_weights, dev), algo="tiled")
+    assert_close(pb.points, rp.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.rotation, rp.rotation, tol(npdt, "pose"), "ds_drotation")
+    assert_close(pb.background, rp.background, tol(npdt, "pose"), "ds_dbackground")
+
+
+def test_1024_cube_fp32_forward_auto_is_tiled_and_matches_the_oracle(oracle, dev):
+    """The reference README's largest grid (README.md:193: 1024^3): 131 072 tiles, four slabs.
+    AUTO takes the tiled path for the forward from 10^6 points on (10^7 -> 1024^3 as well); 10^6
+    points against the oracle, compared on the device (4.3 GB per grid)."""
+    n, P = 1024, 1_000_000
+    assert dpr_amd.resolve_algo("raster", (n, n, n), P, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (n, n, n), 10_000_000, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (n, n, n), 100_000, 1, 3) == "atomic"   # README row: 1e5 points
+    d = D.make(n_points=P, n_in=3, n_out=3, batch=1, grid_n=n, seed=22, dtype=np.float32)
+    ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, None, d.weights, dtype=np.float32,
+                        threaded=True)
+    out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), None,
+                         T(d.weights, dev))
+    _assert_close_on_device(out, grid_to_dev(ref, dev), 5e-5, "out (1024^3)")
