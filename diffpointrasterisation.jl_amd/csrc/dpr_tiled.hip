@@ -720,7 +720,6 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
         // per thread (lane-adjacent records would hit the same voxel and same-address LDS
         // atomics serialise).  88 vs 94 us for the random order at C3.
         n_items[1] = ((uint64_t)s_nzsum * 8 >= (uint64_t)nblk * (uint64_t)NT) ? 0u : 1u;
-        n_items[2] = 0u;  // max |point_weight| bits, published by the scatter that follows
     }
     uint32_t wbase = 0, sbase = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) {
@@ -776,7 +775,10 @@ __device__ __forceinline__ void tilescan_body(const uint32_t* __restrict__ total
 #endif
 constexpr int kScanTiles = DPR_SCAN_TILES, kScanGroups = 1024 / DPR_SCAN_TILES;
 __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts, int nblk, int NT,
-                                                  uint32_t* __restrict__ totals) {
+                                                  uint32_t* __restrict__ totals,
+                                                  uint32_t* __restrict__ zero_word = nullptr) {
+    // (max |point_weight| bits: published by the scatter that follows with atomicMax)
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
     // A thread owns `rows` consecutive rows of one column.  Its loads are issued kRowBatch at a
     // time (one row per iteration was a chain of 2 x rows dependent round trips: 9.2 us for the
     // 512 x 2048 table of C3, 16 rows per thread); when the rows fit one batch -- up to 512 count
@@ -920,7 +922,20 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
     int nb, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ tile_start,
     RecT<T, W3>* __restrict__ rec, uint32_t* __restrict__ slot_of, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, int zero_dropped, uint32_t* __restrict__ maxpw) {
+    T* __restrict__ ds_dpw, int zero_dropped, uint32_t* __restrict__ maxpw, int fused_scan,
+    TileScanArgs ts) {
+    // fused_scan: the tile scan (tile offsets for later kernels, work list, binning header) runs
+    // as ONE EXTRA workgroup of this launch instead of a launch of its own between the column scan
+    // and the scatter -- nothing in the scatter depends on its results: every scatter workgroup
+    // scans the 2048-4096 tile totals itself in its prologue (~1 us, under its first point
+    // loads).  One dependent launch and its gap less per binning (C3: scan stage 14 -> 7 us).
+    const unsigned n_slices = fused_scan ? gridDim.x - 1u : gridDim.x;
+    if (fused_scan && blockIdx.x == n_slices) {
+        tilescan_body(ts.totals, ts.NT, ts.cap, ts.tile_start, ts.items, ts.n_items, ts.tile_parts,
+                      ts.tile_slab, ts.split_list, ts.n_split, ts.hdr, ts.hdr_out, ts.rot,
+                      ts.rot_words, ts.trans, ts.trans_words, ts.nonzero_bins, ts.nblk);
+        return;
+    }
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kWcThreads;  // points per thread per sub-chunk
     uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of k_tile_splat's fixed point)
@@ -939,18 +954,50 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
     // in between), and dest[] is dead after the write-out of the previous round (barrier)
     uint32_t* const wsum = dest;
     static_assert(S >= kWcThreads / kWave, "wave sums fit");
-    const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
+    const unsigned slice = xcd_slice(blockIdx.x, n_slices);
     const uint32_t* row = prefix + (size_t)slice * NTe;
-    for (int i = threadIdx.x; i < NTe; i += kWcThreads) cursor[i] = tile_start[i] + row[i];
+    constexpr int kMaxBpt = 4096 / kWcThreads;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (fused_scan) {
+        // exclusive scan of the tile totals (= tile_start, which the extra workgroup is writing for
+        // the kernels downstream at this very moment) + this slice's column prefix
+        const int bpe = (NTe + kWcThreads - 1) / kWcThreads;  // <= 4
+        const int e0 = threadIdx.x * bpe;
+        uint32_t c[kMaxBpt], rw[kMaxBpt], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kMaxBpt; ++q) {
+            const int i = e0 + q;
+            const bool in = q < bpe && i < NTe;
+            c[q] = in ? ts.totals[i] : 0u;
+            rw[q] = in ? row[i] : 0u;
+            sum += c[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
+#pragma unroll
+        for (int q = 0; q < kMaxBpt; ++q) {
+            const int i = e0 + q;
+            if (q < bpe && i < NTe) cursor[i] = run + rw[q];
+            run += c[q];
+        }
+    } else {
+        for (int i = threadIdx.x; i < NTe; i += kWcThreads) cursor[i] = tile_start[i] + row[i];
+    }
     for (int i = threadIdx.x; i < NT; i += kWcThreads) lhist[i] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)slice * chunk;
     const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
     // bins owned by this thread in the scan / cursor update (NT <= 4096: at most 4)
-    constexpr int kMaxBpt = 4096 / kWcThreads;
     const int bpt = (NT + kWcThreads - 1) / kWcThreads;
     const int bin0 = threadIdx.x * bpt;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lo >= hi) return;
     // Single pose: the next sub-chunk's points are requested while the current one goes through
     // its LDS phases.  Pose groups load at the top of the round instead: the second register set
@@ -2979,7 +3026,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // (function-local static: thread-safe, no getenv on the call path) and clamped to valid ranges.
 struct Knobs {
     int cap3d_div, cap2d_div, cap_min, pose_group, scatter_wc, bwd_unpermute, compact_records,
-        splat_blocked, fixed_point;
+        splat_blocked, fixed_point, fuse_tilescan;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -2998,9 +3045,25 @@ static const Knobs& knobs() {
         q.compact_records = env_int("DPR_COMPACT_RECORDS", 1, 0, 1);
         q.splat_blocked = env_int("DPR_SPLAT_BLOCKED", 2, 0, 2);  // 2: decided on the device
         q.fixed_point = env_int("DPR_FIXED_POINT", 1, 0, 1);  // 0: f64 LDS accumulators for fp32 data too
+        q.fuse_tilescan = env_int("DPR_FUSE_TILESCAN", 1, 0, 1);  // 0: k_tilescan as a launch of its own
         return q;
     }();
     return k;
+}
+
+// compute units of the current device (cached)
+static int cu_count() {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
 }
 
 // Workspace layout (identical for raster and pullback so that a pullback can reuse the
@@ -3349,20 +3412,21 @@ template <typename T, int NI, int NO, bool HAS_PW, bool WANT_IDX>
 static int launch_scatter(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>& tg,
                           const Plan& pl, char* ws, int64_t P, const T* points, const T* pw,
                           const T* rot, const T* trans, int64_t b, int nb, T* d_pts, T* d_pw,
-                          int zero_dropped) {
+                          int zero_dropped, const TileScanArgs& ts, bool fused) {
     // write-combining variant: needs 2 NT counters + the sub-chunk in LDS, and does not
     // produce rec_idx (only the direct-store pullback mode with point weights reads that)
     if (scatter_is_wc(tg.NT, nb, HAS_PW, WANT_IDX)) {
         constexpr int S = (sizeof(T) == 4) ? DPR_WC_PPT * kWcThreads : DPR_WC_PPT * kWcThreads / 2;
         const size_t lds2 = (size_t)tg.NT * (nb + 1) * 4;
 #define DPR_LAUNCH_WC(GROUP, W3)                                                                  \
-    hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S, GROUP, W3>), dim3(pl.nblk),           \
+    hipLaunchKernelGGL((k_scatter_wc<T, NI, NO, HAS_PW, S, GROUP, W3>),                          \
+                       dim3(pl.nblk + (fused ? 1 : 0)),                                          \
                        dim3(kWcThreads), lds2, st, gd, tg, P, pl.chunk, points, pw, rot, trans, \
                        b, nb, (const uint32_t*)(ws + pl.off_counts),                             \
                        (const uint32_t*)(ws + pl.off_tile_start),                                \
                        (RecT<T, W3>*)(ws + pl.off_rec),                     \
                        WANT_IDX ? (uint32_t*)(ws + pl.off_slot) : (uint32_t*)nullptr, d_pts,     \
-                       d_pw, zero_dropped, (uint32_t*)(ws + pl.off_nitems) + 2)
+                       d_pw, zero_dropped, (uint32_t*)(ws + pl.off_nitems) + 2, fused ? 1 : 0, ts)
         if constexpr (!HAS_PW) {
             if (records_are_compact(tg.NT, nb, false, WANT_IDX)) {
                 if (nb > 1) DPR_LAUNCH_WC(true, true);
@@ -3439,26 +3503,30 @@ static int bin_points(hipStream_t st, const GridDesc<NO>& gd, const TileGeom<NO>
     ts.nonzero_bins = (const uint32_t*)(ws + pl.off_nzbins);
     ts.nblk = pl.nblk;
     hipLaunchKernelGGL(k_colscan, dim3((NTe + kScanTiles - 1) / kScanTiles), dim3(1024), 0, st,
-                       counts, pl.nblk, NTe, totals);
-    hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, ts);
+                       counts, pl.nblk, NTe, totals, (uint32_t*)(ws + pl.off_nitems) + 2);
+    // The tile scan rides in the scatter launch as one extra workgroup when the write-combining
+    // scatter runs (its workgroups scan the totals themselves) and a CU is left for it.
+    const bool fused = knobs().fuse_tilescan && scatter_is_wc(tg.NT, nb, pw != nullptr, want_idx) &&
+                       pl.nblk < cu_count();
+    if (!fused) hipLaunchKernelGGL(k_tilescan, dim3(1), dim3(1024), 0, st, ts);
     stage_mark(st);
     int rc;
     if (pw) {
         rc = want_idx ? launch_scatter<T, NI, NO, true, true>(st, gd, tg, pl, ws, P, points, pw,
                                                               rot, trans, b, nb, d_pts,
-                                                              d_pw, zero_dropped)
+                                                              d_pw, zero_dropped, ts, fused)
                       : launch_scatter<T, NI, NO, true, false>(st, gd, tg, pl, ws, P, points, pw,
                                                                rot, trans, b, nb, d_pts,
-                                                               d_pw, zero_dropped);
+                                                               d_pw, zero_dropped, ts, fused);
     } else {
         // without point weights the original index rides in the record for free; slot_of is
         // only written when a pullback will consume the binning
         rc = want_idx ? launch_scatter<T, NI, NO, false, true>(st, gd, tg, pl, ws, P, points, pw,
                                                                rot, trans, b, nb, d_pts,
-                                                               d_pw, zero_dropped)
+                                                               d_pw, zero_dropped, ts, fused)
                       : launch_scatter<T, NI, NO, false, false>(st, gd, tg, pl, ws, P, points, pw,
                                                                 rot, trans, b, nb, d_pts,
-                                                                d_pw, zero_dropped);
+                                                                d_pw, zero_dropped, ts, fused);
     }
     stage_mark(st);
     return rc;
