@@ -657,16 +657,21 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
                     }
                 }
             }
+            // The ACCUMULATIONS below are fused multiply-adds (explicit: the library is built with
+            // -ffp-contract=off): these sums run over neighbours, points and poses in an order the
+            // reference does not share anyway, so fusing changes nothing a parity statement rests on
+            // (cell choice and the per-neighbour weights stay in the reference's operation order) and
+            // takes ~25 of the ~150 vector instructions per (point, pose) out of a VALU-bound loop.
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const T gi = gq[s];
                 // src/raster_pullback.jl:51-60 (a dropped neighbour adds nothing: gi == 0)
                 const T dweight = voxel_weight<T, 2>(dlo, s, gi);
-                dow_part += dweight * pwi;
-                dpw_part += dweight * ps.ow;
+                dow_part = fma_t(dweight, pwi, dow_part);
+                dpw_part = fma_t(dweight, ps.ow, dpw_part);
                 const T factor = gi * ps.ow * pwi;
 #pragma unroll
-                for (int n = 0; n < 2; ++n) dcoord[n] += factor * interp_weight<T, 2>(n, dlo, s);
+                for (int n = 0; n < 2; ++n) dcoord[n] = fma_t(factor, interp_weight<T, 2>(n, dlo, s), dcoord[n]);
             }
             T scaled[2];
 #pragma unroll
@@ -674,13 +679,13 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) vals[n + j * 2] += scaled[n] * pt[k][j];  // :69
-                vals[2 * NI + n] += scaled[n];                                         // :68
+                for (int j = 0; j < NI; ++j) vals[n + j * 2] = fma_t(scaled[n], pt[k][j], vals[n + j * 2]);  // :69
+                vals[2 * NI + n] += scaled[n];                                                              // :68
             }
             vals[2 * NI + 2] += dow_part;
 #pragma unroll
             for (int j = 0; j < NI; ++j)  // rotation' * scaled (:70)
-                dp[k][j] += ps.R[0 + j * 2] * scaled[0] + ps.R[1 + j * 2] * scaled[1];
+                dp[k][j] = fma_t(ps.R[1 + j * 2], scaled[1], fma_t(ps.R[0 + j * 2], scaled[0], dp[k][j]));
             dpw[k] += dpw_part;
         }
         // per-pose sums: T within the thread (kCOPPT points), f64 across the block.  Every thread

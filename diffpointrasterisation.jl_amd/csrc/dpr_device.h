@@ -220,6 +220,11 @@ __device__ __forceinline__ void cell_add(double* cell, T v, const FixScale& fs) 
     if constexpr (FIX && sizeof(T) == 4) atomicAdd((unsigned long long*)cell, fix_bits((float)v, fs));
     else atomicAdd(cell, (double)v);
 }
+// explicit fused multiply-add (the library is compiled with -ffp-contract=off; see the call sites
+// for why a given sum may fuse)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // wave-level sum (all 64 lanes must call)
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
