@@ -1380,14 +1380,15 @@ struct RunScanArgs {
     int NT;
     uint32_t cap;
     int max_items;
+    int clear_cursors;  // 0: the cursors were cleared with the totals (fused with the placement)
     BinHeader hdr;
     const uint32_t* rot;  // pose b0 (words)
     int rot_words;
     const uint32_t* trans;
     int trans_words;
 };
-__global__ __launch_bounds__(1024) void k_runscan(RunScanArgs a) {
-    char* const wsp = a.ws + (size_t)blockIdx.x * a.pose_stride;
+__device__ __forceinline__ void runscan_body(const RunScanArgs& a, unsigned pose) {
+    char* const wsp = a.ws + (size_t)pose * a.pose_stride;
     const uint32_t* __restrict__ tile_ndesc = (const uint32_t*)(wsp + a.off_ltot);
     const uint32_t* __restrict__ tile_npts = tile_ndesc + a.NT;
     uint32_t* __restrict__ tile_dstart = (uint32_t*)(wsp + a.off_dstart);
@@ -1402,8 +1403,8 @@ __global__ __launch_bounds__(1024) void k_runscan(RunScanArgs a) {
     const BinHeader& hdr = a.hdr;
     const int NT = a.NT, max_items = a.max_items;
     const uint32_t cap = a.cap;
-    const uint32_t* rot = a.rot + (size_t)blockIdx.x * a.rot_words;
-    const uint32_t* trans = a.trans + (size_t)blockIdx.x * a.trans_words;
+    const uint32_t* rot = a.rot + (size_t)pose * a.rot_words;
+    const uint32_t* trans = a.trans + (size_t)pose * a.trans_words;
     const int rot_words = a.rot_words, trans_words = a.trans_words;
     if (threadIdx.x >= 1024 - 64) {  // binning header, as in the tile scan
         const int i = threadIdx.x - (1024 - 64);
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(1024) void k_runscan(RunScanArgs a) {
             if (i >= iend) continue;
             const uint32_t c = cc[u], nd = dd[u];
             tile_dstart[i] = run;
-            tile_cursor[i] = 0;
+            if (a.clear_cursors) tile_cursor[i] = 0;
             const uint32_t k = parts_of(c, nd);
             const uint32_t sz = (c + k - 1) / k;
             const uint32_t dsz = (nd + k - 1) / k;  // descriptors per part
@@ -1533,26 +1534,70 @@ __global__ __launch_bounds__(1024) void k_runscan(RunScanArgs a) {
     if (threadIdx.x == 0) *n_split = s_nsplit;
 }
 
+__global__ __launch_bounds__(1024) void k_runscan(RunScanArgs a) { runscan_body(a, blockIdx.x); }
+
 // local binning: K3 -- descriptors into tile order (any order inside a tile).  A wave per
 // sub-chunk slot; blockIdx.y = pose copy.
-__global__ __launch_bounds__(256) void k_place_desc(char* ws, size_t pose_stride, size_t off_desc,
-                                                    size_t off_bdesc, size_t off_dstart,
-                                                    size_t off_dcursor, size_t off_sdesc,
-                                                    int64_t nsub, int S) {
+// FUSED (grids of up to 4096 tiles): the run scan rides in this launch as ONE EXTRA workgroup per
+// pose (blockIdx.x == gridDim.x - 1) -- what the placement needs from it, the exclusive scan of
+// the per-tile descriptor counts, every workgroup computes itself in its prologue (as the
+// write-combining scatter does with the tile scan): one dependent launch and its gap less.
+// The cursors are then the caller's to clear (they sit behind the totals in `ltot`).
+__global__ __launch_bounds__(1024) void k_place_desc(char* ws, size_t pose_stride, size_t off_desc,
+                                                     size_t off_bdesc, size_t off_dstart,
+                                                     size_t off_dcursor, size_t off_sdesc,
+                                                     int64_t nsub, int S, int fused, RunScanArgs ra) {
+    __shared__ uint32_t s_dstart[4096];
+    __shared__ uint32_t wsum[16];
+    if (fused && blockIdx.x == gridDim.x - 1) {
+        runscan_body(ra, blockIdx.y);
+        return;
+    }
     char* const wsp = ws + (size_t)blockIdx.y * pose_stride;
     const RunDesc* __restrict__ desc = (const RunDesc*)(wsp + off_desc);
     const uint32_t* __restrict__ blk_ndesc = (const uint32_t*)(wsp + off_bdesc);
     const uint32_t* __restrict__ tile_dstart = (const uint32_t*)(wsp + off_dstart);
     uint32_t* __restrict__ tile_cursor = (uint32_t*)(wsp + off_dcursor);
     RunDesc* __restrict__ sorted = (RunDesc*)(wsp + off_sdesc);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave0 = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
-    const int64_t nwaves = (int64_t)gridDim.x * (256 / kWave);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (fused) {
+        // exclusive scan of tile_ndesc[NT] (NT <= 4096) into LDS
+        const uint32_t* __restrict__ tile_ndesc = (const uint32_t*)(wsp + ra.off_ltot);
+        const int NT = ra.NT;
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x * 4 + q;
+            c[q] = i < NT ? tile_ndesc[i] : 0u;
+            sum += c[q];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += v;
+        }
+        if (lane == kWave - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x * 4 + q;
+            if (i < NT) s_dstart[i] = run;
+            run += c[q];
+        }
+        __syncthreads();
+    }
+    const unsigned nblocks = fused ? gridDim.x - 1 : gridDim.x;
+    const int64_t wave0 = (int64_t)blockIdx.x * (1024 / kWave) + wave;
+    const int64_t nwaves = (int64_t)nblocks * (1024 / kWave);
     for (int64_t sub = wave0; sub < nsub; sub += nwaves) {
         const uint32_t n = blk_ndesc[sub] < (uint32_t)S ? blk_ndesc[sub] : (uint32_t)S;
         for (uint32_t i = lane; i < n; i += kWave) {
             const RunDesc d = desc[(size_t)sub * S + i];
-            sorted[tile_dstart[d.tile()] + atomicAdd(&tile_cursor[d.tile()], 1u)] = d;
+            const uint32_t base = fused ? s_dstart[d.tile()] : tile_dstart[d.tile()];
+            sorted[base + atomicAdd(&tile_cursor[d.tile()], 1u)] = d;
         }
     }
 }
@@ -3213,12 +3258,12 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     if (pl.local) {
         pl.max_desc = pl.nsub * pl.sub;  // every sub-chunk owns `sub` descriptor slots ...
         nrec = pl.nsub * pl.sub;         // ... and a slab of `sub` records
-        pl.off_ltot = o;
+        pl.off_ltot = o;  // (the cursors follow the totals directly: one clear covers both)
         o += align_up((size_t)(2 * NT1 + 2) * 4);
-        pl.off_dstart = o;
-        o += align_up((size_t)(NT1 + 1) * 4);
         pl.off_dcursor = o;
         o += align_up((size_t)NT1 * 4);
+        pl.off_dstart = o;
+        o += align_up((size_t)(NT1 + 1) * 4);
         pl.off_bdesc = o;
         o += align_up((size_t)pl.nsub * 4);
         pl.off_desc = o;
@@ -3559,7 +3604,8 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
         hdr_points = points;
         hdr_pw = pw;
     }
-    const size_t ltot_bytes = (size_t)(2 * tg.NT + 2) * 4;  // ndesc[NT] | npts[NT] | - | max|pw| bits
+    // ndesc[NT] | npts[NT] | - | max|pw| bits, and behind them the placement's cursors
+    const size_t ltot_bytes = (pl.off_dcursor - pl.off_ltot) + (size_t)tg.NT * 4;
     if (nb > 1)
         DPR_HIP(hipMemset2DAsync(ws + pl.off_ltot, pl.pose_stride, 0, ltot_bytes, (size_t)nb, st));
     else
@@ -3618,12 +3664,16 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     ra.rot_words = (int)(NO * NI * sizeof(T) / 4);
     ra.trans = (const uint32_t*)(trans + b * NO);
     ra.trans_words = (int)(NO * sizeof(T) / 4);
-    hipLaunchKernelGGL(k_runscan, dim3((unsigned)nb), dim3(1024), 0, st, ra);
-    int64_t pblocks = (pl.nsub + 3) / 4;  // a wave per sub-chunk slot
-    if (pblocks > 2048) pblocks = 2048;
-    hipLaunchKernelGGL(k_place_desc, dim3((unsigned)pblocks, (unsigned)nb), dim3(256), 0, st, ws,
-                       pl.pose_stride, pl.off_desc, pl.off_bdesc, pl.off_dstart, pl.off_dcursor,
-                       pl.off_sdesc, pl.nsub, pl.sub);
+    // the run scan rides in the placement launch when every placement workgroup can scan the
+    // descriptor counts itself (up to 4096 tiles)
+    const bool fused = knobs().fuse_tilescan && tg.NT <= 4096;
+    ra.clear_cursors = 0;  // (cleared with the totals above)
+    if (!fused) hipLaunchKernelGGL(k_runscan, dim3((unsigned)nb), dim3(1024), 0, st, ra);
+    int64_t pblocks = (pl.nsub + 15) / 16;  // a wave per sub-chunk slot, 16 waves per workgroup
+    if (pblocks > 1024) pblocks = 1024;
+    hipLaunchKernelGGL(k_place_desc, dim3((unsigned)pblocks + (fused ? 1u : 0u), (unsigned)nb), dim3(1024),
+                       0, st, ws, pl.pose_stride, pl.off_desc, pl.off_bdesc, pl.off_dstart,
+                       pl.off_dcursor, pl.off_sdesc, pl.nsub, pl.sub, fused ? 1 : 0, ra);
     stage_mark(st);
     return DPR_OK;
 }
