@@ -1847,16 +1847,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
             // cell-sorted, random inside its cell: no collisions to avoid).
             const uint32_t per = (n + kSplatThreads - 1) / kSplatThreads;
             const uint32_t step = blocked ? 1u : (uint32_t)kSplatThreads;
-            // (blocked: the shares of a wave's 64 lanes are 8 shares apart, not adjacent -- on a
-            // sorted cloud adjacent shares still lie within a few voxels of each other and their
-            // neighbourhoods collide on LDS addresses)
-#ifndef DPR_SPLAT_SPREAD
-#define DPR_SPLAT_SPREAD 1
-#endif
-            const uint32_t share = DPR_SPLAT_SPREAD
-                                       ? (threadIdx.x & (kWave - 1)) * (kSplatThreads / kWave) + threadIdx.x / kWave
-                                       : threadIdx.x;
-            uint32_t i = blocked ? share * per : threadIdx.x;
+            uint32_t i = blocked ? threadIdx.x * per : threadIdx.x;
             const uint32_t i1 = blocked ? ((i + per < n) ? i + per : n) : n;
             if (i < i1) {
                 RunCursor cu;
