@@ -1155,22 +1155,27 @@ constexpr int kTouchCap = 1024;
 // with their larger histograms run one workgroup per CU anyway)
 // ONE: a single pose (nb == 1) -- the points die after the placement instead of living across a pose
 // loop, which is what lets the fp32 kernel fit 64 VGPRs.
-template <typename T, int NI, int NO, bool HAS_PW, int S, bool W3, bool ONE>
-__global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_local(
+// TH / STAGE: 1024 threads that order the records in LDS and write them out as one coalesced run
+// (fp32: two 16-byte records share a 32-byte sector), or -- fp64 batches -- 512 threads that store
+// their 32-byte records (whole sectors) straight to their place in the sub-chunk's 64 KB slab:
+// without the 64 KB staging buffer next to the 64 KB histogram of a 16 384-tile grid TWO
+// workgroups fit a CU, and the write bursts of one overlap the ranking phases of the other.
+template <typename T, int NI, int NO, bool HAS_PW, int S, bool W3, bool ONE, int TH, bool STAGE>
+__global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_local(
     GridDesc<NO> gd, TileGeom<NO> tg, int64_t P, const T* __restrict__ points,
     const T* __restrict__ pw, const T* __restrict__ rot, const T* __restrict__ trans, int64_t b0,
     int nb, LocalBinArgs la, int want_slot, uint32_t spare_slot, T* __restrict__ ds_dpoints,
     T* __restrict__ ds_dpw, int zero_dropped) {
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
-    constexpr int PPT = S / kBinThreads;
+    constexpr int PPT = S / TH;
     if (ONE) nb = 1;
     const int NT = tg.NT;
     extern __shared__ uint32_t lhist[];  // [NT]
-    __shared__ RecT<T, W3> recs[S];
+    __shared__ RecT<T, W3> recs[STAGE ? S : 1];
     __shared__ uint16_t touched[kTouchCap];
-    __shared__ uint32_t wsum[kBinThreads / kWave];
+    __shared__ uint32_t wsum[TH / kWave];
     __shared__ uint32_t s_ntouch, s_nvalid;
-    for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
+    for (int i = threadIdx.x; i < NT; i += TH) lhist[i] = 0;
     if (threadIdx.x == 0) s_ntouch = 0;
     // Everything per point is addressed as (block base: uniform, 64-bit) + (index inside the
     // sub-chunk: 32-bit): with 64-bit per-point addresses the compiler hoists a dozen of them out
@@ -1182,7 +1187,7 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
     T pt[PPT][NI], w[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
+        const uint32_t lp = threadIdx.x + (uint32_t)k * TH;
         const uint32_t ll = lp < nloc ? lp : nloc - 1;
         load_point<T, NI>(pts_blk, (int64_t)ll, pt[k]);
         w[k] = HAS_PW ? pw_blk[ll] : T(1);
@@ -1211,7 +1216,7 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
         // progress -- those lanes go to the per-lane atomics at once.)
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
+            const uint32_t lp = threadIdx.x + (uint32_t)k * TH;
             int ref0[NO];
             T dlo[NO];
             bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && lp < nloc;
@@ -1290,7 +1295,7 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
             }
         } else {
             // every bin: (count, non-empty) packed as count + (1 << 16) per non-empty bin (<= 4096 each)
-            const int bpt = (NT + kBinThreads - 1) / kBinThreads;
+            const int bpt = (NT + TH - 1) / TH;
             const int bin0 = threadIdx.x * bpt;
             uint32_t packed = 0;
             for (int q = 0; q < bpt; ++q) {
@@ -1310,7 +1315,7 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
             for (int wv = 0; wv < wave; ++wv) run += wsum[wv];
             uint32_t total = 0;
 #pragma unroll
-            for (int wv = 0; wv < kBinThreads / kWave; ++wv) total += wsum[wv];
+            for (int wv = 0; wv < TH / kWave; ++wv) total += wsum[wv];
             for (int q = 0; q < bpt; ++q) {
                 const int i = bin0 + q;
                 if (i >= NT) break;
@@ -1335,14 +1340,15 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
         // c. place into LDS in tile order
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const uint32_t lp = threadIdx.x + (uint32_t)k * kBinThreads;
+            const uint32_t lp = threadIdx.x + (uint32_t)k * TH;
             if (tile[k] >= 0) {
                 const uint32_t sidx = lhist[tile[k]] + lrank[k];
                 RecT<T, W3> r;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
                 if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)base + lp, T(0));
-                recs[sidx] = r;
+                if constexpr (STAGE) recs[sidx] = r;
+                else rec_blk[sidx] = r;  // (a whole 32-byte sector; the slab's lines fill up within the round)
                 if (slot_blk) __builtin_nontemporal_store((uint32_t)base + sidx, &slot_blk[lp]);
             } else if (lp < nloc) {
                 if (slot_blk) __builtin_nontemporal_store(spare_slot, &slot_blk[lp]);
@@ -1357,11 +1363,13 @@ __global__ __launch_bounds__(kBinThreads, ((sizeof(T) == 4 && ONE) ? 8 : 4)) voi
         lds_barrier();
         // d. write-out: one contiguous, coalesced run; clean the histogram for the next pose
         const uint32_t n_valid = s_nvalid;
-        for (uint32_t i = threadIdx.x; i < n_valid; i += kBinThreads) rec_blk[i] = recs[i];
+        if constexpr (STAGE)
+            for (uint32_t i = threadIdx.x; i < n_valid; i += TH) rec_blk[i] = recs[i];
+        (void)n_valid;
         if (listed) {
-            for (uint32_t i = threadIdx.x; i < n_t; i += kBinThreads) lhist[touched[i]] = 0;
+            for (uint32_t i = threadIdx.x; i < n_t; i += TH) lhist[touched[i]] = 0;
         } else {
-            for (int i = threadIdx.x; i < NT; i += kBinThreads) lhist[i] = 0;
+            for (int i = threadIdx.x; i < NT; i += TH) lhist[i] = 0;
         }
         if (threadIdx.x == 0) s_ntouch = 0;
         lds_barrier();
@@ -3071,7 +3079,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 // (function-local static: thread-safe, no getenv on the call path) and clamped to valid ranges.
 struct Knobs {
     int cap3d_div, cap2d_div, cap_min, pose_group, scatter_wc, bwd_unpermute, compact_records,
-        splat_blocked, fixed_point, fuse_tilescan;
+        splat_blocked, fixed_point, fuse_tilescan, bin_direct_store;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
@@ -3091,6 +3099,7 @@ static const Knobs& knobs() {
         q.splat_blocked = env_int("DPR_SPLAT_BLOCKED", 2, 0, 2);  // 2: decided on the device
         q.fixed_point = env_int("DPR_FIXED_POINT", 1, 0, 1);  // 0: f64 LDS accumulators for fp32 data too
         q.fuse_tilescan = env_int("DPR_FUSE_TILESCAN", 1, 0, 1);  // 0: k_tilescan as a launch of its own
+        q.bin_direct_store = env_int("DPR_BIN_DIRECT_STORE", 1, 0, 1);  // 0: fp64 batches stage records in LDS too
         return q;
     }();
     return k;
@@ -3621,24 +3630,28 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     la.off_desc = pl.off_desc;
     la.off_bdesc = pl.off_bdesc;
     la.off_ltot = pl.off_ltot;
-#define DPR_LAUNCH_LOCAL1(HAS_PW, W3, ONE)                                                        \
+#define DPR_LAUNCH_LOCAL2(HAS_PW, W3, ONE, TH, STAGE)                                              \
     do {                                                                                          \
-        auto kern = k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3, ONE>;     \
+        auto kern = k_bin_local<T, NI, NO, HAS_PW, (sizeof(T) == 4 ? 4096 : 2048), W3, ONE, TH,  \
+                                STAGE>;                                                           \
         if (int rc = allow_lds_bytes(kern, lds)) return rc;                                       \
-        hipLaunchKernelGGL(kern, dim3((unsigned)pl.nsub), dim3(kBinThreads), lds, st, gd, tg, P,  \
-                           points, pw, rot, trans, b, nb, la, want_idx ? 1 : 0, spare, d_pts,     \
-                           d_pw, zero_dropped);                                                   \
+        hipLaunchKernelGGL(kern, dim3((unsigned)pl.nsub), dim3(TH), lds, st, gd, tg, P, points,   \
+                           pw, rot, trans, b, nb, la, want_idx ? 1 : 0, spare, d_pts, d_pw,       \
+                           zero_dropped);                                                         \
     } while (0)
-#define DPR_LAUNCH_LOCAL(HAS_PW, W3)                    \
-    do {                                                \
-        if (nb == 1) DPR_LAUNCH_LOCAL1(HAS_PW, W3, true); \
-        else DPR_LAUNCH_LOCAL1(HAS_PW, W3, false);      \
+    // fp64 batches: two 512-thread workgroups per CU without LDS staging (see k_bin_local)
+    const bool direct_store = sizeof(T) == 8 && nb > 1 && knobs().bin_direct_store;
+#define DPR_LAUNCH_LOCAL(HAS_PW, W3)                                        \
+    do {                                                                    \
+        if (nb == 1) DPR_LAUNCH_LOCAL2(HAS_PW, W3, true, 1024, true);       \
+        else if (direct_store) DPR_LAUNCH_LOCAL2(HAS_PW, W3, false, 512, false); \
+        else DPR_LAUNCH_LOCAL2(HAS_PW, W3, false, 1024, true);              \
     } while (0)
     if (pw) DPR_LAUNCH_LOCAL(true, false);
     else if (!want_idx && knobs().compact_records) DPR_LAUNCH_LOCAL(false, true);
     else DPR_LAUNCH_LOCAL(false, false);
 #undef DPR_LAUNCH_LOCAL
-#undef DPR_LAUNCH_LOCAL1
+#undef DPR_LAUNCH_LOCAL2
     stage_mark(st);
     int64_t grid64[3] = {1, 1, 1};
     for (int d = 0; d < NO; ++d) grid64[d] = gd.n[d];
