@@ -72,7 +72,12 @@ extern "C" {
 #define DPR_ALGO_AUTO 0
 #define DPR_ALGO_ATOMIC 1 /* thread per point, direct global float atomics / gathers */
 #define DPR_ALGO_TILED 2  /* per-pose binning of points into voxel tiles, LDS-resident
-                             tile accumulation, plain-store flush (no global atomics) */
+                             tile accumulation (fp32 data: exact 64-bit fixed-point sums, scale
+                             from |out_weight| * max|point_weight|; NaN / Inf weights and fp64
+                             data: f64 sums), plain-store flush (no global atomics).  Grids of
+                             more than 32768 tiles (e.g. 1024^3) are walked in slabs of tile
+                             layers along the last axis -- no KEEP / REUSE there; a single tile
+                             layer of more than 16384 tiles is DPR_ERR_UNSUPPORTED_ALGO. */
 #define DPR_ALGO_CHUNKED 3 /* chunks of consecutive points of a spatially coherent cloud.
                               2-D grids (projections; what AUTO picks for several poses of a
                               cloud, by a cost model -- dpr_resolve_algo_ex): a
