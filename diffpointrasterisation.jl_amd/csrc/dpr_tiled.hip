@@ -34,6 +34,9 @@
 //   DPR_BWD_UNPERMUTE=0  owner threads store ds_dpoints directly instead of un-permuting
 //   DPR_POSE_GROUP=n     at most n poses per group (1 = per-pose pipeline)
 //   DPR_FIXED_POINT=0    f64 LDS accumulators instead of 64-bit fixed point in the fp32 forward
+//   DPR_FUSE_TILESCAN=0  k_tilescan / k_runscan as launches of their own
+//   DPR_BIN_DIRECT_STORE=0  fp64 batches stage their records in LDS like everything else
+//   DPR_MAX_TILES=n      tiles per launch sequence (default 32768): lets a test walk slabs on small grids
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -150,18 +153,18 @@ static int max_tiles() {
     return v;
 }
 template <int NO> static bool make_slab_cut(const int64_t* grid, SlabCut* sc) {
-    const int kMaxTiles = max_tiles();  // (shadows the compile-time bound in this function)
+    const int cap = max_tiles();  // tiles one launch sequence may hold (kMaxTiles unless DPR_MAX_TILES)
     int64_t per = 1;
     for (int d = 0; d + 1 < NO; ++d) per *= (grid[d] + TileDims<NO>::T[d] - 1) / TileDims<NO>::T[d];
     const int64_t layers = (grid[NO - 1] + TileDims<NO>::T[NO - 1] - 1) / TileDims<NO>::T[NO - 1];
-    if (per > kMaxTiles / 2 || layers > (1 << 20)) return false;  // (a real + a ghost layer must fit)
+    if (per > cap / 2 || layers > (1 << 20)) return false;  // (a real + a ghost layer must fit)
     sc->per_layer = (int)per;
     sc->layers = (int)layers;
-    if (per * layers <= kMaxTiles) {
+    if (per * layers <= cap) {
         sc->lps = (int)layers;
         sc->nslab = 1;
     } else {
-        sc->lps = (int)(kMaxTiles / per) - 1;
+        sc->lps = (int)(cap / per) - 1;
         sc->nslab = (int)((layers + sc->lps - 1) / sc->lps);
     }
     return true;
