@@ -857,3 +857,48 @@ def test_c5_full_batch_64_poses_against_the_oracle(oracle, dev):
         assert abs(float(pb.background[b]) - rp.background[k]) <= 1e-8 * float(np.abs(np_g[..., k]).sum())
     others = [b for b in range(B) if b not in check]
     assert float(pb.rotation[others].abs().max()) == 0.0 and float(pb.out_weight[others].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float64, torch.float64), (np.float32, torch.float32)])
+@pytest.mark.parametrize("batch,share", [(11, False), (19, True)])
+def test_local_batches_with_a_remainder(oracle, dev, npdt, tdt, batch, share):
+    """Local binning bins up to 8 poses per launch (all B poses, 16 per launch, for a kept batch):
+    11 poses = a batch of 8 + one of 3, 19 kept poses = 16 + 3 -- on a grid of 4100 tiles, where the
+    cloud is cell-sorted inside the call (fp64: the 512-thread direct-store binning).  Forward and
+    pullback (re-binning, or reusing the kept binning) against the oracle, with point weights."""
+    grid = (320, 320, 328)  # 5 x 20 x 41 tiles
+    d = D.make(n_points=220_000, n_in=3, n_out=3, batch=batch, grid_n=grid, seed=41, dtype=npdt)
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+            T(d.weights, dev), T(d.point_weights, dev))
+    ws = None
+    if share:
+        need = max(dpr_amd.workspace_bytes(op, d.grid, d.n_points, batch, 3, tdt, "tiled", sharing=True)
+                   for op in ("raster", "pullback"))
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, batch, tdt, dev)
+    dpr_amd.raster_(out, *args, algo="tiled", workspace=ws, keep_binning=share)
+    # five poses against the single-pose oracle: first / last of the first launch, first of the
+    # second, one in the middle, the last
+    for b in sorted({0, 7, 8, batch // 2, batch - 1}):
+        ref = oracle.raster(d.grid, d.points, d.rotations[b:b + 1], d.translations[b:b + 1],
+                            d.backgrounds[b:b + 1], d.weights[b:b + 1], d.point_weights, dtype=npdt)
+        assert_close(out[..., b], ref[..., 0], tol(npdt, "out"), f"out, pose {b}")
+    del out
+    # sensitivities on three poses only (first of a launch, last of the first launch, last pose)
+    hot = [0, 7, batch - 1]
+    g = torch.zeros((batch,) + tuple(reversed(grid)), device=dev, dtype=tdt)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    for b in hot:
+        g[b].normal_(generator=gen)
+    g = g.permute(3, 2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, *args, algo="tiled", workspace=ws, reuse_binning=share)
+    np_g = np.asfortranarray(np.stack([g[..., b].cpu().numpy() for b in hot], axis=-1))
+    rp = oracle.raster_pullback(np_g, d.points, d.rotations[hot], d.translations[hot], d.weights[hot],
+                                d.point_weights, dtype=npdt)
+    assert_close(pb.points, rp.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.point_weight, rp.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    for k, b in enumerate(hot):
+        assert_close(pb.rotation[b], rp.rotation[k], tol(npdt, "pose"), f"ds_drotation, pose {b}")
+        assert_close(pb.translation[b], rp.translation[k], tol(npdt, "pose"), f"ds_dtranslation, pose {b}")
+    cold = [b for b in range(batch) if b not in hot]
+    assert float(pb.rotation[cold].abs().max()) == 0.0
