@@ -657,21 +657,28 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
                     }
                 }
             }
-            // The ACCUMULATIONS below are fused multiply-adds (explicit: the library is built with
-            // -ffp-contract=off): these sums run over neighbours, points and poses in an order the
-            // reference does not share anyway, so fusing changes nothing a parity statement rests on
-            // (cell choice and the per-neighbour weights stay in the reference's operation order) and
-            // takes ~25 of the ~150 vector instructions per (point, pose) out of a VALU-bound loop.
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const T gi = gq[s];
-                // src/raster_pullback.jl:51-60 (a dropped neighbour adds nothing: gi == 0)
-                const T dweight = voxel_weight<T, 2>(dlo, s, gi);
-                dow_part = fma_t(dweight, pwi, dow_part);
-                dpw_part = fma_t(dweight, ps.ow, dpw_part);
-                const T factor = gi * ps.ow * pwi;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) dcoord[n] = fma_t(factor, interp_weight<T, 2>(n, dlo, s), dcoord[n]);
+            // The bilinear form and its two partial derivatives in FACTORED form (src/raster_pullback.jl:
+            // 51-65 sums g_s * sigma(s_n) * prod_{m != n} omega_m(s_m) over the four neighbours; with
+            // omega(0) = 1 - d, omega(1) = d that is
+            //   W     = g00 + dx (g10 - g00) + dy [(g01 - g00) + dx ((g11 - g10) - (g01 - g00))]
+            //   dW/dx = (g10 - g00) + dy ((g11 - g01) - (g10 - g00))
+            //   dW/dy = (g01 - g00) + dx ((g11 - g10) - (g01 - g00))
+            // ): 14 instead of 36 vector instructions per (point, pose) of this VALU-bound loop, and
+            // explicit FMAs (the library is built with -ffp-contract=off).  These sums run over
+            // neighbours, points and poses in an order the reference does not share anyway; cell
+            // choice and deltas above stay in the reference's operation order.  A dropped neighbour
+            // arrives as g = 0, which is what dropping its term means.
+            {
+                const T a = gq[1] - gq[0], c = gq[2] - gq[0];
+                const T b = gq[3] - gq[2], d = gq[3] - gq[1];
+                const T dWdx = fma_t(dlo[1], b - a, a);
+                const T dWdy = fma_t(dlo[0], d - c, c);
+                const T W = fma_t(dlo[1], dWdy, fma_t(dlo[0], a, gq[0]));
+                dow_part = W * pwi;
+                dpw_part = W * ps.ow;
+                const T owpw = ps.ow * pwi;
+                dcoord[0] = owpw * dWdx;
+                dcoord[1] = owpw * dWdy;
             }
             T scaled[2];
 #pragma unroll
