@@ -157,8 +157,12 @@ extern "C" {
 #define DPR_FLAG_MAX_POSE_GROUP(n) (((unsigned)(n) & 0xffu) << 8)
 /* DPR_FLAG_COHERENT_POINTS: the caller states that neighbouring points in memory are
  * neighbours in space (e.g. the output of dpr_sort_points_*).  DPR_ALGO_CHUNKED on 2-D grids
- * then skips its own Hilbert sort (and the workspace shrinks to the per-pose partial sums).
- * A wrong claim costs speed, never correctness. */
+ * then skips its own Hilbert sort (and the workspace shrinks to the per-pose partial sums);
+ * DPR_ALGO_TILED bins such a cloud locally (sub-chunks of 4096 / 2048 consecutive points ordered
+ * by tile in LDS, run descriptors instead of a count pass; grids of up to 16384 tiles) and, for a
+ * batch, all poses of up to 8 in one launch.  Without the flag batched calls on grids of more than
+ * 4096 tiles order the cloud themselves first (a counting sort into 4096 cells of the model frame,
+ * once per call).  A wrong claim costs speed, never correctness. */
 #define DPR_FLAG_COHERENT_POINTS 4u
 
 int dpr_version(void);
@@ -208,7 +212,8 @@ int dpr_stage_timing_end(void);
  * 256-byte aligned (DPR_ERR_WORKSPACE otherwise; hipMalloc / AMDGPU.jl / torch allocations
  * are); every non-NULL data pointer must be aligned to its element type
  * (DPR_ERR_INVALID_ARG otherwise, before any launch).  DPR_ALGO_TILED with a shape it would
- * refuse (more than 32768 tiles, P >= 2^32) returns (size_t)-1 here too. */
+ * refuse (a tile layer of more than 16384 tiles, P >= 2^32, KEEP / REUSE flags on a grid of more
+ * than 32768 tiles) returns (size_t)-1 here too. */
 size_t dpr_workspace_bytes_f32(int op, int algo, int n_in, int n_out, const int64_t *grid,
                                int64_t P, int64_t B);
 size_t dpr_workspace_bytes_f64(int op, int algo, int n_in, int n_out, const int64_t *grid,
