@@ -1192,8 +1192,14 @@ __global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_l
     for (int k = 0; k < PPT; ++k) {
         const uint32_t lp = threadIdx.x + (uint32_t)k * TH;
         const uint32_t ll = lp < nloc ? lp : nloc - 1;
-        load_point<T, NI>(pts_blk, (int64_t)ll, pt[k]);
-        w[k] = HAS_PW ? pw_blk[ll] : T(1);
+        if (nloc) {  // (uniform; an empty cloud still runs the pipeline: the tiles get their background)
+            load_point<T, NI>(pts_blk, (int64_t)ll, pt[k]);
+            w[k] = HAS_PW ? pw_blk[ll] : T(1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) pt[k][j] = T(0);
+            w[k] = T(1);
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;

@@ -689,6 +689,23 @@ def test_edge_points(oracle, dev, algo, npdt, tdt):
     assert (pb.points[3:6] == 0).all() and (pb.point_weight[3:6] == 0).all()
 
 
+def test_empty_cloud_with_the_coherent_flag(dev):
+    """P = 0 on the local-binning path (the sub-chunk kernel has nothing to load): background only,
+    zero gradients of the right shapes -- single pose and a batch on a grid of more than 4096 tiles."""
+    for grid, B in (((40, 40, 40), 1), ((320, 320, 328), 5)):
+        R = torch.eye(3, device=dev, dtype=torch.float32)[None].repeat(B, 1, 1)
+        t = torch.zeros(B, 3, device=dev, dtype=torch.float32)
+        empty = torch.zeros(0, 3, device=dev, dtype=torch.float32)
+        bg = torch.arange(1, B + 1, device=dev, dtype=torch.float32)
+        out = dpr_amd.raster(grid, empty, R, t, bg, algo="tiled", coherent_points=True)
+        for b in range(B):
+            assert (out[..., b] == float(b + 1)).all()
+        g = torch.ones((B,) + tuple(reversed(grid)), device=dev, dtype=torch.float32).permute(3, 2, 1, 0)
+        pb = dpr_amd.raster_pullback_(g, empty, R, t, bg, algo="tiled", coherent_points=True)
+        assert pb.points.shape == (0, 3) and float(pb.rotation.abs().max()) == 0.0
+        assert torch.allclose(pb.background, torch.full((B,), float(np.prod(grid)), device=dev))
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_empty_and_tiny_inputs(dev, algo):
     R = torch.eye(3, device=dev, dtype=torch.float64)[None].repeat(2, 1, 1)
