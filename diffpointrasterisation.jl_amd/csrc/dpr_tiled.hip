@@ -3183,7 +3183,7 @@ static int pose_group(int NT, int64_t P, int64_t B, int max_group) {
 
 static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, int max_group,
                       bool coherent = false, int n_in = 3, bool share_batch = false,
-                      bool slabbed = false) {
+                      bool slabbed = false, bool fwd_only = false) {
     Plan pl;
     if (slabbed) coherent = false;  // local binning keeps a batch's bins: one slab at a time cannot
     share_batch = share_batch && B > 1;
@@ -3245,8 +3245,12 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     // split threshold: ~P/256 records (even a fully clustered cloud then yields >= 256 items,
     // one per CU, while the headline Gaussian cloud has no tile above it), at least 4096; a
     // split tile's parts hold more than cap/2 records each
+    // (a forward call that keeps nothing for a pullback splits later: the parts of a split tile
+    // cost the halo pass more than a 2x longer item costs the fixed-point tile kernel -- 1 M points
+    // -> 128^3: forward 0.065 -> 0.059 ms; the pullback's gather prefers the finer split)
     int64_t cap = P / knobs().cap3d_div;
-    if (cap < knobs().cap_min) cap = knobs().cap_min;
+    const int64_t cap_min = fwd_only ? 2 * (int64_t)knobs().cap_min : knobs().cap_min;
+    if (cap < cap_min) cap = cap_min;
     if (n_out == 2) {
         // 2-D grids have few tiles (256 at 512^2) with cheap LDS tiles (8.7 KB): split
         // earlier so that a dense projection still gives the chip ~2048 items
@@ -3429,8 +3433,12 @@ size_t tiled_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int 
     SlabCut sc;
     if (!grid_cut(n_out, grid, &sc)) return (size_t)-1;
     if (sc.nslab > 1 && (flags & 3u)) return (size_t)-1;
+    // (sized for the plan of a sharing pair / a pullback: a forward call that keeps nothing splits
+    // heavy tiles later and needs no more than this -- so a workspace sized for `raster` serves every
+    // call of the same problem, as before)
     return make_plan(elem, n_out, slab_max_tiles(sc), P, B, (int)((flags >> 8) & 0xffu),
-                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in, (flags & 3u) != 0, sc.nslab > 1).total;
+                     (flags & DPR_FLAG_COHERENT_POINTS) != 0, n_in, (flags & 3u) != 0, sc.nslab > 1)
+        .total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -3726,7 +3734,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     // KEEP_BINNING with B > 1: every pose keeps its own binning (Plan::pose_stride)
     const Plan pl = make_plan(sizeof(T), NO, NTmax, P, B, (int)((flags >> 8) & 0xffu),
                               (flags & DPR_FLAG_COHERENT_POINTS) != 0, NI, (flags & 3u) != 0,
-                              sc.nslab > 1);
+                              sc.nslab > 1, !(flags & 3u));
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_TILED raster needs %zu workspace bytes, got %zu",
                     pl.total, ws_ ? ws_bytes : (size_t)0);
