@@ -3141,9 +3141,9 @@ struct Plan {
     int max_slabs;   // overflow slabs (parts of split tiles)
     size_t off_hdr, off_counts, off_totals, off_tile_start, off_items, off_nitems, off_nzbins, off_tparts, off_tslab,
         off_split, off_rec, off_idx, off_slot, off_aux, total;
-    // Hilbert sort of the cloud inside the call (batched poses on grids with more than 4096
-    // tiles, where the plain scatter runs 2.4x faster on coherent input: 50 M points -> 512^3,
-    // 1.64 -> 0.68 ms per pose against 2.7 ms for the sort, once per call)
+    // Cell sort of the cloud inside the call (dpr_coarse.h; batched poses on grids with more than
+    // 4096 tiles): what local binning of all poses of a batch needs; up to 16384 tiles per pose --
+    // beyond that the plain count / scatter pipeline runs on the cell-sorted copy
     bool sort_inside;
     size_t off_spts, off_spw, off_perm, off_iperm, off_sgrad, off_sgradw, off_sorttmp;
     // KEEP_BINNING / REUSE_BINNING with B > 1: every pose owns a copy of the per-pose part of the

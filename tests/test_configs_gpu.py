@@ -325,9 +325,9 @@ def test_local_binning_of_coherent_points(oracle, dev, npdt, tdt, n_in, n_out, g
 
 
 def test_batched_large_grid_sorts_the_cloud_inside(oracle, dev, with_pw=True):
-    """Batched poses on a grid with more than 4096 tiles: the tiled path Hilbert-sorts the cloud
-    into the workspace once per call and scatters the point gradients back through the
-    permutation.  250 k points -> 384 x 384 x 256 (4608 tiles), 4 poses, against the oracle."""
+    """Batched poses on a grid with more than 4096 tiles: the tiled path cell-sorts the cloud
+    into the workspace once per call (dpr_coarse.h), bins all poses locally, and brings the point
+    gradients back through the inverse permutation.  250 k points -> 384 x 384 x 256 (4608 tiles), 4 poses, against the oracle."""
     npdt = np.float32
     d = D.make(n_points=250_000, n_in=3, n_out=3, batch=4, grid_n=384, seed=6, dtype=npdt)
     d.grid = (384, 384, 256)
