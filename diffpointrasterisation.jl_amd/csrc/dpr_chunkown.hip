@@ -67,6 +67,10 @@ constexpr int kCOWaves = kCOThreads / kWave;
 constexpr int kCOCap = DPR_CO_CAP;               // LDS tile cells (8 bytes each): 78 KiB, 2 blocks / CU
                                                  // (round 2: 9216; fewer wide pairs, C4 forward -2 %)
 constexpr int kCOWideCap = 2 * kCOCap;            // tile of k_co_splat_wide (one workgroup per CU)
+#ifndef DPR_CO_GATHER_CAP
+#define DPR_CO_GATHER_CAP 8192
+#endif
+constexpr int kCOGatherCap = DPR_CO_GATHER_CAP;   // cells (of T) of the pullback's ds_dout tile
 constexpr int kCOMaxSlice = 64;                  // poses per block (per-pose sums live in LDS)
 static_assert(kCOChunk / kWave == kCOWaves * kCOPPT, "spread assignment covers the chunk");
 
@@ -561,9 +565,21 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     }
     // tile: footprint of ds_dout | red: per-thread per-pose sums.  The epilogue reuses both as
     // one buffer to turn the chunk's point gradients into coalesced rows.
-    __shared__ T smem[kCOCap + NVAL * kCOThreads];
-    T* const tile = smem;
-    T(*const red)[kCOThreads] = reinterpret_cast<T(*)[kCOThreads]>(smem + kCOCap);
+    // fp32 data (PIPE): two tiles and two `red` buffers -- the footprint of pose b + 1 is requested
+    // into registers before pose b is gathered and written to the other tile after it, so its
+    // latency hides behind the arithmetic and one barrier per pose is enough (the kernel runs one
+    // workgroup per CU by its 1024 threads x ~100 VGPRs anyway, so the LDS is there).
+#ifndef DPR_CO_NO_FOOT_TABLE
+    constexpr bool PIPE = sizeof(T) == 4;
+#else
+    constexpr bool PIPE = false;
+#endif
+    constexpr int CAP = PIPE ? kCOGatherCap : kCOCap;
+    constexpr int NBUF = PIPE ? 2 : 1;
+    constexpr int kRed = NVAL * kCOThreads;
+    __shared__ T smem[NBUF * (CAP + kRed)];
+    T* const tile0 = smem;
+    T* const red0 = smem + NBUF * CAP;
     __shared__ T sbox[kCOWaves][6];
     __shared__ double pacc[kCOMaxSlice][NVAL];
     static_assert(NVAL <= kCOWaves, "one wave per per-pose sum");
@@ -586,37 +602,26 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     __shared__ int foot[kCOMaxSlice][4];
     co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, any ? (int)(b_hi - b_lo) : 0);
 #endif
-    for (int64_t b = b_lo; any && b < b_hi; ++b) {
-        const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
-        int lo[2], hi[2];
-#ifndef DPR_CO_NO_FOOT_TABLE
-        const int64_t cells = co_read_footprint(foot, (int)(b - b_lo), lo, hi);
-#else
-        const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
-#endif
-        if (cells == 0) continue;  // uniform: no neighbour of the chunk is in the grid (sums stay 0)
-        // A footprint that does not fit the LDS tile (sparse tails of the cloud, incoherent
-        // input) is gathered from global memory directly (L2-resident image; unlike the
-        // forward's atomics these are plain loads).
-        const bool fits = cells <= kCOCap;
+    // stage the footprint of ds_dout (residual mode: scale * (out - target)); no barrier
+    auto stage = [&](T* tile, const int (&lo)[2], int W, int H, int64_t b) {
+        const T* gb = g + b * gd.G;
+        const T* tb = rs.target ? rs.target + b * gd.G : nullptr;
+        for (int r = wave; r < H; r += kCOWaves) {
+            const size_t off = (size_t)(lo[1] + r) * gd.n[0] + lo[0];
+            for (int x = lane; x < W; x += kWave) {
+                T v = gb[off + x];
+                if (tb) v = rs.scale * (v - tb[off + x]);
+                tile[r * W + x] = v;
+            }
+        }
+    };
+    // one pose: the thread's kCOPPT points against the staged footprint (or global memory when it
+    // does not fit); per-pose sums into vals, point gradients into dp / dpw
+    auto gather_pose = [&](const Pose<T, NI, 2>& ps, const int (&lo)[2], const int (&hi)[2], bool fits,
+                           const T* tile, int64_t b, T (&vals)[NVAL]) {
         const int W = hi[0] - lo[0] + 1, H = hi[1] - lo[1] + 1;
         const T* gb = g + b * gd.G;
         const T* tb = rs.target ? rs.target + b * gd.G : nullptr;
-        if (fits) {
-            // stage the footprint of ds_dout (residual mode: scale * (out - target))
-            for (int r = wave; r < H; r += kCOWaves) {
-                const size_t off = (size_t)(lo[1] + r) * gd.n[0] + lo[0];
-                for (int x = lane; x < W; x += kWave) {
-                    T v = gb[off + x];
-                    if (tb) v = rs.scale * (v - tb[off + x]);
-                    tile[r * W + x] = v;
-                }
-            }
-            __syncthreads();
-        } else {
-            lds_barrier();  // `red` of the previous pose has been read
-        }
-        T vals[NVAL];
 #pragma unroll
         for (int q = 0; q < NVAL; ++q) vals[q] = T(0);
 #pragma unroll
@@ -695,19 +700,138 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
                 dp[k][j] = fma_t(ps.R[1 + j * 2], scaled[1], fma_t(ps.R[0 + j * 2], scaled[0], dp[k][j]));
             dpw[k] += dpw_part;
         }
-        // per-pose sums: T within the thread (kCOPPT points), f64 across the block.  Every thread
-        // parks its NVAL sums in LDS; after the barrier (which also releases the tile for the next
-        // pose) wave q adds up value q -- it is done before it arrives at the next barrier, and
-        // `red` is next written after that one.
-#pragma unroll
-        for (int q = 0; q < NVAL; ++q) red[q][threadIdx.x] = vals[q];
-        lds_barrier();
+    };
+    // per-pose sums: T within the thread (kCOPPT points), f64 across the block.  Every thread
+    // parks its NVAL sums in LDS; after a barrier wave q adds up value q.
+    auto reduce_parked = [&](const T* red, int j) {
         if (wave < NVAL) {
+#ifndef DPR_CO_RED_F64
+            if constexpr (sizeof(T) == 4) {
+                // fp32 data: the block's 4096 terms are summed in f32 as a tree (4 per thread, 16 per
+                // reducer lane, 64 lanes: what the reference's pairwise `sum` does in the same
+                // precision); across blocks in f64 (k_co_reduce).  The f64 version of this step --
+                // 16 conversions and f64 adds per lane and six ds_bpermute round trips -- sat on the
+                // critical path of every pose (nine of the sixteen waves reduce).
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < kCOThreads / kWave; ++i) sum += red[wave * kCOThreads + i * kWave + lane];
+                sum = wave_sum_lane63(sum);
+                if (lane == kWave - 1) pacc[j][wave] = (double)sum;
+                return;
+            }
+#endif
             double sum = 0.0;
 #pragma unroll
-            for (int i = 0; i < kCOThreads / kWave; ++i) sum += (double)red[wave][i * kWave + lane];
+            for (int i = 0; i < kCOThreads / kWave; ++i) sum += (double)red[wave * kCOThreads + i * kWave + lane];
             sum = wave_sum<double>(sum);
-            if (lane == 0) pacc[b - b_lo][wave] = sum;
+            if (lane == 0) pacc[j][wave] = sum;
+        }
+    };
+    if constexpr (PIPE) {
+#ifndef DPR_CO_NO_FOOT_TABLE
+        // Prefetch: thread t requests cells t, t + 1024, ... of the next footprint (row-major, width
+        // Wn) -- all of a tile's loads are in flight at once, every lane takes part, the LDS writes are
+        // linear.  (Measured against a wave-per-row mapping, which needs no division per cell: 3.09
+        // against 3.41 ms for C4's pullback, and against the same mapping with LDS-DMA loads,
+        // global_load_lds_dword: 3.33 ms -- experiments/r04_gather_prefetch_modes.patch.)
+        constexpr int kSlots = (CAP + kCOThreads - 1) / kCOThreads;
+        const int nbs = any ? (int)(b_hi - b_lo) : 0;
+        int lo[2] = {0, 0}, hi[2] = {-1, -1};
+        int64_t cells = 0;
+        bool staged = false;  // tile[buf] holds the current pose's footprint
+        if (nbs > 0) cells = co_read_footprint(foot, 0, lo, hi);
+        __syncthreads();  // (pacc zeroed)
+        const int n0 = gd.n[0];
+        for (int j = 0; j < nbs; ++j) {
+            const int64_t b = b_lo + j;
+            const int buf = j & 1;
+            const bool fits = cells > 0 && cells <= CAP;
+            if (fits && !staged) {  // (uniform) the first pose of the block
+                stage(tile0 + buf * CAP, lo, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, b);
+                __syncthreads();
+            }
+            // the next pose's footprint: requested now, parked in the other tile after this pose
+            int lo_n[2] = {0, 0}, hi_n[2] = {-1, -1};
+            int64_t cells_n = 0;
+            if (j + 1 < nbs) cells_n = co_read_footprint(foot, j + 1, lo_n, hi_n);
+            const int Wn = hi_n[0] - lo_n[0] + 1;
+            const bool pref_n = cells_n > 0 && cells_n <= CAP;
+            T pf_g[kSlots], pf_t[kSlots];
+            const T* gb_n = g + (b + 1) * gd.G;
+            const T* tb_n = rs.target ? rs.target + (b + 1) * gd.G : nullptr;
+            T* const tn = tile0 + (buf ^ 1) * CAP;
+            if (pref_n) {
+                const float inv_w = 1.0f / (float)Wn;
+#pragma unroll
+                for (int u = 0; u < kSlots; ++u) {
+                    const int i = threadIdx.x + u * kCOThreads;
+                    pf_g[u] = T(0);
+                    pf_t[u] = T(0);
+                    if (i < (int)cells_n) {
+                        // row of cell i: i / Wn through the reciprocal (i <= 8192: exact after the fix-up)
+                        int r = (int)(((float)i + 0.5f) * inv_w);
+                        int x = i - r * Wn;
+                        if (x < 0) { --r; x += Wn; }
+                        if (x >= Wn) { ++r; x -= Wn; }
+                        const size_t off = (size_t)(lo_n[1] + r) * n0 + lo_n[0] + x;
+                        pf_g[u] = gb_n[off];
+                        if (tb_n) pf_t[u] = tb_n[off];
+                    }
+                }
+            }
+            T* const red = red0 + buf * kRed;
+            if (cells > 0) {  // (uniform; else: no neighbour of the chunk is in the grid, sums stay 0)
+                const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
+                T vals[NVAL];
+                gather_pose(ps, lo, hi, fits, tile0 + buf * CAP, b, vals);
+#pragma unroll
+                for (int q = 0; q < NVAL; ++q) red[q * kCOThreads + threadIdx.x] = vals[q];
+            }
+            if (pref_n) {
+#pragma unroll
+                for (int u = 0; u < kSlots; ++u) {
+                    const int i = threadIdx.x + u * kCOThreads;
+                    if (i < (int)cells_n) tn[i] = rs.target ? rs.scale * (pf_g[u] - pf_t[u]) : pf_g[u];
+                }
+            }
+            // one barrier per pose: `red[buf]` is parked and the other tile is staged; both are next
+            // written two poses on, behind the barrier of the pose in between
+            lds_barrier();
+            if (cells > 0) reduce_parked(red, j);
+            lo[0] = lo_n[0]; lo[1] = lo_n[1]; hi[0] = hi_n[0]; hi[1] = hi_n[1];
+            cells = cells_n;
+            staged = pref_n;
+        }
+#endif
+    } else {
+        for (int64_t b = b_lo; any && b < b_hi; ++b) {
+            const Pose<T, NI, 2> ps = load_pose<T, NI, 2>(rot, trans, ow, b);
+            int lo[2], hi[2];
+#ifndef DPR_CO_NO_FOOT_TABLE
+            const int64_t cells = co_read_footprint(foot, (int)(b - b_lo), lo, hi);
+#else
+            const int64_t cells = co_footprint<T, NI>(c, h, ps, gd, lo, hi);
+#endif
+            if (cells == 0) continue;  // uniform: no neighbour of the chunk is in the grid (sums stay 0)
+            // A footprint that does not fit the LDS tile (sparse tails of the cloud, incoherent
+            // input) is gathered from global memory directly (L2-resident image; unlike the
+            // forward's atomics these are plain loads).
+            const bool fits = cells <= CAP;
+            if (fits) {
+                stage(tile0, lo, hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, b);
+                __syncthreads();
+            } else {
+                lds_barrier();  // `red` of the previous pose has been read
+            }
+            T vals[NVAL];
+            gather_pose(ps, lo, hi, fits, tile0, b, vals);
+            // after the barrier (which also releases the tile for the next pose) wave q adds up
+            // value q -- it is done before it arrives at the next barrier, and `red` is next
+            // written after that one
+#pragma unroll
+            for (int q = 0; q < NVAL; ++q) red0[q * kCOThreads + threadIdx.x] = vals[q];
+            lds_barrier();
+            reduce_parked(red0, (int)(b - b_lo));
         }
     }
     __syncthreads();
@@ -723,7 +847,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
     // instead: element i of the chunk's [kCOChunk][NI] block sits at i + i / 64 (the padding
     // keeps the strided writes off one bank), the weights behind it.
     constexpr int kPwBase = kCOChunk * NI + kCOChunk * NI / 64;
-    static_assert(kPwBase + kCOChunk + kCOChunk / 64 <= kCOCap + NVAL * kCOThreads, "epilogue fits");
+    static_assert(kPwBase + kCOChunk + kCOChunk / 64 <= CAP + NVAL * kCOThreads, "epilogue fits");
     if (perm) {  // straight to the caller's order (host: only when the poses are not split over grid.y)
         const int64_t cbase = (int64_t)blockIdx.x * kCOChunk;
 #pragma unroll

@@ -232,6 +232,23 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+// f32 wave sum through the DPP crossbar (row shifts, then the two row broadcasts): the total
+// arrives in lane 63; no LDS traffic, ~12 full-rate instructions (ds_bpermute-based __shfl_xor
+// is a chain of six LDS round trips).  All 64 lanes must call.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_shift_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_shift_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_shift_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_shift_add<0x118, 0xf>(v);  // row_shr:8   (lane 15 of each row: the row's sum)
+    v = dpp_shift_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+    v = dpp_shift_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 template <typename T> __device__ __forceinline__ void atomic_add(T* addr, T v) {
     unsafeAtomicAdd(addr, v);  // native global_atomic_add_f32 / _f64 on gfx950
 }
