@@ -8,6 +8,10 @@ C=diffpointrasterisation.jl_amd/csrc
 i=0
 for fl in "${VARS[@]}"; do
   ( cd $C && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function $fl -c $F -o ${F%.hip}.o && make ../libdpr.so >/dev/null ) || exit 1
+  if [ -n "$AB_SCRIPT" ]; then  # any other timing script instead of bench.py
+    echo "[$fl]"; timeout -k 10 300 python3 $AB_SCRIPT "$@" 2> $OUT/v$i.err || exit 1
+    i=$((i+1)); continue
+  fi
   timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-secondary --no-scaling-reference "$@" > $OUT/v$i.json 2> $OUT/v$i.err || exit 1
   python3 - $OUT/v$i.json "$fl" <<'PY'
 import json, sys
