@@ -112,11 +112,11 @@ extern "C" {
  *                        of a part vary: rounding level.
  *                        fp64: f64 LDS atomics, order-dependent
  *                        at 1e-16 relative
- *   DPR_ALGO_CHUNKED     2-D: exact fixed-point sums per chunk   registers across the poses, fixed      per-thread in T, f64 across threads, partials
- *                        (fp32), then float atomics into the     order: bit-reproducible for a given    per (chunk, pose) reduced in a fixed order:
- *                        image across chunks: run to run,        point order (2-D); 3-D lists: read-    bit-reproducible for a given point order (2-D)
- *                        rounding level.  3-D lists: f64 LDS     modify-write per pose in index order
- *                        atomics + diverted global atomics
+ *   DPR_ALGO_CHUNKED     2-D: exact fixed-point sums per chunk   registers across the poses, fixed      2-D: the 4096 terms of a (chunk, pose) as a
+ *                        (fp32), then float atomics into the     order: bit-reproducible for a given    fixed tree in T (fp32 data; fp64: f64 across
+ *                        image across chunks: run to run,        point order (2-D); 3-D lists: read-    threads), the partials per (chunk, pose) in f64
+ *                        rounding level.  3-D lists: f64 LDS     modify-write per pose in index order   in a fixed order: bit-reproducible for a given
+ *                        atomics + diverted global atomics                                              point order
  *
  * "Rounding level" = the differences any two summation orders of the same terms show in the
  * accumulation type; no output depends on the order beyond that.  The contributions themselves
