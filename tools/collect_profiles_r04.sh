@@ -21,7 +21,7 @@ ARGS="--no-cpu-baseline --no-secondary --no-scaling-reference"
 cd /tmp && export TMPDIR=/tmp
 step stats_c3
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $ROOT/bench.py --steps 30 --warmup 3 $ARGS > $O/stats.log 2>&1 || exit 1
-tail -1 $O/stats.log > $O/bench_under_rocprof.json
+grep '^{"metric"' $O/stats.log | tail -1 > $O/bench_under_rocprof.json
 step stats_coherent
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_coherent -- python $ROOT/bench.py --steps 30 --warmup 3 $ARGS --order hilbert --coherent > $O/stats_coherent.log 2>&1 || exit 1
 step stats_c4
@@ -34,6 +34,14 @@ for mode in random coherent; do
   timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$mode -- python $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/fetch_$mode.log 2>&1 || exit 1
   step write_$mode
   timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$mode -- python $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/write_$mode.log 2>&1 || exit 1
+done
+cd $ROOT
+for cfg in c3 c3coh c4; do
+  case $cfg in c3) M="";; c3coh) M="--order hilbert --coherent";; c4) M="--config C4 --poses 64";; esac
+  step sq_$cfg
+  SQ_OUT=final4/sq_$cfg bash tools/r04_sq_pmc.sh $M || exit 1
+  step sqi_$cfg
+  SQ_OUT=final4/sqi_$cfg bash tools/r04_sq_insts.sh $M || exit 1
 done
 cd $ROOT
 step other_configs

@@ -87,3 +87,35 @@ for k, v in out["kernels"].items():
 d = json.load(open("profiles/r04_bench_default.json"))
 print("bench:", d["value"], d["ms_per_step"], d.get("ms_per_step_cold"), d["roofline"]["frac"], d["roofline"]["traffic"], d["coherent_input"]["value"], d["cpu_baseline"]["value"], d["no_share"])
 print(json.dumps(d["roofline"]["stages"]))
+
+
+# SQ counter passes (tools/r04_sq_pmc.sh, tools/r04_sq_insts.sh): busy shares per kernel + executed instructions
+import subprocess
+def sq(sub_busy, sub_insts, stats_txt, label, dst, mode="w"):
+    busy = max(glob.glob(f"{O}/{sub_busy}/sq/*/*_counter_collection.csv"), key=os.path.getmtime)
+    txt = subprocess.run(["python3", "tools/summarise_sq_pmc.py", busy, stats_txt, label], capture_output=True, text=True).stdout
+    rows = list(csv.DictReader(open(max(glob.glob(f"{O}/{sub_insts}/sq/*/*_counter_collection.csv"), key=os.path.getmtime))))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        k = r["Kernel_Name"].split("<")[0].split("(")[0].replace("void ", "")
+        if k.startswith("dpr::"):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines = ["", "Executed wave-instructions per launch (tools/r04_sq_insts.sh, same command):",
+             f"{'kernel':24s} {'VALU':>10s} {'SALU':>10s} {'LDS':>10s} {'SMEM':>10s} {'VMEM rd':>10s}"]
+    for k, v in sorted(agg.items()):
+        a = {c: sum(x) / len(x) for c, x in v.items()}
+        lines.append(f"{k:24s} {a.get('SQ_INSTS_VALU', 0):10.4g} {a.get('SQ_INSTS_SALU', 0):10.4g} {a.get('SQ_INSTS_LDS', 0):10.4g} "
+                     f"{a.get('SQ_INSTS_SMEM', 0):10.4g} {a.get('SQ_INSTS_VMEM_RD', 0):10.4g}")
+    open(f"profiles/{dst}", mode).write(txt + "\n".join(lines) + "\n\n")
+
+HEAD = ("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-scaling-reference [...]\n"
+        "One pass of 8 SQ slots per command (tools/r04_sq_pmc.sh); averages per launch.  SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* are quad-cycles summed over all\n"
+        "waves (MI355X_MICROARCH.md), SQ_BUSY_CYCLES cycles summed over the 32 shader engines.  Derived columns: simd_time = kernel duration (the kernel trace of the\n"
+        "same command, launch-weighted over template instances) x 1024 SIMDs x 2.0 GHz / 4 (the clock is an assumption, +-10 %); waves/SIMD = WAVE_CYCLES / simd_time;\n"
+        "VALU busy = ACTIVE_INST_VALU / simd_time (a SIMD issues one vector instruction per quad-cycle); LDS busy likewise.\n\n")
+if glob.glob(f"{O}/sq_c3/sq/*/*_counter_collection.csv"):
+    open("profiles/r04_c3_sq_counters.txt", "w").write(HEAD)
+    sq("sq_c3", "sqi_c3", "profiles/r04_c3_kernel_stats.txt", "C3 step, random order", "r04_c3_sq_counters.txt", "a")
+    sq("sq_c3coh", "sqi_c3coh", "profiles/r04_c3_coherent_kernel_stats.txt", "C3 step, --order hilbert --coherent (k_hilbert_keys / k_gather_points: the bench's untimed pre-sort)", "r04_c3_sq_counters.txt", "a")
+    open("profiles/r04_c4_sq_counters.txt", "w").write(HEAD)
+    sq("sq_c4", "sqi_c4", "profiles/r04_c4_kernel_stats.txt", "C4 share: --config C4 --poses 64", "r04_c4_sq_counters.txt", "a")
