@@ -92,7 +92,18 @@ constexpr int kSplatThreads = DPR_SPLAT_THREADS;    // forward tile kernel block
 #ifndef DPR_SPLAT_RUNS_OCC
 #define DPR_SPLAT_RUNS_OCC (DPR_SPLAT_THREADS >= 1024 ? 8 : 4)  // waves per SIMD for two blocks per CU
 #endif
-constexpr int kGatherThreads = DPR_GATHER_THREADS;  // pullback tile kernel block
+#ifndef DPR_GATHER_THREADS_F64
+#define DPR_GATHER_THREADS_F64 512
+#endif
+// fp64: the ds_dout tile is 80 KB, two workgroups per CU -- 512 threads each keep 16 waves on the CU
+// as the fp32 kernel's four workgroups of 256 do (with 256: 2.3 waves per SIMD, half the wave time
+// spent waiting; profiles/r04_c5_sq_counters.txt)
+template <typename T> __host__ __device__ constexpr int gather_threads() {
+    return sizeof(T) == 8 ? DPR_GATHER_THREADS_F64 : DPR_GATHER_THREADS;
+}
+// waves per SIMD the pullback tile kernels are compiled for (fp64: 128 VGPRs, so that two
+// workgroups of 512 fit a CU; fp32: four workgroups of 256 need no more than that either)
+template <typename T> __host__ __device__ constexpr int gather_waves_per_simd() { return 4; }
 #ifndef DPR_UPB
 #define DPR_UPB 4  // points per thread of the single-pose un-permute (a block = one scatter sub-chunk)
 #endif
@@ -2339,16 +2350,17 @@ __global__ __launch_bounds__(256) void k_halo_gather(GridDesc<NO> gd, TileGeom<N
 // original order with one random read per point.  !UNPERM: the owner thread stores straight
 // to ds_dpoints[idx] / ds_dpoint_weight[idx] (good when the input order is spatially coherent).
 template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM>
-__global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
+__global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) void k_tile_gather(
     GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, int64_t P,
     const uint32_t* __restrict__ rec_idx, const WorkItem* __restrict__ items,
     const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b0,
     T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials,
     Residual<T> rs, BinHeader want, BinHeader* hdr) {
+    constexpr int GT = gather_threads<T>();
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NVAL = NO * NI + NO + 3;  // dR | dt | d out_weight | d background | loss
-    constexpr int NW = kGatherThreads / kWave;
+    constexpr int NW = GT / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
     if (want.magic) {
@@ -2404,7 +2416,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         const int lane = threadIdx.x & (kWave - 1);
         const int x = lane % TX;
         const bool x_ok = x0[0] + x < gd.n[0];
-        constexpr int STEP = (kGatherThreads / kWave) * RPW;
+        constexpr int STEP = (GT / kWave) * RPW;
         // an unsplit tile's ds_dout cells are read by this block only (plus the neighbours' halo
         // rows): streamed with non-temporal loads; the parts of a split tile re-read them
         auto stage_rows = [&](auto nt_tag) {
@@ -2445,7 +2457,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         if ((item.part_nparts >> 16) > 1) stage_rows(std::false_type{});
         else stage_rows(std::true_type{});
         // the x == TX column (halo cells only): one cell per row
-        for (int row = threadIdx.x; row < ROWS; row += kGatherThreads) {
+        for (int row = threadIdx.x; row < ROWS; row += GT) {
             const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
             const int g0 = x0[0] + TX, g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
             const bool in = g0 < gd.n[0] && g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
@@ -2470,7 +2482,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
         const uint32_t rcur = r;
-        r += kGatherThreads;
+        r += GT;
         {
             const uint32_t rl = r < r1 ? r : r1 - 1;  // clamped prefetch
             nxt = rec[rl];
@@ -2594,16 +2606,17 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather(
 // original order with one random read per point.  !UNPERM: the owner thread stores straight
 // to ds_dpoints[idx] / ds_dpoint_weight[idx] (good when the input order is spatially coherent).
 template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE, bool UNPERM, bool RUNS>
-__global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
+__global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) void k_tile_gather_runs(
     GridDesc<NO> gd, TileGeom<NO> tg, Rec4<T>* rec, const RunDesc* __restrict__ runs, int64_t P,
     const uint32_t* __restrict__ rec_idx, const WorkItem* __restrict__ items,
     const uint32_t* __restrict__ n_items, int max_items, const T* __restrict__ g,
     const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ ow, int64_t b0,
     T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw, double* __restrict__ partials,
     Residual<T> rs, BinHeader want, BinHeader* hdr) {
+    constexpr int GT = gather_threads<T>();
     constexpr int NVH = tile_voxels_halo<NO>();
     constexpr int NVAL = NO * NI + NO + 3;  // dR | dt | d out_weight | d background | loss
-    constexpr int NW = kGatherThreads / kWave;
+    constexpr int NW = GT / kWave;
     __shared__ T tile_g[NVH];
     __shared__ double red[NW][NVAL];
     if (want.magic) {
@@ -2649,7 +2662,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
     if (r < r1) {
         if constexpr (RUNS) {
             cu.seek(rt, r, nruns);
-            nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1);
+            nxt_phys = cu.next(rt, GT, nruns, r + GT < r1);
         } else {
             nxt_phys = r;
         }
@@ -2678,7 +2691,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
         const int lane = threadIdx.x & (kWave - 1);
         const int x = lane % TX;
         const bool x_ok = x0[0] + x < gd.n[0];
-        constexpr int STEP = (kGatherThreads / kWave) * RPW;
+        constexpr int STEP = (GT / kWave) * RPW;
         // an unsplit tile's ds_dout cells are read by this block only (plus the neighbours' halo
         // rows): streamed with non-temporal loads; the parts of a split tile re-read them
         auto stage_rows = [&](auto nt_tag) {
@@ -2719,7 +2732,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
         if ((item.part_nparts >> 16) > 1) stage_rows(std::false_type{});
         else stage_rows(std::true_type{});
         // the x == TX column (halo cells only): one cell per row
-        for (int row = threadIdx.x; row < ROWS; row += kGatherThreads) {
+        for (int row = threadIdx.x; row < ROWS; row += GT) {
             const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
             const int g0 = x0[0] + TX, g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
             const bool in = g0 < gd.n[0] && g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
@@ -2747,12 +2760,12 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
                 const Rec4<T> rc = nxt;
                 const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
                 const uint32_t rcur = nxt_phys;
-                r += kGatherThreads;
+                r += GT;
                 // The prefetch is issued unconditionally (past the end: this record again): with a
                 // branch around it the compiler cannot count the memory operations of an iteration
                 // and waits for EVERYTHING outstanding (s_waitcnt vmcnt(0)), i.e. also for the
                 // in-place gradient store of the previous iteration -- 135 instead of ~100 us.
-                if (r < r1r) nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1r);
+                if (r < r1r) nxt_phys = cu.next(rt, GT, nruns, r + GT < r1r);
                 nxt = rec[nxt_phys];
                 if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
                 T pt[NI];
@@ -2857,7 +2870,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_tile_gather_runs(
             r = threadIdx.x;
             if (r < r1r) {
                 cu.seek(rt, r, nruns);
-                nxt_phys = cu.next(rt, kGatherThreads, nruns, r + kGatherThreads < r1r);
+                nxt_phys = cu.next(rt, GT, nruns, r + GT < r1r);
                 nxt = rec[nxt_phys];
                 if (HAS_PW && !UNPERM) nxt_idx = rec_idx[nxt_phys];
             }
@@ -3946,7 +3959,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             return rc;
 #define DPR_LAUNCH_GATHER_RUNS(HAS_PW, FIRST, UNP)                                               \
     hipLaunchKernelGGL((k_tile_gather_runs<T, NI, NO, HAS_PW, FIRST, UNP, true>),                \
-                       dim3(pl.max_items), dim3(kGatherThreads), 0, st, gd, tg,                  \
+                       dim3(pl.max_items), dim3(gather_threads<T>()), 0, st, gd, tg,                  \
                        (Rec4<T>*)(wsb + pl.off_rec), (const RunDesc*)(wsb + pl.off_sdesc),       \
                        pl.nsub * pl.sub, (const uint32_t*)(wsb + pl.off_idx),                    \
                        (const WorkItem*)(wsb + pl.off_items),                                    \
@@ -3954,7 +3967,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                        b, d_pts, d_pw, partials, rs, want, hdr)
 #define DPR_LAUNCH_GATHER_PLAIN(HAS_PW, FIRST, UNP)                                              \
     hipLaunchKernelGGL((k_tile_gather<T, NI, NO, HAS_PW, FIRST, UNP>), dim3(pl.max_items),       \
-                       dim3(kGatherThreads), 0, st, gd, tg, (Rec4<T>*)(wsb + pl.off_rec), P * nb, \
+                       dim3(gather_threads<T>()), 0, st, gd, tg, (Rec4<T>*)(wsb + pl.off_rec), P * nb, \
                        (const uint32_t*)(wsb + pl.off_idx), (const WorkItem*)(wsb + pl.off_items), \
                        (const uint32_t*)(wsb + pl.off_nitems), pl.max_items, g, rot, trans, ow,   \
                        b, d_pts, d_pw, partials, rs, want, hdr)
