@@ -221,6 +221,47 @@ def test_chunk_owner_fuzz(oracle, dev, seed):
     chunk_owner_fuzz_case(oracle, dev, seed)
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_chunk_owner_pullback_pipeline_over_mixed_poses(oracle, dev, residual):
+    """The fp32 chunk-owner pullback prefetches the next pose's footprint into a second LDS tile
+    while it gathers the current one.  One pose slice that alternates the three kinds of footprint
+    the loop tells apart -- fits the tile (prefetched), empty (the chunk projects outside the
+    image: nothing staged, sums stay 0) and too large for the tile (gathered from global memory) --
+    in every order of succession, with and without the fused residual."""
+    rng = np.random.default_rng(77)
+    P, grid = 3 * 4096 + 100, (200, 160)
+    pts = (0.05 * rng.normal(size=(P, 3)) + np.array([0.2, -0.1, 0.3])).astype(np.float32)
+    kinds = [0, 1, 2, 0, 2, 1, 1, 0, 0, 2, 2, 1, 0]  # 0 fits, 1 outside, 2 blown up
+    B = len(kinds)
+    R = D.random_rotations(rng, B, 3)[:, :2, :].astype(np.float32)
+    t = (0.05 * rng.normal(size=(B, 2))).astype(np.float32)
+    for b, k in enumerate(kinds):
+        if k == 1:
+            t[b] += 3.0           # everything beyond the image
+        if k == 2:
+            R[b] *= 14.0          # a 4096-point chunk spreads over more than 8192 pixels
+            t[b] -= (R[b] @ np.array([0.2, -0.1, 0.3], np.float32))  # ... centred on the image
+    ow = rng.uniform(0.5, 2, size=B).astype(np.float32)
+    pw = rng.uniform(0.2, 2, size=P).astype(np.float32)
+    g = np.asfortranarray(rng.normal(size=grid + (B,)).astype(np.float32))
+    dp, dR, dt_, dow, dpw = (T(x, dev) for x in (pts, R, t, ow, pw))
+    if not residual:
+        ref = oracle.raster_pullback(g, pts, R, t, ow, pw, dtype=np.float32)
+        pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), dp, dR, dt_, None, dow, dpw, algo="chunked")
+    else:
+        out = oracle.raster(grid, pts, R, t, None, ow, pw, dtype=np.float32)
+        ref = oracle.raster_pullback(np.asfortranarray(2.0 * (out - g)), pts, R, t, ow, pw, dtype=np.float32)
+        pb, loss = dpr_amd.raster_residual_pullback_(grid_to_dev(np.asfortranarray(out), dev),
+                                                     grid_to_dev(g, dev), dp, dR, dt_, None, dow, dpw,
+                                                     scale=2.0, algo="chunked")
+        assert_close(loss, ((out.astype(np.float64) - g) ** 2).sum(axis=(0, 1)), 1e-5, "loss")
+    assert float(np.abs(ref.rotation[[b for b, k in enumerate(kinds) if k == 1]]).max()) == 0.0
+    assert float(np.abs(ref.rotation[[b for b, k in enumerate(kinds) if k == 2]]).max()) > 0.0
+    for name, kind in (("points", "points"), ("point_weight", "points"), ("rotation", "pose"),
+                       ("translation", "pose"), ("out_weight", "pose")):
+        assert_close(getattr(pb, name), getattr(ref, name), tol(np.float32, kind), name)
+
+
 @pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
 @pytest.mark.parametrize("with_pw", [False, True])
 def test_chunk_owner_keeps_the_sorted_cloud_for_the_pullback(oracle, dev, npdt, tdt, with_pw):
