@@ -153,7 +153,10 @@ __device__ __forceinline__ bool co_load_chunk(const T* __restrict__ points,
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         T l = sbox[0][j], u = sbox[0][3 + j];
-#pragma unroll
+        // (not unrolled all the way: the compiler requests the 16 x 6 values at once -- 96 VGPRs in
+        // fp32, 192 in fp64 -- and spills what lives across this point; with point weights the fp64
+        // forward then needed 300 bytes of scratch per lane, which costs every dispatch ~0.14 ms)
+#pragma unroll 2
         for (int q = 1; q < kCOWaves; ++q) {
             l = sbox[q][j] < l ? sbox[q][j] : l;
             u = sbox[q][3 + j] > u ? sbox[q][3 + j] : u;
@@ -163,23 +166,6 @@ __device__ __forceinline__ bool co_load_chunk(const T* __restrict__ points,
         h[j] = T(0.5) * u - T(0.5) * l;
     }
     return any;
-}
-
-// the chunk's points (and weights) once more, as co_load_chunk left them
-template <typename T, int NI, bool HAS_PW>
-__device__ __forceinline__ void co_reload_points(const T* __restrict__ points, const T* __restrict__ pw,
-                                                 int64_t P, int64_t base, T (&pt)[kCOPPT][NI],
-                                                 T (&w)[kCOPPT]) {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    asm volatile("" ::: "memory");  // (a second load, not the first one kept alive)
-#pragma unroll
-    for (int k = 0; k < kCOPPT; ++k) {
-        const int64_t p = base + co_point(lane, wave, k);
-        const int64_t pl = p < P ? p : P - 1;
-        load_point<T, NI>(points, pl, pt[k]);
-        if (p >= P) pt[k][0] = T(__builtin_nanf(""));
-        w[k] = HAS_PW ? pw[pl] : T(1);
-    }
 }
 
 // max |point_weight| over the chunk (1 without point weights), identical in every thread; NaN
@@ -356,13 +342,6 @@ __global__ __launch_bounds__(kCOThreads, COSplatOcc<T>::value) void k_co_splat(
     __shared__ int foot[kCOMaxSlice][4];
     __shared__ int fexp[kCOMaxSlice];
     co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, nbs, fexp, ow, maxpw, fixed);
-#endif
-#ifndef DPR_CO_NO_RELOAD
-    // The points are loaded AGAIN here (L2 hits, once per block): held across the prologue's
-    // reductions and the footprint arithmetic they push the kernel past its 64 registers, and the
-    // allocator then spills values of the pose loop (weighted clouds: 79 spilled VGPRs, 12 scratch
-    // loads per pose and wave).
-    co_reload_points<T, NI, HAS_PW>(points, pw, P, (int64_t)blockIdx.x * kCOChunk, pt, w);
 #endif
     unsigned long long wide_mask = 0;  // poses of this slice whose footprint outgrows the tile
     static_assert(kCOMaxSlice <= 64, "one bit per pose of a slice");
@@ -625,10 +604,6 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
 #ifndef DPR_CO_NO_FOOT_TABLE
     __shared__ int foot[kCOMaxSlice][4];
     co_fill_footprints<T, NI>(foot, c, h, gd, rot, trans, b_lo, any ? (int)(b_hi - b_lo) : 0);
-#endif
-#ifndef DPR_CO_NO_RELOAD
-    // (see k_co_splat; fp64: 12-39 spilled VGPRs -> 0-7.  The wide forward kernel gets worse with it.)
-    co_reload_points<T, NI, HAS_PW>(points, pw, P, (int64_t)blockIdx.x * kCOChunk, pt, w);
 #endif
     // stage the footprint of ds_dout (residual mode: scale * (out - target)); no barrier
     auto stage = [&](T* tile, const int (&lo)[2], int W, int H, int64_t b) {
