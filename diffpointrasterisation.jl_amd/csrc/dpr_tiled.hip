@@ -3401,6 +3401,18 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
     if (P >= (int64_t)1 << 32) return false;
     SlabCut sc;
     if (!grid_cut(n_out, grid, &sc)) return false;
+    // A cloud that is SPARSE on the grid: the tiled path pays per tile (zeroing and flushing an LDS
+    // tile, staging a ds_dout tile: ~25 ns each) whether points fall into it or not, the direct
+    // kernels pay per point only.  Crossovers measured on 256^3 ... 768^3 and 2048^2 / 4096^2 with
+    // 1e5 ... 1e7 points, 1 and 4 poses (tools/sparse_grid_probe.py, profiles/r04_sparse_grids.txt):
+    // forward ~60 points per tile (3-D) / ~48 (2-D), pullback ~320 (3-D) / 150-430 (2-D) -- the
+    // direct pullback only READS the cells its points touch.  Below that AUTO regretted up to 2.8x
+    // (3e5 points -> 4096^2, pullback) with the thresholds that follow, which were fitted on grids
+    // of up to 2048 tiles.
+    const int64_t NT_all = (int64_t)sc.per_layer * sc.layers;
+    const int64_t per_tile = op == DPR_OP_RASTER ? (n_out == 3 ? 60 : 48)
+                                                 : (n_out == 3 ? 320 : (NT_all <= 4096 ? 150 : 430));
+    if (P < per_tile * NT_all) return false;
     if (sc.nslab > 1) {
         // More than 32768 tiles (e.g. 1024^3): every slab re-reads the cloud, and the tile kernels
         // write the whole grid -- which the direct path's background fill does as well.  Forward:

@@ -631,8 +631,9 @@ def test_autograd_rule_matches_the_explicit_pullback(oracle, dev):
 
 @pytest.mark.parametrize("n_points,n_out,grid,batch", [
     (150_000, 2, (96, 96), 12),        # AUTO -> the chunk-owner pair: the sorted cloud is shared
-    (650_000, 3, (336, 336, 336), 4),  # AUTO -> tiled pair on a grid too large for pose groups:
-                                       # every pose keeps its binning
+    (1_000_000, 3, (272, 272, 272), 4),  # AUTO -> tiled pair on a grid too large for pose groups
+                                         # (2890 tiles; dense enough for the tiled pullback: 320
+                                         # points per tile): every pose keeps its binning
 ])
 def test_autograd_rule_on_batches_that_share(oracle, dev, n_points, n_out, grid, batch):
     """`raster_ad` on a BATCH: where the library shares between a raster call and its pullback
@@ -1272,15 +1273,17 @@ def test_tiled_on_a_2d_grid_of_more_than_32768_tiles(oracle, dev, n_in, n_out, g
 
 def test_1024_cube_fp32_forward_auto_is_tiled_and_matches_the_oracle(oracle, dev):
     """The reference README's largest grid (README.md:193: 1024^3): 131 072 tiles, four slabs.
-    AUTO takes the tiled path for the forward from 10^6 points on (10^7 -> 1024^3 as well); 10^6
-    points against the oracle, compared on the device (4.3 GB per grid)."""
+    AUTO takes the tiled path for the forward where the cloud is dense enough on the grid (~60
+    points per tile: 10^7 -> 1024^3), the direct kernels below (10^6 points: 2x faster there,
+    profiles/r04_sparse_grids.txt); 10^6 points through the slabs (algo="tiled") against the
+    oracle, compared on the device (4.3 GB per grid)."""
     n, P = 1024, 1_000_000
-    assert dpr_amd.resolve_algo("raster", (n, n, n), P, 1, 3) == "tiled"
     assert dpr_amd.resolve_algo("raster", (n, n, n), 10_000_000, 1, 3) == "tiled"
+    assert dpr_amd.resolve_algo("raster", (n, n, n), P, 1, 3) == "atomic"
     assert dpr_amd.resolve_algo("raster", (n, n, n), 100_000, 1, 3) == "atomic"   # README row: 1e5 points
     d = D.make(n_points=P, n_in=3, n_out=3, batch=1, grid_n=n, seed=22, dtype=np.float32)
     ref = oracle.raster(d.grid, d.points, d.rotations, d.translations, None, d.weights, dtype=np.float32,
                         threaded=True)
     out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), None,
-                         T(d.weights, dev))
+                         T(d.weights, dev), algo="tiled")
     _assert_close_on_device(out, grid_to_dev(ref, dev), 5e-5, "out (1024^3)")
