@@ -77,7 +77,11 @@ extern "C" {
                              data: f64 sums), plain-store flush (no global atomics).  Grids of
                              more than 32768 tiles (e.g. 1024^3) are walked in slabs of tile
                              layers along the last axis -- no KEEP / REUSE there; a single tile
-                             layer of more than 16384 tiles is DPR_ERR_UNSUPPORTED_ALGO. */
+                             layer of more than 16384 tiles is DPR_ERR_UNSUPPORTED_ALGO.
+                             AUTO picks it from ~2.5e5 points on where the cloud is dense enough
+                             on the grid (the path costs ~25 ns per tile, with or without points
+                             in it): >= 60 points per tile for the forward (48 on 2-D grids),
+                             >= 320 for the pullback (150-430 on 2-D grids). */
 #define DPR_ALGO_CHUNKED 3 /* chunks of consecutive points of a spatially coherent cloud.
                               2-D grids (projections; what AUTO picks for several poses of a
                               cloud, by a cost model -- dpr_resolve_algo_ex): a
