@@ -63,10 +63,14 @@ static PairCost chunkown_cost(int n_in, int64_t G, int64_t P, int64_t B, bool co
                          pm * (0.0055 + 0.02 * clamp01((f - 2000) / 10000) +
                                0.06 * clamp01((f - 20000) / 100000)));
     c.bwd = 0.025 + 0.0075 * pm +
-            (double)B * (0.0006 + 0.0006 * gm + pm * (0.007 + 0.006 * clamp01((f - 2000) / 5000)));
+            (double)B * (0.0006 + 0.0022 * (pm < 1.0 ? pm : 1.0) + 0.0006 * gm +
+                         pm * (0.0046 + 0.004 * clamp01((f - 2000) / 5000)));
+    // (round 4: 0.007 / 0.006 until the gather kernel prefetched its footprints -- 1e7 points: 0.044 ms
+    // per pose measured, 1e6 points: 0.007-0.009: one wave of blocks, ~2 us of latency per pose)
     if (!coherent) {
         c.fwd += sort_cost(pm);
-        c.bwd += sort_cost(pm) + 0.01 + 0.033 * pm;  // + gradients back to the caller's order
+        c.bwd += sort_cost(pm) + 0.01 + 0.015 * pm;  // + gradients back to the caller's order (large
+                                                     // clouds: stored through the permutation by the gather kernel)
     }
     return c;
 }
@@ -100,7 +104,7 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
     if (n_out != 2 || P >= ((int64_t)1 << 32) || P < 1 || B < 1) return false;
     if (B > 65535 * 64) return false;  // the chunk-owner kernels' grid.y (pose slices of <= 64)
     const PairCost c = chunkown_cost(n_in, G, P, B, coherent), o = other_cost(n_out, grid, G, P, B);
-    const double margin = B >= 32 ? 1.2 : (B >= 16 ? 1.1 : 0.9);
+    const double margin = B >= 32 ? 1.2 : (B >= 16 ? 1.0 : 0.9);
     if (op == DPR_OP_RASTER) return c.fwd < margin * o.fwd;
     if (op == DPR_OP_PULLBACK) return c.bwd < margin * o.bwd;
     const double pm = (double)P * 1e-6;

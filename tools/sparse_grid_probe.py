@@ -12,6 +12,8 @@ import dpr_amd as dpr  # noqa: E402
 from tests import data as D  # noqa: E402
 
 dev = torch.device("cuda:0")
+F64 = "--f64" in sys.argv  # fp64 data on the regret table's grid sizes instead of fp32 on large grids
+DT, NPDT = (torch.float64, np.float64) if F64 else (torch.float32, np.float32)
 
 
 def timed(fn, n=5):
@@ -27,16 +29,17 @@ def timed(fn, n=5):
 
 for P in (100_000, 300_000, 1_000_000, 3_000_000, 10_000_000):
     rng = np.random.default_rng(5)
-    pts = torch.from_numpy(0.4 * rng.standard_normal(size=(P, 3), dtype=np.float32)).to(dev)
-    for grid in ((256, 256, 256), (384, 384, 384), (512, 512, 512), (768, 768, 768), (2048, 2048), (4096, 4096)):
-        for B in (1, 4):
+    pts = torch.from_numpy((0.4 * rng.standard_normal(size=(P, 3), dtype=np.float32)).astype(NPDT)).to(dev)
+    for grid in (((128, 128, 128), (256, 256, 256), (384, 384, 384), (512, 512), (1024, 1024), (2048, 2048)) if F64 else
+                 ((256, 256, 256), (384, 384, 384), (512, 512, 512), (768, 768, 768), (2048, 2048), (4096, 4096))):
+        for B in ((1, 8) if F64 else (1, 4)):
             n_out = len(grid)
-            if int(np.prod(grid)) * B * 4 > 4e9:
+            if int(np.prod(grid)) * B * (8 if F64 else 4) > 4e9:
                 continue
-            R = torch.from_numpy(D.random_rotations(rng, B, 3)[:, :n_out, :].astype(np.float32)).to(dev)
-            t = torch.from_numpy((0.05 * rng.normal(size=(B, n_out))).astype(np.float32)).to(dev)
-            out = dpr.empty_grid(grid, B, torch.float32, dev)
-            g = dpr.empty_grid(grid, B, torch.float32, dev).normal_()
+            R = torch.from_numpy(D.random_rotations(rng, B, 3)[:, :n_out, :].astype(NPDT)).to(dev)
+            t = torch.from_numpy((0.05 * rng.normal(size=(B, n_out))).astype(NPDT)).to(dev)
+            out = dpr.empty_grid(grid, B, DT, dev)
+            g = dpr.empty_grid(grid, B, DT, dev).normal_()
             res = {}
             for algo in ("atomic", "tiled", "chunked"):
                 try:
