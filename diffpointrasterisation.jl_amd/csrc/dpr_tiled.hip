@@ -3432,7 +3432,8 @@ bool tiled_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t 
     // (one pose on a small grid -- up to 256^2 or 128^3: from 1e5 points -- the direct kernel's atomics are
     // at most 1.25x ahead there on a cloud that fills the grid and 2x behind on a clustered one,
     // profiles/r03_auto_regret.txt)
-    if (op == DPR_OP_RASTER && B == 1 && (NT <= 64 || (n_out == 3 && NT <= 256))) return P >= 100000;
+    // (two or three poses: the same per pose -- 1e5 points x 2 poses -> 128^3: tiled 0.058 ms, direct 0.099)
+    if (op == DPR_OP_RASTER && B < 4 && (NT <= 64 || (n_out == 3 && NT <= 256))) return P >= 100000;
     if (op == DPR_OP_RASTER) return P >= (grouped ? 60000 : 250000);
     if (B >= 4) return P >= (grouped ? 300000 : 600000);
     return P >= 250000;

@@ -12,6 +12,7 @@ import dpr_amd as dpr  # noqa: E402
 from tests import data as D  # noqa: E402
 
 dev = torch.device("cuda:0")
+MID = "--mid" in sys.argv  # fp32, the regret table's grids, batch sizes between its columns
 F64 = "--f64" in sys.argv  # fp64 data on the regret table's grid sizes instead of fp32 on large grids
 DT, NPDT = (torch.float64, np.float64) if F64 else (torch.float32, np.float32)
 
@@ -30,9 +31,10 @@ def timed(fn, n=5):
 for P in (100_000, 300_000, 1_000_000, 3_000_000, 10_000_000):
     rng = np.random.default_rng(5)
     pts = torch.from_numpy((0.4 * rng.standard_normal(size=(P, 3), dtype=np.float32)).astype(NPDT)).to(dev)
-    for grid in (((128, 128, 128), (256, 256, 256), (384, 384, 384), (512, 512), (1024, 1024), (2048, 2048)) if F64 else
+    for grid in (((128, 128, 128), (256, 256, 256), (512, 512), (1024, 1024)) if MID else
+                 ((128, 128, 128), (256, 256, 256), (384, 384, 384), (512, 512), (1024, 1024), (2048, 2048)) if F64 else
                  ((256, 256, 256), (384, 384, 384), (512, 512, 512), (768, 768, 768), (2048, 2048), (4096, 4096))):
-        for B in ((1, 8) if F64 else (1, 4)):
+        for B in ((2, 8, 32) if MID else (1, 8) if F64 else (1, 4)):
             n_out = len(grid)
             if int(np.prod(grid)) * B * (8 if F64 else 4) > 4e9:
                 continue
