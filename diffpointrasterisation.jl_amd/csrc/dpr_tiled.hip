@@ -1713,7 +1713,10 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
     if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
-    if (blocked == 2) blocked = (int)order_flag;  // (uniform)
+    // (uniform)  A projection (N_in > N_out) of a sorted cloud stays strided: neighbours in 3-D land
+    // on the same pixels whichever share of the list a thread takes, and the blocked assignment only
+    // adds its uncoalesced loads (10 M points x 64 poses -> 512^2, Hilbert-sorted: 13.9 against 11.3 ms).
+    if (blocked == 2) blocked = (NI == NO) ? (int)order_flag : 0;
     // item.tile = (pose within the group) * NT + tile
     const int tile = (int)(item.tile % (uint32_t)tg.NT);
     const int64_t b = b0 + (int64_t)(item.tile / (uint32_t)tg.NT);
