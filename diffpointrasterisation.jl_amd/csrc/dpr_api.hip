@@ -128,7 +128,7 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
     if (op != DPR_OP_RASTER || n_out != 3 || (flags & 3u) || !(flags & DPR_FLAG_COHERENT_POINTS))
         return false;
     if (B < 4 || P < 30000 || P >= ((int64_t)1 << 32)) return false;
-    if (!chunked_supported(n_out, grid)) return false;
+    if (!owner_supported(grid)) return false;
     // (fewer than 16 poses: only the very sparse cloud -- on a clustered one the lists lose 2x at
     // one point per 17-21 voxels and 4 poses, where they win 1.3x on a Gaussian or uniform cloud)
     return P * (B >= 16 ? 10 : 25) <= G;
@@ -294,8 +294,8 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
                 return raster_chunkown<T, NI>(st, flags, grid, G, P, B, out, points, rot, trans, \
                                               bg, ow, pw, ws, ws_bytes);                       \
             else                                                                               \
-                return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot,   \
-                                                 trans, bg, ow, pw, ws, ws_bytes);             \
+                return raster_owner<T>(st, flags, grid, G, P, B, out, points, rot, trans, bg,  \
+                                       ow, pw, ws, ws_bytes);                                  \
         }                                                                                      \
     }
     DPR_CASE(2, 2)
@@ -411,9 +411,9 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
                 if (rs.target)                                                                   \
                     return fail(DPR_ERR_UNSUPPORTED_ALGO,                                        \
                                 "the residual pullback has no 3-D DPR_ALGO_CHUNKED variant");    \
-                return pullback_chunked<T, NI, NO>(st, flags, grid, G, P, B, g, points, rot,     \
-                                                   trans, ow, pw, d_pts, d_rot, d_trans, d_bg,   \
-                                                   d_ow, d_pw, ws, ws_bytes);                    \
+                return pullback_owner<T>(st, flags, grid, G, P, B, g, points, rot, trans, ow,    \
+                                         pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
+                                         ws_bytes);                                              \
             }                                                                                    \
         }                                                                                        \
     }
@@ -464,7 +464,10 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
             if (n == (size_t)-1) fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
             return n;
         }
-        return chunked_workspace_bytes(n_out, grid, P, B);
+        const size_t n = owner_workspace_bytes(op, grid, P, B);
+        if (n == (size_t)-1)
+            fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs too many tiles or P >= 2^32");
+        return n;
     }
     fail(DPR_ERR_UNSUPPORTED_ALGO, "unknown algorithm %d", algo);
     return (size_t)-1;

@@ -1,0 +1,1524 @@
+// DPR_ALGO_CHUNKED on 3-D grids: owner-computes voxel tiles over a bounding-box hierarchy of
+// the cloud.  No per-point record is ever written: the points are read in place.
+//
+// For a spatially coherent cloud (dpr_sort_points_*: Hilbert order) 16 consecutive points are a
+// blob of a few voxels.  The cloud gets a two-level bounding-box hierarchy in the MODEL frame
+// (pose independent):
+//
+//   level 0   sub-chunk  = 16 consecutive points   {lo[3], hi[3]}            24 B
+//   level 1   chunk      = 64 sub-chunks = 1024 pt {lo[3], hi[3], max|pw|}   32 B
+//
+//   level 2   64 chunks  = 65536 points          {lo[3], hi[3], max|pw|}   32 B
+//
+// and a voxel tile of 32 x 32 x 14 cells (with a one-cell pad 148 KB of 64-bit LDS accumulators:
+// one workgroup of 1024 threads per CU) finds the points it needs by testing boxes, rotated into
+// the grid frame as centre +- sum_j |R_dj| h_j, against its own coordinate range:
+//
+//   boxes    k_own_boxes    one streaming pass over the points (the only kernel that reads all of
+//                           them): level-0 and level-1 boxes; k_own_boxes2: level 2 from level 1
+//   plan     k_own_plan     block per (tile, pose): tests the level-1 boxes, writes the tile's
+//                           candidate list, estimates its load from the box overlaps, splits heavy
+//                           tiles into parts (every n-th candidate) and files the work items in
+//                           buckets by size (heaviest first)
+//   forward  k_own_splat    block per work item.  A WAVE takes a candidate chunk, tests its 64
+//                           level-0 boxes (one per lane), queues the hits; whenever 64 sub-chunks
+//                           are queued every lane walks ONE of them (16 points, 4 per 48-byte
+//                           load) -- lanes are >= 16 points apart in the cloud, so LDS atomics of
+//                           one instruction rarely share an address.  Only contributions to cells
+//                           the tile OWNS are kept (a point near a tile face is visited by both
+//                           tiles): no halo exchange, no global atomics; out = background + tile
+//                           with plain stores.  fp32 data: exact 64-bit fixed-point sums
+//                           (dpr_device.h FixScale), fp64 / non-finite weights: f64 atomics.
+//            k_own_combine  split tiles only: the parts left their raw 64-bit tiles in slabs,
+//                           summed here (integer sums: exact, whatever the split)
+//   pullback k_own_gather   block per work item: ds_dout tile (+1 upper halo) staged in LDS; a
+//                           point is OWNED by the tile of its base voxel (clamped into the grid, so
+//                           that rejected points have an owner too and get their zeros), is
+//                           differentiated exactly once and its gradient is stored in cloud order:
+//                           no gradient records, no un-permute, no read-modify-write for one pose
+//            k_own_reduce   per-item partial sums (f64) -> ds_drotation, ds_dtranslation, ...
+//
+// Correct for ANY point order: a box that covers half the grid is listed by every tile it
+// overlaps (slow, never wrong); candidate lists that outgrow their buffer make the tile scan all
+// chunks itself.  Reference semantics: /root/reference/src/raster.jl:36-66 (forward kernel),
+// src/raster_pullback.jl:39-72 (per-point pullback), :85-148 (batch).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/dpr.h"
+#include "dpr_device.h"
+#include "dpr_tiled.h"
+
+namespace dpr {
+
+constexpr int kSC = 16;              // points per sub-chunk (level-0 box, one lane's share)
+constexpr int kFan = 64;             // sub-chunks per chunk (level-1 box, one wave's box tests)
+constexpr int kL1 = kSC * kFan;      // 1024 points
+constexpr int kOT = 1024;            // threads of the tile kernels
+constexpr int kOW = kOT / kWave;     // 16 waves
+constexpr int kTX = 32, kTY = 32, kTZ = 14;
+constexpr int kCells = kTX * kTY * kTZ;                     // 14336 owned cells
+// forward: the LDS tile is PADDED by one cell on every side (34 x 34 x 16 cells of 8 bytes = 148 KB):
+// all eight neighbours of every point the tile looks at have a cell, no ownership tests; the pad
+// cells are never flushed (the neighbouring tile computes them itself)
+constexpr int kPX = kTX + 2, kPY = kTY + 2, kPZ = kTZ + 2;
+constexpr int kPCells = kPX * kPY * kPZ;                    // 18496
+// pullback: the ds_dout tile is staged with the same pad (the upper one is the halo a point's upper
+// neighbours need; the lower one is only read by points below the grid's first cell, as zeros)
+constexpr int kL2 = 64;              // chunks per level-2 box (65536 points)
+constexpr int kBuckets = 16;
+constexpr int kMaxParts = 32;
+constexpr int kOwnBw = 16;           // poses planned at once (one copy of the per-pose arrays each)
+constexpr int kQueue = 128;          // queued sub-chunks per wave (64 + up to 63 left over)
+constexpr int kCtlWords = 32;        // per pose: [0] list cursor, [1] slab cursor (pose 0's), [2] split
+                                     // tiles, [3] list overflow seen, [16..31] bucket counts
+constexpr int kMaxOwnTiles = 1 << 20;
+
+struct alignas(8) Box0 {
+    float lo[3], hi[3];
+};
+struct alignas(16) Box1 {
+    float lo[3], hi[3], maxw, pad;
+};
+struct alignas(16) TileRec {
+    uint32_t begin;   // first entry of the candidate list, 0xffffffff: overflow (scan all chunks)
+    uint32_t count;   // candidate chunks
+    int sexp;         // fixed-point exponent of the tile (all parts share it), kFixNone: f64 sums
+    uint32_t parts;   // nparts | first_slab << 8
+};
+struct OGeom {
+    int nt[3];
+    int NT;
+};
+
+static bool make_ogeom(const int64_t* grid, OGeom* tg) {
+    const int T[3] = {kTX, kTY, kTZ};
+    int64_t NT = 1;
+    for (int d = 0; d < 3; ++d) {
+        tg->nt[d] = (int)((grid[d] + T[d] - 1) / T[d]);
+        NT *= tg->nt[d];
+    }
+    if (NT > kMaxOwnTiles) return false;
+    tg->NT = (int)NT;
+    return true;
+}
+
+// ---------------------------------------------------------------- box tests
+// Range of grid coordinates (src/raster.jl:88-92: coord = (R p + t + 1) * n / 2) the points of a
+// model-frame box can take, inflated by a bound on the rounding of this estimate AND of the
+// kernels' own coordinate arithmetic (8 ulp of the magnitudes involved + 1e-3 voxel): whatever
+// cell the splat / gather arithmetic picks for a point of the box lies inside.  NaN-safe: a box
+// with non-finite bounds yields NaN and is never "provably outside".  Computed in fp32 from the
+// pose the kernels use (fp64 poses are rounded: the slack covers that too); |x| is an operand
+// modifier, so the absolute values cost neither registers nor instructions.
+template <typename T>
+__device__ __forceinline__ void box_span(const float (&lo)[3], const float (&hi)[3], const Pose<T, 3, 3>& ps,
+                                         const GridDesc<3>& gd, float (&cmin)[3], float (&cmax)[3]) {
+    float c[3], h[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        c[j] = 0.5f * (lo[j] + hi[j]);
+        h[j] = 0.5f * (hi[j] - lo[j]);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float r0 = (float)ps.R[d], r1 = (float)ps.R[d + 3], r2 = (float)ps.R[d + 6], t = (float)ps.t[d];
+        const float sc = 0.5f * (float)gd.n[d];
+        const float cc = r0 * c[0] + r1 * c[1] + r2 * c[2] + (t + 1.f);
+        const float hh = fabsf(r0) * h[0] + fabsf(r1) * h[1] + fabsf(r2) * h[2];
+        const float mg = fabsf(r0 * c[0]) + fabsf(r1 * c[1]) + fabsf(r2 * c[2]) + (fabsf(t) + 1.f);
+        const float e = (mg + hh) * (sc * 4.8e-7f) + 1e-3f;
+        cmin[d] = (cc - hh) * sc - e;
+        cmax[d] = (cc + hh) * sc + e;
+    }
+}
+
+// Coordinate range a tile needs: a point contributes to cells of the tile iff its lower neighbour
+// ref0 = ceil(coord - 1/2) - 1 lies in [x0 - 1, x0 + T - 1], i.e. coord in (x0 - 1/2, x0 + T + 1/2].
+// The tiles of a border layer extend to infinity outwards: points outside the grid (rejected by the
+// range test of the arithmetic) are then visited by a border tile, which owns them in the pullback
+// (their gradients are zeros that somebody has to store).
+struct TileRange {
+    float lo[3], hi[3];
+};
+__device__ __forceinline__ TileRange tile_range(const int (&tc)[3], const OGeom& tg) {
+    const int T[3] = {kTX, kTY, kTZ};
+    TileRange r;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        r.lo[d] = tc[d] == 0 ? -__builtin_inff() : (float)(tc[d] * T[d]) - 0.5f;
+        r.hi[d] = tc[d] == tg.nt[d] - 1 ? __builtin_inff() : (float)(tc[d] * T[d] + T[d]) + 0.5f;
+    }
+    return r;
+}
+__device__ __forceinline__ bool span_hits(const float (&cmin)[3], const float (&cmax)[3], const TileRange& r) {
+    bool miss = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) miss = miss || (cmax[d] < r.lo[d]) || (cmin[d] > r.hi[d]);
+    return !miss;
+}
+
+__device__ __forceinline__ void tile_coords(int tile, const OGeom& tg, int (&tc)[3], int (&x0)[3]) {
+    const int T[3] = {kTX, kTY, kTZ};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        tc[d] = tile % tg.nt[d];
+        tile /= tg.nt[d];
+        x0[d] = tc[d] * T[d];
+    }
+}
+
+// A wave-uniform floating-point value the compiler computed with vector instructions (this chip has
+// no scalar float ALU) sits in a vector register for the whole kernel; through readfirstlane it
+// lives in scalar registers instead -- the tile kernels hoist a dozen of these (scales, origins).
+__device__ __forceinline__ float uniform(float x) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+__device__ __forceinline__ double uniform(double x) {
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// src/raster.jl:88-99 with the loop invariants (origin = -1 - t, scale = n / 2, n as T) held in
+// scalar registers; the same operations in the same order as ref_and_deltas (dpr_device.h)
+template <typename T> struct OwnXform {
+    T origin[3], scale[3], nf[3];
+};
+template <typename T>
+__device__ __forceinline__ OwnXform<T> own_xform(const Pose<T, 3, 3>& ps, const GridDesc<3>& gd) {
+    OwnXform<T> xf;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        xf.origin[d] = uniform(T(-1) - ps.t[d]);
+        xf.scale[d] = uniform(T(gd.n[d]) / T(2));
+        xf.nf[d] = uniform(T(gd.n[d]));
+    }
+    return xf;
+}
+
+__device__ __forceinline__ float f_down(float x) { return x; }
+__device__ __forceinline__ float f_up(float x) { return x; }
+__device__ __forceinline__ float f_down(double x) { return __double2float_rd(x); }
+__device__ __forceinline__ float f_up(double x) { return __double2float_ru(x); }
+
+// 16 bytes at a time where the caller's buffer allows it (`vec`: wave-uniform)
+template <typename T, int N> __device__ __forceinline__ void load_run(const T* __restrict__ src, bool vec, T (&v)[N]) {
+    constexpr int PER = 16 / sizeof(T);
+    static_assert(N % PER == 0, "whole 16-byte vectors");
+    if (vec) {
+        typedef T VecT __attribute__((ext_vector_type(PER)));
+#pragma unroll
+        for (int k = 0; k < N / PER; ++k) {
+            const VecT x = ((const VecT*)src)[k];
+#pragma unroll
+            for (int e = 0; e < PER; ++e) v[k * PER + e] = x[e];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = src[k];
+    }
+}
+
+// ---------------------------------------------------------------- boxes
+// One block per chunk of 1024 points; thread t owns points 4t .. 4t + 3 of it, four threads a
+// sub-chunk.  Also clears the control words of the plan (first block).
+template <typename T>
+__global__ __launch_bounds__(256) void k_own_boxes(int64_t P, const T* __restrict__ points,
+                                                   const T* __restrict__ pw, int vec_ok,
+                                                   Box0* __restrict__ b0, Box1* __restrict__ b1,
+                                                   uint32_t* __restrict__ ctl, int ctl_words) {
+    __shared__ float red[4][8];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < ctl_words; i += 256) ctl[i] = 0u;
+    const int64_t c = blockIdx.x;
+    const int64_t p0 = c * kL1 + (int64_t)threadIdx.x * 4;
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, mw = 0.f;
+    bool bad = false;
+    if (p0 < P) {
+        T v[12];
+        const bool full = p0 + 4 <= P;
+        if (full) {
+            load_run<T, 12>(points + p0 * 3, vec_ok != 0, v);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int64_t p = p0 + k / 3;
+                v[k] = points[(p < P ? p : P - 1) * 3 + k % 3];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const T x = v[q * 3 + j];
+                bad = bad || !(fabs((double)x) < (double)inf);
+                lo[j] = fminf(lo[j], f_down(x));
+                hi[j] = fmaxf(hi[j], f_up(x));
+            }
+        }
+        if (pw) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t p = p0 + q;
+                const T w = pw[p < P ? p : P - 1];
+                const float a = (w == w) ? fabsf((float)w) : inf;  // NaN weights: f64 sums (IEEE)
+                mw = fmaxf(mw, a);
+            }
+        }
+    }
+    // sub-chunk = 4 neighbouring lanes
+    int badi = bad ? 1 : 0;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, kWave));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], o, kWave));
+        }
+        badi |= __shfl_xor(badi, o, kWave);
+    }
+    if (badi) {  // a NaN / Inf coordinate: the box is everything (every tile looks at these points)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lo[j] = -inf;
+            hi[j] = inf;
+        }
+    }
+    if ((threadIdx.x & 3) == 0 && p0 < P) {
+        Box0 b;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            b.lo[j] = lo[j];
+            b.hi[j] = hi[j];
+        }
+        b0[c * kFan + threadIdx.x / 4] = b;
+    }
+    // chunk = the block
+#pragma unroll
+    for (int o = 4; o < kWave; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, kWave));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], o, kWave));
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            red[wave][j] = lo[j];
+            red[wave][3 + j] = hi[j];
+        }
+        red[wave][6] = mw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Box1 b;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            b.lo[j] = fminf(fminf(red[0][j], red[1][j]), fminf(red[2][j], red[3][j]));
+            b.hi[j] = fmaxf(fmaxf(red[0][3 + j], red[1][3 + j]), fmaxf(red[2][3 + j], red[3][3 + j]));
+        }
+        b.maxw = fmaxf(fmaxf(red[0][6], red[1][6]), fmaxf(red[2][6], red[3][6]));
+        b.pad = 0.f;
+        b1[c] = b;
+    }
+}
+
+// level-2 boxes: one wave per 64 chunks
+__global__ __launch_bounds__(256) void k_own_boxes2(int64_t nL1, const Box1* __restrict__ b1,
+                                                    Box1* __restrict__ b2) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t c2 = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
+    const int64_t c = c2 * kL2 + lane;
+    if (c2 * kL2 >= nL1) return;  // (uniform)
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, mw = 0.f;
+    if (c < nL1) {
+        const Box1 b = b1[c];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lo[j] = b.lo[j];
+            hi[j] = b.hi[j];
+        }
+        mw = b.maxw;
+    }
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, kWave));
+            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], o, kWave));
+        }
+        mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
+    }
+    if (lane == 0) {
+        Box1 b;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            b.lo[j] = lo[j];
+            b.hi[j] = hi[j];
+        }
+        b.maxw = mw;
+        b.pad = 0.f;
+        b2[c2] = b;
+    }
+}
+
+// ---------------------------------------------------------------- what a KEEP forward leaves
+struct OwnHeader {
+    uint32_t magic, elem;
+    int64_t P, B;
+    int32_t grid[3];
+    uint32_t state;  // 1: valid
+    uint64_t points, pw;
+    uint32_t pose_bits[kOwnBw][2];  // a hash of every pose's 12 values (64 bits)
+};
+constexpr uint32_t kOwnMagic = 0x4f574e35u;  // "OWN5"
+
+template <typename T>
+__device__ __forceinline__ void pose_hash(const T* __restrict__ rot, const T* __restrict__ trans,
+                                          int64_t b, uint32_t (&h)[2]) {
+    // FNV-1a over the bit patterns: a pose that changed by one ulp is another pose
+    uint64_t x = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) {
+        x ^= v;
+        x *= 1099511628211ull;
+    };
+    for (int k = 0; k < 9; ++k) {
+        if constexpr (sizeof(T) == 4) mix(__float_as_uint((float)rot[b * 9 + k]));
+        else mix((uint64_t)__double_as_longlong((double)rot[b * 9 + k]));
+    }
+    for (int k = 0; k < 3; ++k) {
+        if constexpr (sizeof(T) == 4) mix(__float_as_uint((float)trans[b * 3 + k]));
+        else mix((uint64_t)__double_as_longlong((double)trans[b * 3 + k]));
+    }
+    h[0] = (uint32_t)x;
+    h[1] = (uint32_t)(x >> 32);
+}
+
+// ---------------------------------------------------------------- plan
+struct OwnPlanArgs {
+    char* ws;
+    size_t off_ctl, off_rec, off_list, off_items, off_split, off_hdr;
+    size_t rec_stride, list_stride, items_stride, split_stride;  // per pose copy (bytes)
+    uint32_t list_cap;   // entries per pose
+    int max_items;       // per bucket
+    int max_slabs;       // per pose group
+    int max_split;       // per pose
+    uint32_t cap;        // visits per part above which a tile is split
+    int fixed;           // fixed-point forward wanted
+    int keep;            // write the header
+};
+
+// block per (tile, pose copy): walks the box hierarchy top down.  Wave w of the block takes the
+// w-th quarter of the level-2 boxes, so the candidate list comes out in ascending chunk order
+// whatever the timing (two passes: count, then write at the reserved offset).
+template <typename T>
+__global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int64_t P, int64_t B,
+                                                  int64_t nL1, int64_t nL2, const Box1* __restrict__ b1,
+                                                  const Box1* __restrict__ b2,
+                                                  const T* __restrict__ rot, const T* __restrict__ trans,
+                                                  const T* __restrict__ ow, const T* points,
+                                                  const T* pw, int64_t bfirst, OwnPlanArgs pa) {
+    __shared__ uint32_t s_cnt[4], s_base[4], s_begin;
+    __shared__ float s_est[4], s_mw[4];
+    const int tile = blockIdx.x, bl = blockIdx.y;
+    const int64_t b = bfirst + bl;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    int tc[3], x0[3];
+    tile_coords(tile, tg, tc, x0);
+    const TileRange tr = tile_range(tc, tg);
+    const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, nullptr, b);
+    const int64_t per = ((nL2 + 3) / 4 + kWave - 1) / kWave * kWave;
+    const int64_t i0 = wave * per, i1 = (i0 + per < nL2) ? i0 + per : nL2;
+    uint32_t* ctl = (uint32_t*)(pa.ws + pa.off_ctl) + (size_t)bl * kCtlWords;
+    uint32_t* ctl0 = (uint32_t*)(pa.ws + pa.off_ctl);
+    // calls f(chunk, hit, box) for the 64 chunks under every level-2 box that meets the tile
+    auto descend = [&](auto f) {
+        for (int64_t i = i0; i < i1; i += kWave) {  // (uniform)
+            bool hit2 = false;
+            if (i + lane < i1) {
+                const Box1 bx = b2[i + lane];
+                float cmin[3], cmax[3];
+                box_span<T>(bx.lo, bx.hi, ps, gd, cmin, cmax);
+                hit2 = span_hits(cmin, cmax, tr);
+            }
+            unsigned long long m = __ballot(hit2);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int64_t c = (i + l) * kL2 + lane;
+                bool hit = false;
+                Box1 bx;
+                float cmin[3], cmax[3];
+                if (c < nL1) {
+                    bx = b1[c];
+                    box_span<T>(bx.lo, bx.hi, ps, gd, cmin, cmax);
+                    hit = span_hits(cmin, cmax, tr);
+                }
+                f(c, hit, bx, cmin, cmax);
+            }
+        }
+    };
+    // pass 1: count, load estimate, largest weight
+    uint32_t cnt = 0;
+    float est = 0.f, mw = 0.f;
+    descend([&](int64_t c, bool hit, const Box1& bx, const float (&cmin)[3], const float (&cmax)[3]) {
+        if (hit) {
+            float f = 1.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float w = cmax[d] - cmin[d];
+                const float ov = fminf(cmax[d], tr.hi[d]) - fmaxf(cmin[d], tr.lo[d]);
+                float fr = ov / w;
+                fr = (fr >= 0.f && fr <= 1.f) ? fr : 1.f;  // NaN / Inf widths: the whole box
+                f *= fr;
+            }
+            const int64_t npts = (c + 1) * kL1 <= P ? kL1 : P - c * kL1;
+            est += f * (float)npts;
+            mw = fmaxf(mw, bx.maxw);
+        }
+        cnt += (uint32_t)__popcll(__ballot(hit));
+    });
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        est += __shfl_xor(est, o, kWave);
+        mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
+    }
+    if (lane == 0) {
+        s_cnt[wave] = cnt;
+        s_est[wave] = est;
+        s_mw[wave] = mw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const float e = s_est[0] + s_est[1] + s_est[2] + s_est[3];
+        const float m = fmaxf(fmaxf(s_mw[0], s_mw[1]), fmaxf(s_mw[2], s_mw[3]));
+        s_base[0] = 0;
+        s_base[1] = s_cnt[0];
+        s_base[2] = s_cnt[0] + s_cnt[1];
+        s_base[3] = s_cnt[0] + s_cnt[1] + s_cnt[2];
+        uint32_t begin = 0;
+        if (total) {
+            begin = atomicAdd(&ctl[0], total);
+            if (begin > pa.list_cap || total > pa.list_cap - begin) {
+                begin = 0xffffffffu;  // the list does not fit: the tile kernels scan every chunk
+                ctl[3] = 1u;
+            }
+        }
+        // parts: every n-th candidate each
+        uint32_t ev = e < 4.0e9f ? (uint32_t)e : 4000000000u;
+        uint32_t np = 1;
+        if (ev > pa.cap) {
+            np = (ev + pa.cap - 1) / pa.cap;
+            if (np > (uint32_t)kMaxParts) np = kMaxParts;
+            const uint32_t units = begin == 0xffffffffu ? (uint32_t)nL1 : total;
+            if (np > units) np = units ? units : 1;
+        }
+        uint32_t first_slab = 0;
+        if (np > 1) {
+            first_slab = atomicAdd(&ctl0[1], np);
+            uint32_t sidx = 0;
+            if (first_slab + np > (uint32_t)pa.max_slabs ||
+                (sidx = atomicAdd(&ctl[2], 1u)) >= (uint32_t)pa.max_split) {
+                np = 1;  // no slab left: one long item (slower, still right)
+                first_slab = 0;
+            } else {
+                ((uint32_t*)(pa.ws + pa.off_split + (size_t)bl * pa.split_stride))[sidx] = (uint32_t)tile;
+            }
+        }
+        // fixed-point exponent of the tile: |contribution| <= |out_weight| * max|pw| of the
+        // candidates, at most 1024 contributions per candidate to one cell
+        const float owv = ow ? fabsf((float)ow[b]) : 1.f;
+        const float maxw = (sizeof(T) == 4) ? owv * (pw ? m : 1.f) : __builtin_inff();
+        const uint64_t nmax = (uint64_t)(total ? total : 1) * kL1;
+        const int sexp = fix_exponent(maxw, nmax < 0x7fffffffu ? (uint32_t)nmax : 0x7fffffffu, pa.fixed);
+        TileRec rec;
+        rec.begin = begin;
+        rec.count = total;
+        rec.sexp = sexp;
+        rec.parts = np | (first_slab << 8);
+        ((TileRec*)(pa.ws + pa.off_rec + (size_t)bl * pa.rec_stride))[tile] = rec;
+        // work items, bucketed by size
+        const uint32_t epart = ev / np;
+        int bucket = epart < 512 ? 0 : (32 - __clz((int)epart)) - 9;
+        if (bucket > kBuckets - 1) bucket = kBuckets - 1;
+        const uint32_t slot = atomicAdd(&ctl[16 + bucket], np);
+        uint2* items = (uint2*)(pa.ws + pa.off_items + (size_t)bl * pa.items_stride) + (size_t)bucket * pa.max_items;
+        for (uint32_t k = 0; k < np; ++k)
+            if (slot + k < (uint32_t)pa.max_items) items[slot + k] = make_uint2((uint32_t)tile, k | (np << 16));
+        s_begin = begin;
+        if (pa.keep && tile == 0) {
+            OwnHeader* h = (OwnHeader*)(pa.ws + pa.off_hdr);
+            if (bl == 0) {
+                h->magic = kOwnMagic;
+                h->elem = sizeof(T);
+                h->P = P;
+                h->B = B;
+                for (int d = 0; d < 3; ++d) h->grid[d] = gd.n[d];
+                h->points = (uint64_t)(uintptr_t)points;
+                h->pw = (uint64_t)(uintptr_t)pw;
+                h->state = 1u;
+            }
+            pose_hash<T>(rot, trans, b, h->pose_bits[bl]);
+        }
+    }
+    __syncthreads();
+    const uint32_t begin = s_begin;
+    if (begin == 0xffffffffu) return;
+    uint32_t* list = (uint32_t*)(pa.ws + pa.off_list + (size_t)bl * pa.list_stride) + begin + s_base[wave];
+    uint32_t run = 0;
+    descend([&](int64_t c, bool hit, const Box1&, const float (&)[3], const float (&)[3]) {
+        const unsigned long long mask = __ballot(hit);
+        if (hit) list[run + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)c;
+        run += (uint32_t)__popcll(mask);
+    });
+}
+
+// ---------------------------------------------------------------- shared by the tile kernels
+struct OwnTileArgs {
+    const char* ws;
+    size_t off_ctl, off_rec, off_list, off_items, off_hdr;
+    size_t rec_stride, list_stride, items_stride;
+    int max_items;
+    int64_t nL1, nSC;
+    const Box0* b0;
+    const Box1* b1;
+};
+
+// work item of this block: buckets from the heaviest down
+__device__ __forceinline__ bool own_item(const OwnTileArgs& ta, int bl, uint32_t idx, uint32_t& tile,
+                                         uint32_t& part, uint32_t& nparts) {
+    const uint32_t* ctl = (const uint32_t*)(ta.ws + ta.off_ctl) + (size_t)bl * kCtlWords;
+    uint32_t cnt[kBuckets];
+#pragma unroll
+    for (int k = 0; k < kBuckets; ++k) cnt[k] = ctl[16 + k];
+    int bucket = -1;
+#pragma unroll
+    for (int k = kBuckets - 1; k >= 0; --k) {
+        const uint32_t c = cnt[k] < (uint32_t)ta.max_items ? cnt[k] : (uint32_t)ta.max_items;
+        if (bucket < 0) {
+            if (idx < c) bucket = k;
+            else idx -= c;
+        }
+    }
+    if (bucket < 0) return false;
+    const uint2 it = ((const uint2*)(ta.ws + ta.off_items + (size_t)bl * ta.items_stride))[(size_t)bucket * ta.max_items + idx];
+    tile = it.x;
+    part = it.y & 0xffffu;
+    nparts = it.y >> 16;
+    return true;
+}
+
+// LDS the discovery loop needs (the tile kernels put it in front of their tile)
+struct OwnWalkLds {
+    uint32_t queue[kOW][kQueue];  // per wave: sub-chunks waiting for a full batch of 64
+    uint32_t pool[kOT];           // what the waves had left over (< 64 each), shared out again
+    uint32_t next, pool_n;
+    uint32_t pad[62];
+};
+
+// The discovery loop of a tile kernel.  Waves draw candidate chunks of the item from a counter in
+// LDS, test the 64 level-0 boxes of a chunk (one per lane; the boxes of the NEXT candidate are
+// requested before the current batch is worked on), queue the hits and call `visit(sc, have)` with
+// 64 queued sub-chunks at a time (one per lane).  What a wave has left when the candidates run out
+// (< 64 sub-chunks) goes to a pool of the block, which the waves share out again in batches of 64:
+// without it every wave of the ~1000-sub-chunk items of the headline config ended on a half-empty
+// batch (36 % idle lanes).  One block barrier inside, reached exactly once by every wave.
+template <typename T, bool PREFETCH_BOXES, typename Visit>
+__device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const TileRec& rec, int bl, uint32_t part,
+                                         uint32_t nparts, const Pose<T, 3, 3>& ps, const GridDesc<3>& gd,
+                                         const TileRange& tr, OwnWalkLds* wl, Visit visit) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t* queue = wl->queue[wave];
+    // a tile whose candidate list did not fit its buffer (an incoherent cloud) takes EVERY chunk
+    // as a candidate: slow, never wrong
+    const bool overflow = rec.begin == 0xffffffffu;
+    const uint32_t* list = (const uint32_t*)(ta.ws + ta.off_list + (size_t)bl * ta.list_stride) + (overflow ? 0u : rec.begin);
+    const uint32_t units = overflow ? (uint32_t)ta.nL1 : rec.count;
+    uint32_t qn = 0;
+    int64_t sc_mine = 0;
+    Box0 bx;
+    // next candidate chunk of this wave: its level-0 boxes are requested here, tested later
+    auto acquire = [&]() -> bool {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&wl->next, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const uint64_t u = (uint64_t)part + (uint64_t)k * nparts;
+        if (u >= units) return false;
+        const uint32_t c = overflow ? (uint32_t)u : list[u];
+        sc_mine = (int64_t)c * kFan + lane;
+        // (PREFETCH_BOXES: requested now, tested after the batch in between -- six registers a kernel
+        // whose batch needs them all does without)
+        if (PREFETCH_BOXES && sc_mine < ta.nSC) bx = ta.b0[sc_mine];
+        return true;
+    };
+    bool have_c = acquire();
+    int stage = 0;  // 0: candidates, 1: leftovers to the pool, 2: pooled batches
+    uint32_t pool_pos = 0, pool_total = 0;
+#ifdef DPR_OWN_STATS
+    uint32_t st_batches = 0, st_take = 0, st_tests = 0;
+#endif
+    for (;;) {
+        if (qn >= (uint32_t)kWave || (stage == 2 && qn > 0)) {
+            const uint32_t take = qn >= (uint32_t)kWave ? kWave : qn;
+            const uint32_t base = qn - take;
+            // lanes take entries a stride of 17 apart: queue neighbours are neighbours in space
+            const uint32_t e = ((uint32_t)lane * 17u) & (kWave - 1);
+            const bool have = e < take;
+            const uint32_t sc = queue[base + (have ? e : 0u)];  // (idle lanes: a valid sub-chunk, not worked on)
+#ifdef DPR_OWN_STATS
+            ++st_batches;
+            st_take += take;
+#endif
+            visit(sc, have);
+            qn = base;
+            continue;
+        }
+        if (stage == 0) {
+            if (have_c) {
+                bool hit = false;
+                if (sc_mine < ta.nSC) {
+                    if (!PREFETCH_BOXES) bx = ta.b0[sc_mine];
+                    float cmin[3], cmax[3];
+                    box_span<T>(bx.lo, bx.hi, ps, gd, cmin, cmax);
+                    hit = span_hits(cmin, cmax, tr);
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (hit) queue[qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)sc_mine;
+                qn += (uint32_t)__popcll(mask);
+#ifdef DPR_OWN_STATS
+                ++st_tests;
+#endif
+                have_c = acquire();
+                continue;
+            }
+            // the candidates are gone: what is left (< 64) goes to the block's pool
+            uint32_t pos = 0;
+            if (lane == 0 && qn) pos = atomicAdd(&wl->pool_n, qn);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if ((uint32_t)lane < qn) wl->pool[pos + lane] = queue[lane];
+            qn = 0;
+            __syncthreads();
+            pool_total = wl->pool_n;
+            pool_pos = (uint32_t)wave * kWave;
+            stage = 2;
+        }
+        if (pool_pos >= pool_total) break;
+        const uint32_t n = pool_total - pool_pos < (uint32_t)kWave ? pool_total - pool_pos : (uint32_t)kWave;
+        if ((uint32_t)lane < n) queue[lane] = wl->pool[pool_pos + lane];
+        qn = n;
+        pool_pos += kOW * kWave;
+    }
+#ifdef DPR_OWN_STATS
+    if (lane == 0) {
+        uint32_t* ctl = (uint32_t*)(ta.ws + ta.off_ctl);
+        atomicAdd(&ctl[6], st_batches);
+        atomicAdd(&ctl[7], st_take);
+        atomicAdd(&ctl[9], st_tests);
+    }
+#endif
+}
+
+// points per 48-byte round of a lane: 4 (fp32) / 2 (fp64)
+template <typename T> __host__ __device__ constexpr int own_ppr() { return 16 / (int)sizeof(T); }
+
+// the 16 points of a lane's sub-chunk, PPR per 48-byte round, the next round requested before the
+// current one is worked on; body(point index in the sub-chunk, live, pt[3], w)
+template <typename T, bool HAS_PW, typename Body>
+__device__ __forceinline__ void own_points(uint32_t sc, bool have, int64_t P, const T* __restrict__ points,
+                                           const T* __restrict__ pw, bool vec, Body body) {
+    constexpr int PPR = own_ppr<T>();
+    // (a lane without a sub-chunk was handed a valid one by own_walk: it loads like the others and
+    // treats every point as dead)
+    const int64_t p0 = (int64_t)sc * kSC;
+    const bool full = p0 + kSC <= P;  // false only for the last sub-chunk of the cloud
+    const int npts = have ? (full ? kSC : (int)(P - p0)) : 0;
+    const T* src = points + p0 * 3;
+    T cur[PPR * 3], nxt[PPR * 3], wc[PPR], wn[PPR];
+    auto fetch = [&](int r, T (&v)[PPR * 3], T (&w)[PPR]) {
+        if (full) {
+            load_run<T, PPR * 3>(src + r * PPR * 3, vec, v);
+            if constexpr (HAS_PW) load_run<T, PPR>(pw + p0 + r * PPR, vec, w);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPR; ++q) {
+                const int64_t p = p0 + r * PPR + q;
+                const int64_t pc = p < P ? p : P - 1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[q * 3 + j] = points[pc * 3 + j];
+                if constexpr (HAS_PW) w[q] = pw[pc];
+            }
+        }
+    };
+    fetch(0, nxt, wn);
+#pragma unroll 1
+    for (int r = 0; r < kSC / PPR; ++r) {
+#pragma unroll
+        for (int k = 0; k < PPR * 3; ++k) cur[k] = nxt[k];
+#pragma unroll
+        for (int k = 0; k < PPR; ++k) wc[k] = wn[k];
+        if (r + 1 < kSC / PPR) fetch(r + 1, nxt, wn);
+#pragma unroll
+        for (int q = 0; q < PPR; ++q) {
+            const T pt[3] = {cur[q * 3], cur[q * 3 + 1], cur[q * 3 + 2]};
+            body(r * PPR + q, r * PPR + q < npts, pt, HAS_PW ? wc[q] : T(1));
+        }
+    }
+}
+
+// the same one point at a time (12- / 24-byte loads, the next point requested before the current
+// one is worked on): for a body that needs the registers itself (the pullback)
+template <typename T, bool HAS_PW, typename Body>
+__device__ __forceinline__ void own_points_single(uint32_t sc, bool have, int64_t P, const T* __restrict__ points,
+                                                  const T* __restrict__ pw, Body body) {
+    const int64_t p0 = (int64_t)sc * kSC;
+    const int64_t left = P - p0;
+    const int npts = have ? (left < kSC ? (int)left : kSC) : 0;
+    const int last = left < kSC ? (int)left - 1 : kSC - 1;  // (reads stay inside the cloud)
+    const T* src = points + p0 * 3;
+    T nxt[3], wn = T(1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) nxt[j] = src[j];
+    if constexpr (HAS_PW) wn = pw[p0];
+#pragma unroll 1
+    for (int i = 0; i < kSC; ++i) {
+        const T pt[3] = {nxt[0], nxt[1], nxt[2]};
+        const T w = wn;
+        const int in = i + 1 < last ? i + 1 : last;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nxt[j] = src[in * 3 + j];
+        if constexpr (HAS_PW) wn = pw[p0 + in];
+        body(i, i < npts, pt, w);
+    }
+}
+
+// ---------------------------------------------------------------- forward
+template <typename T, bool HAS_PW>
+__global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int64_t P,
+                                                   const T* __restrict__ points, const T* __restrict__ pw,
+                                                   int vec_ok, const T* __restrict__ rot,
+                                                   const T* __restrict__ trans, const T* __restrict__ ow,
+                                                   const T* __restrict__ bg, int64_t bfirst,
+                                                   OwnTileArgs ta, unsigned long long* __restrict__ slabs,
+                                                   T* __restrict__ out) {
+    extern __shared__ unsigned char smem[];
+    OwnWalkLds* wl = (OwnWalkLds*)smem;
+    double* acc = (double*)(smem + sizeof(OwnWalkLds));  // kPCells cells
+    const int bl = blockIdx.y;
+    const int64_t b = bfirst + bl;
+    uint32_t tile, part, nparts;
+    if (!own_item(ta, bl, blockIdx.x, tile, part, nparts)) return;
+#ifdef DPR_OWN_STATS
+    const uint64_t st_t0 = wall_clock64();
+#endif
+    const TileRec rec = ((const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride))[tile];
+    int tc[3], x0[3];
+    tile_coords((int)tile, tg, tc, x0);
+    const double bgv = bg ? (double)bg[b] : 0.0;
+    T* o = out + b * gd.G;
+    const bool vec_out = (gd.n[0] & 3) == 0 && (((uintptr_t)o) & 15) == 0;
+    if (rec.count == 0 && rec.begin != 0xffffffffu) {
+        // no candidate: the tile is background
+        for (int i = threadIdx.x; i < kCells; i += kOT) {
+            const int x = i % kTX, y = (i / kTX) % kTY, z = i / (kTX * kTY);
+            const int g0 = x0[0] + x, g1 = x0[1] + y, g2 = x0[2] + z;
+            if (g0 < gd.n[0] && g1 < gd.n[1] && g2 < gd.n[2])
+                __builtin_nontemporal_store((T)bgv, &o[((size_t)g2 * gd.n[1] + g1) * gd.n[0] + g0]);
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < kPCells; i += kOT) acc[i] = 0.0;
+    if (threadIdx.x == 0) {
+        wl->next = 0u;
+        wl->pool_n = 0u;
+    }
+    const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
+    const TileRange tr = tile_range(tc, tg);
+    const FixScale fs = fix_scale_from_exponent(rec.sexp);
+    const OwnXform<T> xf = own_xform<T>(ps, gd);
+    __syncthreads();
+#ifdef DPR_OWN_STATS
+    uint32_t st_vis = 0, st_touch = 0;
+#endif
+    auto run = [&](auto fix_tag) {
+        constexpr bool FIX = decltype(fix_tag)::value;
+        auto visit = [&](uint32_t sc, bool have) {
+            own_points<T, HAS_PW>(sc, have, P, points, pw, vec_ok != 0, [&](int, bool live, const T (&pt)[3], T pwi) {
+                int ref0[3];
+                T dlo[3];
+                bool ok = live;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    T proj = ps.R[d] * pt[0];
+                    proj = proj + ps.R[d + 3] * pt[1];
+                    proj = proj + ps.R[d + 6] * pt[2];
+                    const T coord = (proj - xf.origin[d]) * xf.scale[d];
+                    const T c = coord - T(0.5);
+                    ok = ok && (c > T(-1)) && (c <= xf.nf[d]);
+                    const T r = ceil_t<T>(c);
+                    ref0[d] = ok ? (int)r - 1 : 0;
+                    dlo[d] = coord - (r - T(0.5));
+                }
+                // padded tile coordinates of the lower neighbour: 0 .. T
+                const uint32_t l0 = (uint32_t)(ref0[0] - x0[0] + 1), l1 = (uint32_t)(ref0[1] - x0[1] + 1),
+                               l2 = (uint32_t)(ref0[2] - x0[2] + 1);
+                const bool touches = ok && l0 <= (uint32_t)kTX && l1 <= (uint32_t)kTY && l2 <= (uint32_t)kTZ;
+#ifdef DPR_OWN_STATS
+                st_vis += live ? 1u : 0u;
+                st_touch += touches ? 1u : 0u;
+#endif
+                if (touches) {
+                    const T w = HAS_PW ? ps.ow * pwi : ps.ow;  // src/raster.jl:52
+                    double* cell = acc + (l0 + kPX * l1 + kPX * kPY * l2);
+                    // all eight neighbours have a cell (pad cells, and owned cells beyond the grid
+                    // edge, are never flushed: the individual drop of src/raster.jl:62)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        cell_add<FIX, T>(cell + ((s & 1) + kPX * ((s >> 1) & 1) + kPX * kPY * (s >> 2)),
+                                         voxel_weight<T, 3>(dlo, s, w), fs);
+                }
+            });
+        };
+        own_walk<T, true>(ta, rec, bl, part, nparts, ps, gd, tr, wl, visit);
+    };
+    if (fs.mul != 0.0) run(std::true_type{});  // (uniform)
+    else run(std::false_type{});
+#ifdef DPR_OWN_STATS
+    {
+        uint32_t* ctl = (uint32_t*)(ta.ws + ta.off_ctl);
+        const uint32_t a = (uint32_t)wave_sum<int>((int)st_vis), c = (uint32_t)wave_sum<int>((int)st_touch);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ctl[4], a);
+            atomicAdd(&ctl[5], c);
+        }
+        if (threadIdx.x == 0) {
+            atomicAdd(&ctl[8], 1u);
+            const uint32_t dt = (uint32_t)(wall_clock64() - st_t0);
+            atomicAdd(&ctl[10], dt);
+            atomicMax(&ctl[11], dt);
+        }
+    }
+#endif
+    __syncthreads();
+    // flush the owned cells: thread -> 4 cells along x
+    const bool to_slab = nparts > 1;
+    // (part of a split tile: the raw 64-bit cells go to this part's slab; k_own_combine sums)
+    unsigned long long* slab = slabs + (size_t)((rec.parts >> 8) + part) * kCells;
+    for (int q = threadIdx.x; q < kCells / 4; q += kOT) {
+        const int x = (q % (kTX / 4)) * 4, y = (q / (kTX / 4)) % kTY, z = q / (kTX / 4 * kTY);
+        const double* src = acc + ((x + 1) + kPX * (y + 1) + kPX * kPY * (z + 1));
+        if (to_slab) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) slab[q * 4 + e] = (unsigned long long)__double_as_longlong(src[e]);
+            continue;
+        }
+        const int g0 = x0[0] + x, g1 = x0[1] + y, g2 = x0[2] + z;
+        if (g1 >= gd.n[1] || g2 >= gd.n[2] || g0 >= gd.n[0]) continue;
+        T* dst = &o[((size_t)g2 * gd.n[1] + g1) * gd.n[0] + g0];
+        T v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (T)(bgv + fix_value(src[e], fs));
+        if (vec_out && sizeof(T) == 4) {  // (g0 + 3 < n0 since n0 % 4 == 0)
+            typedef T V4 __attribute__((ext_vector_type(4)));
+            V4 vv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = v[e];
+            __builtin_nontemporal_store(vv, (V4*)dst);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (g0 + e < gd.n[0]) __builtin_nontemporal_store(v[e], dst + e);
+        }
+    }
+}
+
+// split tiles: out = background + sum of the parts' raw tiles (fixed point: integer sums, exact;
+// f64: a fixed order).  Four blocks per split tile.
+template <typename T>
+__global__ __launch_bounds__(kOT) void k_own_combine(OGeom tg, GridDesc<3> gd, const T* __restrict__ bg,
+                                                     int64_t bfirst, OwnTileArgs ta, size_t off_split,
+                                                     size_t split_stride, int max_split,
+                                                     const unsigned long long* __restrict__ slabs,
+                                                     T* __restrict__ out) {
+    const int bl = blockIdx.y;
+    const int64_t b = bfirst + bl;
+    const uint32_t* ctl = (const uint32_t*)(ta.ws + ta.off_ctl) + (size_t)bl * kCtlWords;
+    uint32_t nsplit = ctl[2];
+    if (nsplit > (uint32_t)max_split) nsplit = max_split;
+    const uint32_t* split = (const uint32_t*)(ta.ws + off_split + (size_t)bl * split_stride);
+    const double bgv = bg ? (double)bg[b] : 0.0;
+    T* o = out + b * gd.G;
+    constexpr int kQuarter = (kCells + 3) / 4;
+    for (uint32_t s = blockIdx.x; s < nsplit * 4u; s += gridDim.x) {
+        const uint32_t tile = split[s >> 2];
+        const int i_lo = (int)(s & 3u) * kQuarter, i_hi = i_lo + kQuarter < kCells ? i_lo + kQuarter : kCells;
+        const TileRec rec = ((const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride))[tile];
+        const uint32_t np = rec.parts & 0xffu, first = rec.parts >> 8;
+        const FixScale fs = fix_scale_from_exponent(rec.sexp);
+        int tc[3], x0[3];
+        tile_coords((int)tile, tg, tc, x0);
+        for (int i = i_lo + threadIdx.x; i < i_hi; i += kOT) {
+            const int x = i % kTX, y = (i / kTX) % kTY, z = i / (kTX * kTY);
+            const int g0 = x0[0] + x, g1 = x0[1] + y, g2 = x0[2] + z;
+            if (g0 >= gd.n[0] || g1 >= gd.n[1] || g2 >= gd.n[2]) continue;
+            const unsigned long long* sp = slabs + (size_t)first * kCells + i;
+            double v;
+            if (fs.mul != 0.0) {
+                unsigned long long a = 0;
+                uint32_t k = 0;
+                for (; k + 4 <= np; k += 4) {
+                    const unsigned long long a0 = sp[(size_t)k * kCells], a1 = sp[(size_t)(k + 1) * kCells],
+                                             a2 = sp[(size_t)(k + 2) * kCells], a3 = sp[(size_t)(k + 3) * kCells];
+                    a += a0 + a1 + a2 + a3;
+                }
+                for (; k < np; ++k) a += sp[(size_t)k * kCells];
+                v = fix_value(__longlong_as_double((long long)a), fs);
+            } else {
+                v = 0.0;
+                for (uint32_t k = 0; k < np; ++k) v += __longlong_as_double((long long)sp[(size_t)k * kCells]);
+            }
+            __builtin_nontemporal_store((T)(bgv + v), &o[((size_t)g2 * gd.n[1] + g1) * gd.n[0] + g0]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- pullback
+constexpr int kNVal = 3 * 3 + 3 + 2;  // d rotation, d translation, d out_weight, sum(ds_dout)
+
+struct OwnGatherLds {
+    OwnWalkLds walk;
+    double red[kOW][kNVal];
+};
+
+// A REUSE pullback looks at the header the KEEP forward left: same problem, same buffers, same
+// poses?  (uniform per block; cheap: ~20 scalar loads)
+template <typename T>
+__device__ __forceinline__ bool own_header_ok(const OwnTileArgs& ta, const GridDesc<3>& gd, int64_t P,
+                                              int64_t B, const T* points, const T* pw,
+                                              const T* __restrict__ rot, const T* __restrict__ trans,
+                                              int64_t b, int bl) {
+    const OwnHeader* h = (const OwnHeader*)(ta.ws + ta.off_hdr);
+    bool ok = h->magic == kOwnMagic && h->elem == sizeof(T) && h->P == P && h->B == B && h->state == 1u &&
+              h->points == (uint64_t)(uintptr_t)points && h->pw == (uint64_t)(uintptr_t)pw;
+    for (int d = 0; d < 3; ++d) ok = ok && h->grid[d] == gd.n[d];
+    uint32_t hb[2];
+    pose_hash<T>(rot, trans, b, hb);
+    return ok && h->pose_bits[bl][0] == hb[0] && h->pose_bits[bl][1] == hb[1];
+}
+
+template <typename T, bool HAS_PW, bool FIRST>
+__global__ __launch_bounds__(kOT) void k_own_gather(OGeom tg, GridDesc<3> gd, int64_t P, int64_t B,
+                                                    const T* __restrict__ points, const T* __restrict__ pw,
+                                                    int vec_ok, const T* __restrict__ g,
+                                                    const T* __restrict__ rot, const T* __restrict__ trans,
+                                                    const T* __restrict__ ow, int64_t b, int bl, int reuse,
+                                                    OwnTileArgs ta, T* __restrict__ ds_dpoints,
+                                                    T* __restrict__ ds_dpw, double* __restrict__ partials,
+                                                    int NTp /* partial slots: NT + max_slabs */) {
+    extern __shared__ unsigned char smem[];
+    OwnGatherLds* sl = (OwnGatherLds*)smem;
+    T* tile_g = (T*)(smem + sizeof(OwnGatherLds));
+    if (reuse && !own_header_ok<T>(ta, gd, P, B, points, pw, rot, trans, b, bl)) {
+        // nothing can be trusted: every block NaN-fills its share of the point gradients; the
+        // reduce kernel sees the same header and stores NaN per-pose sums
+        const T nanv = T(__builtin_nanf(""));
+        for (int64_t i = (int64_t)blockIdx.x * kOT + threadIdx.x; i < P; i += (int64_t)gridDim.x * kOT) {
+            for (int j = 0; j < 3; ++j) ds_dpoints[i * 3 + j] = nanv;
+            if (ds_dpw) ds_dpw[i] = nanv;
+        }
+        return;
+    }
+    uint32_t tile, part, nparts;
+    if (!own_item(ta, bl, blockIdx.x, tile, part, nparts)) return;
+    const TileRec rec = ((const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride))[tile];
+    int tc[3], x0[3];
+    tile_coords((int)tile, tg, tc, x0);
+    const T* gb = g + b * gd.G;
+    // stage the padded ds_dout tile (cells beyond the grid: 0); eight loads in flight per thread
+    double bg_sum = 0.0;
+    {
+        constexpr int IT = (kPCells + kOT - 1) / kOT, HB = 8;
+#pragma unroll 1
+        for (int k0 = 0; k0 < IT; k0 += HB) {
+            T v[HB];
+            bool own[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int i = threadIdx.x + (k0 + k) * kOT;
+                const int x = i % kPX, y = (i / kPX) % kPY, z = i / (kPX * kPY);
+                const int g0 = x0[0] - 1 + x, g1 = x0[1] - 1 + y, g2 = x0[2] - 1 + z;
+                const bool ok = i < kPCells && g0 >= 0 && g1 >= 0 && g2 >= 0 && g0 < gd.n[0] && g1 < gd.n[1] && g2 < gd.n[2];
+                const T xv = gb[ok ? ((size_t)g2 * gd.n[1] + g1) * gd.n[0] + g0 : 0];
+                v[k] = ok ? xv : T(0);
+                own[k] = ok && x >= 1 && x <= kTX && y >= 1 && y <= kTY && z >= 1 && z <= kTZ;
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int i = threadIdx.x + (k0 + k) * kOT;
+                if (i < kPCells) tile_g[i] = v[k];
+                if (own[k] && part == 0) bg_sum += (double)v[k];
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        sl->walk.next = 0u;
+        sl->walk.pool_n = 0u;
+    }
+    const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
+    const TileRange tr = tile_range(tc, tg);
+    const OwnXform<T> xf = own_xform<T>(ps, gd);
+    __syncthreads();
+    T vals[kNVal - 1];
+#pragma unroll
+    for (int k = 0; k < kNVal - 1; ++k) vals[k] = T(0);
+    auto visit = [&](uint32_t sc, bool have) {
+        own_points_single<T, HAS_PW>(sc, have, P, points, pw, [&](int i, bool live, const T (&pt)[3], T pwi) {
+            const int64_t p = (int64_t)sc * kSC + i;
+            // src/raster.jl:88-99 per axis, plus the owner tile of the point: the tile of its base
+            // voxel clamped into the grid (a rejected point belongs to a border tile; NaN -> 0)
+            int ref0[3];
+            T dlo[3];
+            bool ok = true, mine = live;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                T proj = ps.R[d] * pt[0];
+                proj = proj + ps.R[d + 3] * pt[1];
+                proj = proj + ps.R[d + 6] * pt[2];
+                const T coord = (proj - xf.origin[d]) * xf.scale[d];
+                const T c = coord - T(0.5);
+                const bool above = c > T(-1), below = c <= xf.nf[d];
+                const bool okd = above && below;
+                const T r_ = ceil_t<T>(c);
+                const int rd = okd ? (int)r_ - 1 : 0;
+                ref0[d] = rd;
+                dlo[d] = coord - (r_ - T(0.5));
+                const int Td = d == 0 ? kTX : (d == 1 ? kTY : kTZ);
+                int owner = (rd < 0 ? 0 : rd) / Td;
+                owner = !above ? 0 : (!below ? tg.nt[d] - 1 : owner);
+                mine = mine && owner == tc[d];
+                ok = ok && okd;
+            }
+            if (!mine) return;
+            T gout[3] = {T(0), T(0), T(0)}, dpw_part = T(0);
+            if (ok) {
+                // padded tile coordinates of the lower neighbour: 0 .. T - 1 (0: below the grid, staged as 0)
+                const T* cell = tile_g + ((ref0[0] - x0[0] + 1) + kPX * (ref0[1] - x0[1] + 1) + kPX * kPY * (ref0[2] - x0[2] + 1));
+                T gv[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) gv[s] = cell[(s & 1) + kPX * ((s >> 1) & 1) + kPX * kPY * (s >> 2)];
+                T dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const T gi = gv[s];
+                    const T dweight = voxel_weight<T, 3>(dlo, s, gi);  // raster_pullback.jl:55
+                    dow_part += dweight * pwi;                         // :57
+                    dpw_part += dweight * ps.ow;                       // :58
+                    const T factor = gi * ps.ow * pwi;                 // :60
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, dlo, s);
+                }
+                T scaled[3];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) scaled[n] = dcoord[n] * xf.scale[n];  // :67
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) vals[n + j * 3] += scaled[n] * pt[j];  // :69
+                    vals[9 + n] += scaled[n];                                         // :68
+                }
+                vals[12] += dow_part;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {  // rotation' * scaled (:70)
+                    T v = ps.R[0 + j * 3] * scaled[0];
+                    v = v + ps.R[1 + j * 3] * scaled[1];
+                    v = v + ps.R[2 + j * 3] * scaled[2];
+                    gout[j] = v;
+                }
+            }
+            if (FIRST) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ds_dpoints[p * 3 + j] = gout[j];
+                if (ds_dpw) ds_dpw[p] = dpw_part;
+            } else if (ok) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ds_dpoints[p * 3 + j] += gout[j];
+                if (ds_dpw) ds_dpw[p] += dpw_part;
+            }
+        });
+    };
+    own_walk<T, false>(ta, rec, bl, part, nparts, ps, gd, tr, &sl->walk, visit);
+    // per-item partial sums: T per thread, f64 across the block
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < kNVal; ++k) {
+        const double v = (k < kNVal - 1) ? (double)vals[k < kNVal - 1 ? k : 0] : bg_sum;
+        const double s = wave_sum<double>(v);
+        if (lane == 0) sl->red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNVal) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kOW; ++w) s += sl->red[w][threadIdx.x];
+        const uint32_t slot = nparts > 1 ? (uint32_t)tg.NT + (rec.parts >> 8) + part : tile;
+        partials[(size_t)threadIdx.x * NTp + slot] = s;
+    }
+}
+
+// per-pose sums from the per-item partials, tiles in index order, parts in part order
+template <typename T>
+__global__ __launch_bounds__(1024) void k_own_reduce(OGeom tg, GridDesc<3> gd, int64_t P, int64_t B,
+                                                     const T* points, const T* pw, const T* __restrict__ rot,
+                                                     const T* __restrict__ trans, int64_t b, int bl, int reuse,
+                                                     OwnTileArgs ta, const double* __restrict__ partials, int NTp,
+                                                     T* __restrict__ ds_drotation, T* __restrict__ ds_dtranslation,
+                                                     T* __restrict__ ds_dbackground, T* __restrict__ ds_dout_weight) {
+    __shared__ double wsum[16];
+    const int k = blockIdx.x;
+    const bool stale = reuse && !own_header_ok<T>(ta, gd, P, B, points, pw, rot, trans, b, bl);
+    double s = 0.0;
+    if (!stale) {
+        const TileRec* recs = (const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride);
+        for (int t = threadIdx.x; t < tg.NT; t += 1024) {
+            const uint32_t parts = recs[t].parts;
+            const uint32_t np = parts & 0xffu, first = parts >> 8;
+            if (np <= 1) {
+                s += partials[(size_t)k * NTp + t];
+            } else {
+                for (uint32_t q = 0; q < np; ++q) s += partials[(size_t)k * NTp + tg.NT + first + q];
+            }
+        }
+    }
+    s = wave_sum<double>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (stale) tot = (double)__builtin_nanf("");
+        if (k < 9) ds_drotation[b * 9 + k] = (T)tot;
+        else if (k < 12) ds_dtranslation[b * 3 + (k - 9)] = (T)tot;
+        else if (k == 12) ds_dout_weight[b] = (T)tot;
+        else ds_dbackground[b] = (T)tot;  // (its partial sums come from the gather kernel too)
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static size_t oalign(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct OwnPlan {
+    int64_t nSC, nL1, nL2, Bw;
+    uint32_t list_cap, cap;
+    int max_items, max_slabs, max_split;
+    size_t off_hdr, off_ctl, off_b0, off_b1, off_b2, off_rec, off_list, off_items, off_split, off_slabs, off_partials, total;
+    size_t rec_stride, list_stride, items_stride, split_stride;
+};
+
+struct OwnKnobs {
+    int cap_div, cap_min, max_slabs, fixed;
+};
+static const OwnKnobs& oknobs() {
+    static const OwnKnobs k = [] {
+        auto env_int = [](const char* name, int dflt, int lo, int hi) {
+            const char* v = getenv(name);
+            int x = v ? atoi(v) : dflt;
+            return x < lo ? lo : (x > hi ? hi : x);
+        };
+        OwnKnobs q;
+        q.cap_div = env_int("DPR_OWN_CAP_DIV", 512, 1, 1 << 20);     // a part: ~1.6 P / 512 visits
+        q.cap_min = env_int("DPR_OWN_CAP_MIN", 8192, 64, 1 << 24);
+        q.max_slabs = env_int("DPR_OWN_MAX_SLABS", 1024, 0, 1 << 16);
+        q.fixed = env_int("DPR_FIXED_POINT", 1, 0, 1);
+        return q;
+    }();
+    return k;
+}
+
+static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
+    OwnPlan pl;
+    pl.nSC = (P + kSC - 1) / kSC;
+    pl.nL1 = (P + kL1 - 1) / kL1;
+    pl.nL2 = (pl.nL1 + kL2 - 1) / kL2;
+    pl.Bw = B < 1 ? 1 : (B < kOwnBw ? B : kOwnBw);
+    const int64_t cap = (P + P / 2) / oknobs().cap_div;
+    pl.cap = (uint32_t)(cap < oknobs().cap_min ? oknobs().cap_min : (cap > 0x3fffffff ? 0x3fffffff : cap));
+    pl.max_slabs = oknobs().max_slabs;
+    pl.max_split = pl.max_slabs / 2 + 1;
+    pl.max_items = tg.NT + pl.max_slabs;
+    // a chunk of a coherent cloud overlaps ~6 tiles; 16 per chunk + one per tile, else the tile
+    // kernels scan the chunks themselves
+    const int64_t lc = pl.nL1 * 16 + tg.NT;
+    pl.list_cap = (uint32_t)(lc > 0x7fffffff ? 0x7fffffff : lc);
+    size_t o = 0;
+    pl.off_hdr = o;
+    o += oalign(sizeof(OwnHeader));
+    pl.off_ctl = o;
+    o += oalign((size_t)pl.Bw * kCtlWords * 4);
+    pl.off_b0 = o;
+    o += oalign((size_t)(pl.nSC + 1) * sizeof(Box0));
+    pl.off_b1 = o;
+    o += oalign((size_t)(pl.nL1 + 1) * sizeof(Box1));
+    pl.off_b2 = o;
+    o += oalign((size_t)(pl.nL2 + 1) * sizeof(Box1));
+    pl.rec_stride = oalign((size_t)tg.NT * sizeof(TileRec));
+    pl.off_rec = o;
+    o += pl.rec_stride * pl.Bw;
+    pl.list_stride = oalign((size_t)pl.list_cap * 4);
+    pl.off_list = o;
+    o += pl.list_stride * pl.Bw;
+    pl.items_stride = oalign((size_t)kBuckets * pl.max_items * sizeof(uint2));
+    pl.off_items = o;
+    o += pl.items_stride * pl.Bw;
+    pl.split_stride = oalign((size_t)pl.max_split * 4);
+    pl.off_split = o;
+    o += pl.split_stride * pl.Bw;
+    pl.off_slabs = o;
+    if (op == DPR_OP_RASTER) o += oalign((size_t)pl.max_slabs * kCells * 8);
+    pl.off_partials = o;
+    if (op == DPR_OP_PULLBACK) o += oalign((size_t)(tg.NT + pl.max_slabs) * kNVal * 8);
+    pl.total = o;
+    return pl;
+}
+
+bool owner_supported(const int64_t* grid) {
+    OGeom tg;
+    return make_ogeom(grid, &tg);
+}
+
+size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B) {
+    OGeom tg;
+    if (!make_ogeom(grid, &tg) || P >= ((int64_t)1 << 32) * kSC / 16) return (size_t)-1;
+    // a KEEP forward and its REUSE pullback share one layout: the larger of the two
+    const OwnPlan a = make_oplan(DPR_OP_RASTER, tg, P, B), b = make_oplan(DPR_OP_PULLBACK, tg, P, B);
+    return a.total > b.total ? a.total : b.total;
+}
+
+#define DPR_HIP(expr)                                                                \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess)                                                        \
+            return fail(DPR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static GridDesc<3> ogrid_desc(const int64_t* grid, int64_t G) {
+    GridDesc<3> gd;
+    for (int d = 0; d < 3; ++d) gd.n[d] = (int)grid[d];
+    gd.G = G;
+    return gd;
+}
+
+static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws, bool keep) {
+    OwnPlanArgs pa;
+    pa.ws = ws;
+    pa.off_ctl = pl.off_ctl;
+    pa.off_rec = pl.off_rec;
+    pa.off_list = pl.off_list;
+    pa.off_items = pl.off_items;
+    pa.off_split = pl.off_split;
+    pa.off_hdr = pl.off_hdr;
+    pa.rec_stride = pl.rec_stride;
+    pa.list_stride = pl.list_stride;
+    pa.items_stride = pl.items_stride;
+    pa.split_stride = pl.split_stride;
+    pa.list_cap = pl.list_cap;
+    pa.max_items = pl.max_items;
+    pa.max_slabs = pl.max_slabs;
+    pa.max_split = pl.max_split;
+    pa.cap = pl.cap;
+    pa.fixed = oknobs().fixed;
+    pa.keep = keep ? 1 : 0;
+    return pa;
+}
+static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
+    OwnTileArgs ta;
+    ta.ws = ws;
+    ta.off_ctl = pl.off_ctl;
+    ta.off_rec = pl.off_rec;
+    ta.off_list = pl.off_list;
+    ta.off_items = pl.off_items;
+    ta.off_hdr = pl.off_hdr;
+    ta.rec_stride = pl.rec_stride;
+    ta.list_stride = pl.list_stride;
+    ta.items_stride = pl.items_stride;
+    ta.max_items = pl.max_items;
+    ta.nL1 = pl.nL1;
+    ta.nSC = pl.nSC;
+    ta.b0 = (const Box0*)(ws + pl.off_b0);
+    ta.b1 = (const Box1*)(ws + pl.off_b1);
+    return ta;
+}
+
+template <typename T> static bool vec_ok(const T* points, const T* pw) {
+    return (((uintptr_t)points) & 15) == 0 && (((uintptr_t)pw) & 15) == 0;
+}
+
+// boxes (first pose group of a call) + plan of poses [b0, b0 + nb)
+template <typename T>
+static int own_prepare(hipStream_t st, const OGeom& tg, const GridDesc<3>& gd, const OwnPlan& pl, char* ws,
+                       int64_t P, int64_t B, const T* points, const T* pw, const T* rot, const T* trans,
+                       const T* ow, int64_t b0, int64_t nb, bool boxes, bool keep) {
+    uint32_t* ctl = (uint32_t*)(ws + pl.off_ctl);
+    const int ctl_words = (int)(pl.Bw * kCtlWords);
+    if (boxes && P > 0) {
+        hipLaunchKernelGGL((k_own_boxes<T>), dim3((unsigned)pl.nL1), dim3(256), 0, st, P, points, pw,
+                           vec_ok(points, pw) ? 1 : 0, (Box0*)(ws + pl.off_b0), (Box1*)(ws + pl.off_b1), ctl,
+                           ctl_words);
+        hipLaunchKernelGGL(k_own_boxes2, dim3((unsigned)((pl.nL2 + 3) / 4)), dim3(256), 0, st, pl.nL1,
+                           (const Box1*)(ws + pl.off_b1), (Box1*)(ws + pl.off_b2));
+    } else {
+        DPR_HIP(hipMemsetAsync(ctl, 0, (size_t)ctl_words * 4, st));
+    }
+    stage_mark(st);
+    hipLaunchKernelGGL((k_own_plan<T>), dim3((unsigned)tg.NT, (unsigned)nb), dim3(256), 0, st, tg, gd, P, B,
+                       pl.nL1, pl.nL2, (const Box1*)(ws + pl.off_b1), (const Box1*)(ws + pl.off_b2), rot,
+                       trans, ow, points, pw, b0, plan_args(pl, ws, keep));
+    stage_mark(st);
+    return DPR_OK;
+}
+
+template <typename K> static int own_lds(K kernel, size_t bytes) {
+    DPR_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DPR_OK;
+}
+
+template <typename T>
+int raster_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                 T* out, const T* points, const T* rot, const T* trans, const T* bg, const T* ow,
+                 const T* pw, void* ws_, size_t ws_bytes) {
+    OGeom tg;
+    if (!make_ogeom(grid, &tg))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles", kMaxOwnTiles);
+    if (P >= ((int64_t)1 << 32)) return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
+    const bool keep = flags & DPR_FLAG_KEEP_BINNING;
+    if (keep && B > kOwnBw)
+        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING on 3-D DPR_ALGO_CHUNKED needs B <= %d (got %lld)",
+                    kOwnBw, (long long)B);
+    const size_t need = owner_workspace_bytes(DPR_OP_RASTER, grid, P, B);
+    if (!ws_ || ws_bytes < need)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED raster needs %zu workspace bytes, got %zu", need,
+                    ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    const GridDesc<3> gd = ogrid_desc(grid, G);
+    const OwnPlan pl = make_oplan(DPR_OP_RASTER, tg, P, B);
+    const size_t lds = sizeof(OwnWalkLds) + (size_t)kPCells * 8;
+    if (pw) {
+        if (int rc = own_lds(k_own_splat<T, true>, lds)) return rc;
+    } else {
+        if (int rc = own_lds(k_own_splat<T, false>, lds)) return rc;
+    }
+    for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
+        const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
+        if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, B, points, pw, rot, trans, ow, b0, nb, b0 == 0, keep))
+            return rc;
+        const OwnTileArgs ta = tile_args(pl, ws);
+        unsigned long long* slabs = (unsigned long long*)(ws + pl.off_slabs);
+        const dim3 tgrid((unsigned)pl.max_items, (unsigned)nb);
+        if (pw)
+            hipLaunchKernelGGL((k_own_splat<T, true>), tgrid, dim3(kOT), lds, st, tg, gd, P, points, pw,
+                               vec_ok(points, pw) ? 1 : 0, rot, trans, ow, bg, b0, ta, slabs, out);
+        else
+            hipLaunchKernelGGL((k_own_splat<T, false>), tgrid, dim3(kOT), lds, st, tg, gd, P, points, pw,
+                               vec_ok(points, pw) ? 1 : 0, rot, trans, ow, bg, b0, ta, slabs, out);
+        stage_mark(st);
+        const int ncomb = pl.max_split * 4 < 1024 ? pl.max_split * 4 : 1024;
+        hipLaunchKernelGGL((k_own_combine<T>), dim3((unsigned)ncomb, (unsigned)nb), dim3(kOT), 0, st, tg, gd, bg,
+                           b0, ta, pl.off_split, pl.split_stride, pl.max_split,
+                           (const unsigned long long*)slabs, out);
+        stage_mark(st);
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+template <typename T>
+int pullback_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                   const T* g, const T* points, const T* rot, const T* trans, const T* ow, const T* pw,
+                   T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw, void* ws_, size_t ws_bytes) {
+    OGeom tg;
+    if (!make_ogeom(grid, &tg))
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles", kMaxOwnTiles);
+    if (P >= ((int64_t)1 << 32)) return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
+    const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
+    if (reuse && B > kOwnBw)
+        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING on 3-D DPR_ALGO_CHUNKED needs B <= %d (got %lld)",
+                    kOwnBw, (long long)B);
+    const size_t need = owner_workspace_bytes(DPR_OP_PULLBACK, grid, P, B);
+    if (!ws_ || ws_bytes < need)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED pullback needs %zu workspace bytes, got %zu", need,
+                    ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    const GridDesc<3> gd = ogrid_desc(grid, G);
+    const OwnPlan pl = make_oplan(DPR_OP_PULLBACK, tg, P, B);
+    // (the partial sums sit where the forward's slabs were: the lists, records and boxes in front
+    // of them are at the same offsets in both layouts)
+    double* partials = (double*)(ws + pl.off_partials);
+    const int NTp = tg.NT + pl.max_slabs;
+    const size_t lds = sizeof(OwnGatherLds) + (size_t)kPCells * sizeof(T);
+#define DPR_OWN_ATTR(HAS_PW, FIRST) \
+    if (int rc = own_lds(k_own_gather<T, HAS_PW, FIRST>, lds)) return rc;
+    if (pw) {
+        DPR_OWN_ATTR(true, true)
+        DPR_OWN_ATTR(true, false)
+    } else {
+        DPR_OWN_ATTR(false, true)
+        DPR_OWN_ATTR(false, false)
+    }
+#undef DPR_OWN_ATTR
+    const int vok = vec_ok(points, pw) ? 1 : 0;
+    for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
+        const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
+        if (reuse) {
+            stage_mark(st);
+            stage_mark(st);
+        } else if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, B, points, pw, rot, trans, ow, b0, nb, b0 == 0,
+                                           false))
+            return rc;
+        const OwnTileArgs ta = tile_args(pl, ws);
+        // the point gradients accumulate over poses: one pose per launch (stream order = race-free
+        // read-modify-write; every point has exactly one owner per pose)
+        for (int64_t bl = 0; bl < nb; ++bl) {
+            const int64_t b = b0 + bl;
+            const dim3 tgrid((unsigned)pl.max_items);
+#define DPR_OWN_GATHER(HAS_PW, FIRST)                                                                       \
+    hipLaunchKernelGGL((k_own_gather<T, HAS_PW, FIRST>), tgrid, dim3(kOT), lds, st, tg, gd, P, B, points, pw, \
+                       vok, g, rot, trans, ow, b, (int)bl, reuse ? 1 : 0, ta, d_pts, d_pw, partials, NTp)
+            if (pw) {
+                if (b == 0) DPR_OWN_GATHER(true, true);
+                else DPR_OWN_GATHER(true, false);
+            } else {
+                if (b == 0) DPR_OWN_GATHER(false, true);
+                else DPR_OWN_GATHER(false, false);
+            }
+#undef DPR_OWN_GATHER
+            stage_mark(st);
+            hipLaunchKernelGGL((k_own_reduce<T>), dim3(kNVal), dim3(1024), 0, st, tg, gd, P, B, points, pw, rot,
+                               trans, b, (int)bl, reuse ? 1 : 0, ta, (const double*)partials, NTp, d_rot,
+                               d_trans, d_bg, d_ow);
+            stage_mark(st);
+        }
+    }
+    DPR_HIP(hipGetLastError());
+    return DPR_OK;
+}
+
+#define DPR_INST(T)                                                                                        \
+    template int raster_owner<T>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, int64_t, T*,     \
+                                 const T*, const T*, const T*, const T*, const T*, const T*, void*, size_t); \
+    template int pullback_owner<T>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, int64_t,      \
+                                   const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, \
+                                   T*, T*, T*, void*, size_t);
+DPR_INST(float)
+DPR_INST(double)
+}  // namespace dpr

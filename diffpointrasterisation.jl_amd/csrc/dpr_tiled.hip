@@ -1250,7 +1250,10 @@ __global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_l
             tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
             valid = tile[k] >= 0;
             lrank[k] = 0;
-            if (HAS_PW && valid && jp == 0) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
+            // (every LOADED point, valid under this pose or not: the maximum is published once for
+            // all poses of the local batch, and a point outside the grid under pose 0 may be inside
+            // under pose j > 0)
+            if (HAS_PW && jp == 0 && lp < nloc) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
             unsigned long long todo = __ballot(valid);
             int rounds = 0;
             while (todo && rounds < 8) {

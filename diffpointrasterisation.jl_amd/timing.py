@@ -12,8 +12,9 @@ STAGES = {
     ("raster", "atomic"): ["fill", "splat"],
     ("pullback", "atomic"): ["zero+grid_sum", "gather"],
     ("raster", "tiled"): ["count", "scan", "scatter", "tile_splat", "halo"],
-    ("raster", "chunked"): ["boxes", "lists", "chunk_splat", "divert"],
-    ("pullback", "chunked"): ["boxes", "lists", "chunk_gather", "pose_reduce", "divert"],
+    # DPR_ALGO_CHUNKED on 3-D grids (owner-computes tiles over a box hierarchy)
+    ("raster", "chunked"): ["boxes", "plan", "own_splat", "combine"],
+    ("pullback", "chunked"): ["boxes", "plan", "own_gather", "pose_reduce"],
     ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "unpermute", "pose_reduce"],
     # DPR_ALGO_TILED with coherent_points=True (local binning): pass algo="tiled_local"
     ("raster", "tiled_local"): ["clear", "bin_local", "runscan", "tile_splat", "halo"],

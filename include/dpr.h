@@ -204,8 +204,8 @@ int dpr_resolve_flags_ex(int op, unsigned flags, int n_in, int n_out, const int6
  * Stage order -- DPR_ALGO_ATOMIC raster: fill, splat; pullback: zero+grid_sum, gather.
  * DPR_ALGO_TILED, per pose -- raster: count, scan, scatter, tile_splat, halo;
  * pullback: count, scan, scatter, tile_gather, unpermute, pose_reduce.
- * DPR_ALGO_CHUNKED, 3-D grids -- raster: boxes, lists, chunk_splat, divert;
- * pullback: boxes, lists, chunk_gather, pose_reduce, divert.
+ * DPR_ALGO_CHUNKED, 3-D grids -- raster: boxes, plan, own_splat, combine;
+ * pullback: boxes, plan, own_gather, pose_reduce.
  * DPR_ALGO_CHUNKED, 2-D grids -- raster: sort, fill, chunk_splat;
  * pullback: sort, grid_sum, chunk_gather, reduce+unsort. */
 int dpr_stage_timing_begin(void **events, int capacity);

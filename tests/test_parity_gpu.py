@@ -1136,6 +1136,39 @@ def test_tiled_fp32_point_weights_over_many_orders_of_magnitude(oracle, dev, coh
     assert err <= 2e-6 * np.abs(ref32).max(), err
 
 
+@pytest.mark.parametrize("mode", ["coherent2d", "coherent3d", "sort_inside"])
+@pytest.mark.parametrize("bad", [None, np.nan])
+def test_tiled_fp32_batch_scale_covers_weights_only_later_poses_see(oracle, dev, mode, bad):
+    """Local binning publishes ONE max |point_weight| for all poses of a local batch (the
+    fixed-point scale of k_tile_splat_runs).  The heaviest points -- and one NaN weight -- are
+    outside the grid under pose 0 and inside under the later poses: the maximum must cover them
+    (round 4's kernel looked at pose 0's valid points only and corrupted the later poses)."""
+    # grids with more than 2048 tiles per pose (no pose groups: local batches); sort_inside: more
+    # than 4096 tiles, B >= 4, >= 2e5 points
+    grid = {"coherent2d": (1472, 1472), "coherent3d": (320, 256, 256), "sort_inside": (2112, 2112)}[mode]
+    n_out = len(grid)
+    n_points, batch = 220_000, 4
+    d = D.make(n_points=n_points, n_in=3, n_out=n_out, batch=batch, grid_n=grid, seed=31, dtype=np.float32)
+    rng = np.random.default_rng(32)
+    pts = rng.uniform(-0.45, 0.45, size=(n_points, 3)).astype(np.float32)
+    pts = pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))]  # coherent in memory
+    R = np.broadcast_to(np.eye(n_out, 3, dtype=np.float32), (batch, n_out, 3)).copy()
+    t = np.zeros((batch, n_out), dtype=np.float32)
+    t[0, 0] = 0.7  # pose 0 pushes x > 0.3 out of the grid; the other poses keep everything
+    pw = rng.uniform(0.5, 1.0, size=n_points).astype(np.float32)
+    heavy = pts[:, 0] > 0.35
+    pw[heavy] *= np.float32(3.0e4)  # 15 bits above the weights pose 0 sees
+    if bad is not None:
+        pw[np.flatnonzero(heavy)[7]] = bad
+    ref = oracle.raster(grid, pts, R, t, None, d.weights, pw, dtype=np.float32)
+    out = dpr_amd.raster(grid, T(pts, dev), T(R, dev), T(t, dev), None, T(d.weights, dev), T(pw, dev),
+                         algo="tiled", coherent_points=mode.startswith("coherent")).cpu().numpy()
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    for b in range(batch):
+        fin = np.isfinite(ref[..., b])
+        assert_close(out[..., b][fin], ref[..., b][fin], 5e-5, f"pose {b}")
+
+
 @pytest.mark.parametrize("bad", [np.inf, np.nan])
 @pytest.mark.parametrize("where", ["point_weight", "out_weight"])
 def test_tiled_fp32_non_finite_weights_fall_back_to_ieee_sums(oracle, dev, bad, where):
