@@ -28,6 +28,7 @@ ALGO_CHUNKED = 3
 FLAG_KEEP_BINNING = 1
 FLAG_REUSE_BINNING = 2
 FLAG_COHERENT_POINTS = 4
+FLAG_NO_POINT_WEIGHT_GRAD = 8
 
 
 def flag_max_pose_group(n: int) -> int:

@@ -88,9 +88,12 @@ class _RasterFn(torch.autograd.Function):
         for k in range(3):
             opt.append(rest.pop(0) if ctx.opt_is_tensor[k] else ctx.opt[k])
         ws, ctx.ws = ctx.ws, None  # the binning is consumed by the pass that reuses it
-        pb = raster_pullback_(ds_dout.detach(), points, rotation, translation, *opt,
-                              algo=ctx.algo, workspace=ws, reuse_binning=ws is not None)
         need = ctx.needs_input_grad  # (grid_size, algo, points, rotation, translation, bg, ow, pw)
+        # the rrule drops the point_weight tangent when that argument was defaulted
+        # (ext/DiffPointRasterisationChainRulesCoreExt.jl:23,70): do not compute / store it then
+        pb = raster_pullback_(ds_dout.detach(), points, rotation, translation, *opt,
+                              algo=ctx.algo, workspace=ws, reuse_binning=ws is not None,
+                              point_weight_grad=bool(ctx.opt_is_tensor[2] and need[7]))
         grads = [None, None,
                  pb.points.to(ctx.points_dtype) if need[2] else None,
                  pb.rotation.to(rotation.dtype) if need[3] else None,

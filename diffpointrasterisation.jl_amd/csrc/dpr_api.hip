@@ -352,7 +352,7 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
         const int accumulate = slices > 1;
         if (accumulate) {
             DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * NI), st));
-            DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
+            if (d_pw) DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
         }
         dim3 gg((unsigned)pblocks, (unsigned)slices);
         hipLaunchKernelGGL((k_bwd_gather<T, NI, NO>), gg, dim3(kBlock), 0, st, gd, P, B, g, points,
@@ -373,14 +373,18 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     int64_t G = 0;
     if (int rc = check_common(n_in, n_out, grid, P, B, &G)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (P > 0 && (!d_pts || !d_pw))
+    // DPR_FLAG_NO_POINT_WEIGHT_GRAD: the caller does not want ds_dpoint_weight (the reference's
+    // rrule drops that tangent whenever point_weight was defaulted,
+    // ext/DiffPointRasterisationChainRulesCoreExt.jl:23,70): nothing is written through the pointer
+    if (flags & DPR_FLAG_NO_POINT_WEIGHT_GRAD) d_pw = nullptr;
+    if (P > 0 && (!d_pts || (!d_pw && !(flags & DPR_FLAG_NO_POINT_WEIGHT_GRAD))))
         return fail(DPR_ERR_INVALID_ARG, "ds_dpoints/ds_dpoint_weight is NULL with P > 0");
     if (P > 0 && !points) return fail(DPR_ERR_INVALID_ARG, "points is NULL with P > 0");
     if (B == 0) {
         // no poses: point gradients are empty sums
         if (P > 0) {
             DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * n_in), st));
-            DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
+            if (d_pw) DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
         }
         return DPR_OK;
     }

@@ -562,7 +562,8 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
             const int n0 = (int)((P - base0 < kCOChunk) ? P - base0 : kCOChunk);
             const T nan = T(__builtin_nanf(""));
             for (int i = threadIdx.x; i < n0 * NI; i += kCOThreads) ds_dpoints[base0 * NI + i] = nan;
-            for (int i = threadIdx.x; i < n0; i += kCOThreads) ds_dpw[base0 + i] = nan;
+            if (ds_dpw)
+                for (int i = threadIdx.x; i < n0; i += kCOThreads) ds_dpw[base0 + i] = nan;
         }
         return;
     }
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
             if (p >= (size_t)P) continue;  // never for a permutation this library wrote
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp[k][j];
-            ds_dpw[p] = dpw[k];
+            if (ds_dpw) ds_dpw[p] = dpw[k];
         }
         return;
     }
@@ -885,6 +886,7 @@ __global__ __launch_bounds__(kCOThreads) void k_co_gather(
         else
             ds_dpoints[base * NI + i] = v;
     }
+    if (!ds_dpw) return;  // (the caller declined ds_dpoint_weight)
     for (int q = threadIdx.x; q < n_here; q += kCOThreads) {
         const T v = smem[kPwBase + q + (q >> 6)];
         if (accumulate_points)
@@ -935,14 +937,14 @@ __global__ __launch_bounds__(256) void k_co_unsort(int64_t P, const uint32_t* __
         const T nan = T(__builtin_nanf(""));
 #pragma unroll
         for (int j = 0; j < NI; ++j) ds_dpoints[i * NI + j] = nan;
-        ds_dpw[i] = nan;
+        if (ds_dpw) ds_dpw[i] = nan;
         return;
     }
     const size_t p = perm[i];
     if (p >= (size_t)P) return;  // never for a permutation this library wrote
 #pragma unroll
     for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = dp_sorted[i * NI + j];
-    ds_dpw[p] = dpw_sorted[i];
+    if (ds_dpw) ds_dpw[p] = dpw_sorted[i];
 }
 
 // ------------------------------------------------------------------ host side
@@ -1143,7 +1145,7 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
         pts = spts;
         pws = spw;
         gp = (T*)(ws + pl.off_grad);
-        gw = (T*)(ws + pl.off_gradw);
+        gw = d_pw ? (T*)(ws + pl.off_gradw) : (T*)nullptr;  // (NULL: the caller declined this gradient)
     }
     // one pose slice per chunk (the usual case from ~4 M points on): the gather kernel writes the
     // gradients through the permutation itself, no sorted gradient buffer and no un-sort pass
@@ -1172,7 +1174,7 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
     if (P > 0) {
         if (accumulate) {
             DPR_HIP(hipMemsetAsync(gp, 0, sizeof(T) * (size_t)(P * NI), st));
-            DPR_HIP(hipMemsetAsync(gw, 0, sizeof(T) * (size_t)P, st));
+            if (gw) DPR_HIP(hipMemsetAsync(gw, 0, sizeof(T) * (size_t)P, st));
         }
         dim3 gg((unsigned)pl.nblk, (unsigned)pl.slices);
         if (pws)

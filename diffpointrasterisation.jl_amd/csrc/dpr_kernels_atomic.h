@@ -207,11 +207,11 @@ __global__ __launch_bounds__(kBlock) void k_bwd_gather(
         if (accumulate_points) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) atomic_add<T>(ds_dpoints + p * NI + j, acc_pt[j]);
-            atomic_add<T>(ds_dpoint_weight + p, acc_pw);
+            if (ds_dpoint_weight) atomic_add<T>(ds_dpoint_weight + p, acc_pw);
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = acc_pt[j];
-            ds_dpoint_weight[p] = acc_pw;
+            if (ds_dpoint_weight) ds_dpoint_weight[p] = acc_pw;
         }
     }
 }

@@ -31,12 +31,10 @@
 //                           (dpr_device.h FixScale), fp64 / non-finite weights: f64 atomics.
 //            k_own_combine  split tiles only: the parts left their raw 64-bit tiles in slabs,
 //                           summed here (integer sums: exact, whatever the split)
-//   pullback k_own_gather   block per work item: ds_dout tile (+1 upper halo) staged in LDS; a
-//                           point is OWNED by the tile of its base voxel (clamped into the grid, so
-//                           that rejected points have an owner too and get their zeros), is
-//                           differentiated exactly once and its gradient is stored in cloud order:
-//                           no gradient records, no un-permute, no read-modify-write for one pose
-//            k_own_reduce   per-item partial sums (f64) -> ds_drotation, ds_dtranslation, ...
+//   pullback k_own_pullback a thread per point in cloud order, gathers straight from ds_dout (the
+//                           cloud is coherent: a wave's gathers share cache lines), 13 per-pose sums
+//                           in registers per block, grid sum for ds_dbackground alongside; no tiles
+//            k_own_reduce   per-block partial sums (f64) -> ds_drotation, ds_dtranslation, ...
 //
 // Correct for ANY point order: a box that covers half the grid is listed by every tile it
 // overlaps (slow, never wrong); candidate lists that outgrow their buffer make the tile scan all
@@ -373,42 +371,10 @@ __global__ __launch_bounds__(256) void k_own_boxes2(int64_t nL1, const Box1* __r
     }
 }
 
-// ---------------------------------------------------------------- what a KEEP forward leaves
-struct OwnHeader {
-    uint32_t magic, elem;
-    int64_t P, B;
-    int32_t grid[3];
-    uint32_t state;  // 1: valid
-    uint64_t points, pw;
-    uint32_t pose_bits[kOwnBw][2];  // a hash of every pose's 12 values (64 bits)
-};
-constexpr uint32_t kOwnMagic = 0x4f574e35u;  // "OWN5"
-
-template <typename T>
-__device__ __forceinline__ void pose_hash(const T* __restrict__ rot, const T* __restrict__ trans,
-                                          int64_t b, uint32_t (&h)[2]) {
-    // FNV-1a over the bit patterns: a pose that changed by one ulp is another pose
-    uint64_t x = 1469598103934665603ull;
-    auto mix = [&](uint64_t v) {
-        x ^= v;
-        x *= 1099511628211ull;
-    };
-    for (int k = 0; k < 9; ++k) {
-        if constexpr (sizeof(T) == 4) mix(__float_as_uint((float)rot[b * 9 + k]));
-        else mix((uint64_t)__double_as_longlong((double)rot[b * 9 + k]));
-    }
-    for (int k = 0; k < 3; ++k) {
-        if constexpr (sizeof(T) == 4) mix(__float_as_uint((float)trans[b * 3 + k]));
-        else mix((uint64_t)__double_as_longlong((double)trans[b * 3 + k]));
-    }
-    h[0] = (uint32_t)x;
-    h[1] = (uint32_t)(x >> 32);
-}
-
 // ---------------------------------------------------------------- plan
 struct OwnPlanArgs {
     char* ws;
-    size_t off_ctl, off_rec, off_list, off_items, off_split, off_hdr;
+    size_t off_ctl, off_rec, off_list, off_items, off_split;
     size_t rec_stride, list_stride, items_stride, split_stride;  // per pose copy (bytes)
     uint32_t list_cap;   // entries per pose
     int max_items;       // per bucket
@@ -416,7 +382,6 @@ struct OwnPlanArgs {
     int max_split;       // per pose
     uint32_t cap;        // visits per part above which a tile is split
     int fixed;           // fixed-point forward wanted
-    int keep;            // write the header
 };
 
 // block per (tile, pose copy): walks the box hierarchy top down.  Wave w of the block takes the
@@ -558,20 +523,6 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         for (uint32_t k = 0; k < np; ++k)
             if (slot + k < (uint32_t)pa.max_items) items[slot + k] = make_uint2((uint32_t)tile, k | (np << 16));
         s_begin = begin;
-        if (pa.keep && tile == 0) {
-            OwnHeader* h = (OwnHeader*)(pa.ws + pa.off_hdr);
-            if (bl == 0) {
-                h->magic = kOwnMagic;
-                h->elem = sizeof(T);
-                h->P = P;
-                h->B = B;
-                for (int d = 0; d < 3; ++d) h->grid[d] = gd.n[d];
-                h->points = (uint64_t)(uintptr_t)points;
-                h->pw = (uint64_t)(uintptr_t)pw;
-                h->state = 1u;
-            }
-            pose_hash<T>(rot, trans, b, h->pose_bits[bl]);
-        }
     }
     __syncthreads();
     const uint32_t begin = s_begin;
@@ -588,12 +539,13 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
 // ---------------------------------------------------------------- shared by the tile kernels
 struct OwnTileArgs {
     const char* ws;
-    size_t off_ctl, off_rec, off_list, off_items, off_hdr;
+    size_t off_ctl, off_rec, off_list, off_items;
     size_t rec_stride, list_stride, items_stride;
     int max_items;
     int64_t nL1, nSC;
     const Box0* b0;
     const Box1* b1;
+    size_t dbg_words;  // (stats build: 32-bit words of the slab area, per-item records at its end)
 };
 
 // work item of this block: buckets from the heaviest down
@@ -722,10 +674,9 @@ __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const TileRec& r
     }
 #ifdef DPR_OWN_STATS
     if (lane == 0) {
-        uint32_t* ctl = (uint32_t*)(ta.ws + ta.off_ctl);
-        atomicAdd(&ctl[6], st_batches);
-        atomicAdd(&ctl[7], st_take);
-        atomicAdd(&ctl[9], st_tests);
+        atomicAdd(&wl->pad[2], st_batches);
+        atomicAdd(&wl->pad[3], st_take);
+        atomicAdd(&wl->pad[4], st_tests);
     }
 #endif
 }
@@ -777,32 +728,6 @@ __device__ __forceinline__ void own_points(uint32_t sc, bool have, int64_t P, co
     }
 }
 
-// the same one point at a time (12- / 24-byte loads, the next point requested before the current
-// one is worked on): for a body that needs the registers itself (the pullback)
-template <typename T, bool HAS_PW, typename Body>
-__device__ __forceinline__ void own_points_single(uint32_t sc, bool have, int64_t P, const T* __restrict__ points,
-                                                  const T* __restrict__ pw, Body body) {
-    const int64_t p0 = (int64_t)sc * kSC;
-    const int64_t left = P - p0;
-    const int npts = have ? (left < kSC ? (int)left : kSC) : 0;
-    const int last = left < kSC ? (int)left - 1 : kSC - 1;  // (reads stay inside the cloud)
-    const T* src = points + p0 * 3;
-    T nxt[3], wn = T(1);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) nxt[j] = src[j];
-    if constexpr (HAS_PW) wn = pw[p0];
-#pragma unroll 1
-    for (int i = 0; i < kSC; ++i) {
-        const T pt[3] = {nxt[0], nxt[1], nxt[2]};
-        const T w = wn;
-        const int in = i + 1 < last ? i + 1 : last;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) nxt[j] = src[in * 3 + j];
-        if constexpr (HAS_PW) wn = pw[p0 + in];
-        body(i, i < npts, pt, w);
-    }
-}
-
 // ---------------------------------------------------------------- forward
 template <typename T, bool HAS_PW>
 __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int64_t P,
@@ -842,6 +767,7 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
     if (threadIdx.x == 0) {
         wl->next = 0u;
         wl->pool_n = 0u;
+        for (int k = 0; k < 8; ++k) wl->pad[k] = 0u;
     }
     const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
     const TileRange tr = tile_range(tc, tg);
@@ -896,17 +822,31 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
     else run(std::false_type{});
 #ifdef DPR_OWN_STATS
     {
-        uint32_t* ctl = (uint32_t*)(ta.ws + ta.off_ctl);
         const uint32_t a = (uint32_t)wave_sum<int>((int)st_vis), c = (uint32_t)wave_sum<int>((int)st_touch);
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&ctl[4], a);
-            atomicAdd(&ctl[5], c);
+            atomicAdd(&wl->pad[0], a);
+            atomicAdd(&wl->pad[1], c);
         }
+        __syncthreads();
         if (threadIdx.x == 0) {
+            uint32_t* ctl = (uint32_t*)(ta.ws + ta.off_ctl);
+            atomicAdd(&ctl[4], wl->pad[0]);
+            atomicAdd(&ctl[5], wl->pad[1]);
+            atomicAdd(&ctl[6], wl->pad[2]);
+            atomicAdd(&ctl[7], wl->pad[3]);
+            atomicAdd(&ctl[9], wl->pad[4]);
             atomicAdd(&ctl[8], 1u);
             const uint32_t dt = (uint32_t)(wall_clock64() - st_t0);
             atomicAdd(&ctl[10], dt);
             atomicMax(&ctl[11], dt);
+            // per-item record at the end of the slab area: {ticks, visits, tile, part | nparts << 16, start tick}
+            uint32_t* dbg = (uint32_t*)(slabs) + (size_t)ta.dbg_words - 8 * ((size_t)blockIdx.x + 1);
+            dbg[0] = dt;
+            dbg[1] = wl->pad[0];
+            dbg[2] = tile;
+            dbg[3] = part | (nparts << 16);
+            dbg[4] = (uint32_t)st_t0;
+            dbg[5] = rec.count;
         }
     }
 #endif
@@ -994,212 +934,186 @@ __global__ __launch_bounds__(kOT) void k_own_combine(OGeom tg, GridDesc<3> gd, c
 }
 
 // ---------------------------------------------------------------- pullback
+// On a coherent cloud the pullback needs no tile at all: a thread per point IN CLOUD ORDER reads its
+// eight ds_dout cells straight from memory -- neighbouring lanes are neighbouring points, so a wave's
+// gathers fall into a handful of cache lines and every cell is fetched from HBM about once --,
+// differentiates the point exactly once and stores its 16 bytes coalesced: no ownership tests, no
+// repeated visits, no divergence, nothing staged.  (The LDS-staged owner-computes gather this file
+// had first ran 0.53 ms at 10 M points -> 256^3: twice the visits of a per-point kernel, and the
+// heavy gradient arithmetic only on the half of the lanes that own their point.)  What the direct
+// kernel of DPR_ALGO_ATOMIC pays for -- 13 wave reductions and 13 same-address global atomics per 256
+// points -- is gone: a block walks a contiguous slice of the cloud, keeps the 13 per-pose sums in
+// registers and reduces them once; the grid sum for ds_dbackground rides along (every block sums a
+// slice of ds_dout with 16-byte loads).  Correct for any point order; an incoherent cloud pays
+// cache misses on its gathers.  src/raster_pullback.jl:39-72 (per point), :78 (background).
 constexpr int kNVal = 3 * 3 + 3 + 2;  // d rotation, d translation, d out_weight, sum(ds_dout)
-
-struct OwnGatherLds {
-    OwnWalkLds walk;
-    double red[kOW][kNVal];
-};
-
-// A REUSE pullback looks at the header the KEEP forward left: same problem, same buffers, same
-// poses?  (uniform per block; cheap: ~20 scalar loads)
-template <typename T>
-__device__ __forceinline__ bool own_header_ok(const OwnTileArgs& ta, const GridDesc<3>& gd, int64_t P,
-                                              int64_t B, const T* points, const T* pw,
-                                              const T* __restrict__ rot, const T* __restrict__ trans,
-                                              int64_t b, int bl) {
-    const OwnHeader* h = (const OwnHeader*)(ta.ws + ta.off_hdr);
-    bool ok = h->magic == kOwnMagic && h->elem == sizeof(T) && h->P == P && h->B == B && h->state == 1u &&
-              h->points == (uint64_t)(uintptr_t)points && h->pw == (uint64_t)(uintptr_t)pw;
-    for (int d = 0; d < 3; ++d) ok = ok && h->grid[d] == gd.n[d];
-    uint32_t hb[2];
-    pose_hash<T>(rot, trans, b, hb);
-    return ok && h->pose_bits[bl][0] == hb[0] && h->pose_bits[bl][1] == hb[1];
-}
+constexpr int kDT = 256;             // threads of the direct pullback kernel
+constexpr int kDBlocksPerCU = 8;
 
 template <typename T, bool HAS_PW, bool FIRST>
-__global__ __launch_bounds__(kOT) void k_own_gather(OGeom tg, GridDesc<3> gd, int64_t P, int64_t B,
-                                                    const T* __restrict__ points, const T* __restrict__ pw,
-                                                    int vec_ok, const T* __restrict__ g,
-                                                    const T* __restrict__ rot, const T* __restrict__ trans,
-                                                    const T* __restrict__ ow, int64_t b, int bl, int reuse,
-                                                    OwnTileArgs ta, T* __restrict__ ds_dpoints,
-                                                    T* __restrict__ ds_dpw, double* __restrict__ partials,
-                                                    int NTp /* partial slots: NT + max_slabs */) {
-    extern __shared__ unsigned char smem[];
-    OwnGatherLds* sl = (OwnGatherLds*)smem;
-    T* tile_g = (T*)(smem + sizeof(OwnGatherLds));
-    if (reuse && !own_header_ok<T>(ta, gd, P, B, points, pw, rot, trans, b, bl)) {
-        // nothing can be trusted: every block NaN-fills its share of the point gradients; the
-        // reduce kernel sees the same header and stores NaN per-pose sums
-        const T nanv = T(__builtin_nanf(""));
-        for (int64_t i = (int64_t)blockIdx.x * kOT + threadIdx.x; i < P; i += (int64_t)gridDim.x * kOT) {
-            for (int j = 0; j < 3; ++j) ds_dpoints[i * 3 + j] = nanv;
-            if (ds_dpw) ds_dpw[i] = nanv;
-        }
-        return;
-    }
-    uint32_t tile, part, nparts;
-    if (!own_item(ta, bl, blockIdx.x, tile, part, nparts)) return;
-    const TileRec rec = ((const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride))[tile];
-    int tc[3], x0[3];
-    tile_coords((int)tile, tg, tc, x0);
-    const T* gb = g + b * gd.G;
-    // stage the padded ds_dout tile (cells beyond the grid: 0); eight loads in flight per thread
-    double bg_sum = 0.0;
-    {
-        constexpr int IT = (kPCells + kOT - 1) / kOT, HB = 8;
-#pragma unroll 1
-        for (int k0 = 0; k0 < IT; k0 += HB) {
-            T v[HB];
-            bool own[HB];
-#pragma unroll
-            for (int k = 0; k < HB; ++k) {
-                const int i = threadIdx.x + (k0 + k) * kOT;
-                const int x = i % kPX, y = (i / kPX) % kPY, z = i / (kPX * kPY);
-                const int g0 = x0[0] - 1 + x, g1 = x0[1] - 1 + y, g2 = x0[2] - 1 + z;
-                const bool ok = i < kPCells && g0 >= 0 && g1 >= 0 && g2 >= 0 && g0 < gd.n[0] && g1 < gd.n[1] && g2 < gd.n[2];
-                const T xv = gb[ok ? ((size_t)g2 * gd.n[1] + g1) * gd.n[0] + g0 : 0];
-                v[k] = ok ? xv : T(0);
-                own[k] = ok && x >= 1 && x <= kTX && y >= 1 && y <= kTY && z >= 1 && z <= kTZ;
-            }
-#pragma unroll
-            for (int k = 0; k < HB; ++k) {
-                const int i = threadIdx.x + (k0 + k) * kOT;
-                if (i < kPCells) tile_g[i] = v[k];
-                if (own[k] && part == 0) bg_sum += (double)v[k];
-            }
-        }
-    }
-    if (threadIdx.x == 0) {
-        sl->walk.next = 0u;
-        sl->walk.pool_n = 0u;
-    }
+__global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P, int64_t per_block,
+                                                      int64_t cells_per_block,
+                                                      const T* __restrict__ points, const T* __restrict__ pw,
+                                                      const T* __restrict__ g, const T* __restrict__ rot,
+                                                      const T* __restrict__ trans, const T* __restrict__ ow,
+                                                      int64_t b, T* __restrict__ ds_dpoints,
+                                                      T* __restrict__ ds_dpw, double* __restrict__ partials) {
+    __shared__ double red[kDT / kWave][kNVal];
     const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
-    const TileRange tr = tile_range(tc, tg);
     const OwnXform<T> xf = own_xform<T>(ps, gd);
-    __syncthreads();
+    const T* gb = g + b * gd.G;
+    const int64_t p_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t p_hi = p_lo + per_block < P ? p_lo + per_block : P;
     T vals[kNVal - 1];
 #pragma unroll
     for (int k = 0; k < kNVal - 1; ++k) vals[k] = T(0);
-    auto visit = [&](uint32_t sc, bool have) {
-        own_points_single<T, HAS_PW>(sc, have, P, points, pw, [&](int i, bool live, const T (&pt)[3], T pwi) {
-            const int64_t p = (int64_t)sc * kSC + i;
-            // src/raster.jl:88-99 per axis, plus the owner tile of the point: the tile of its base
-            // voxel clamped into the grid (a rejected point belongs to a border tile; NaN -> 0)
-            int ref0[3];
-            T dlo[3];
-            bool ok = true, mine = live;
+    const int n0 = gd.n[0], n1 = gd.n[1], n2 = gd.n[2];
+    T nxt[3] = {T(0), T(0), T(0)}, wn = T(1);
+    {
+        const int64_t p = p_lo + threadIdx.x;
+        const int64_t pc = p < P ? p : (P > 0 ? P - 1 : 0);
+        if (P > 0) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                T proj = ps.R[d] * pt[0];
-                proj = proj + ps.R[d + 3] * pt[1];
-                proj = proj + ps.R[d + 6] * pt[2];
-                const T coord = (proj - xf.origin[d]) * xf.scale[d];
-                const T c = coord - T(0.5);
-                const bool above = c > T(-1), below = c <= xf.nf[d];
-                const bool okd = above && below;
-                const T r_ = ceil_t<T>(c);
-                const int rd = okd ? (int)r_ - 1 : 0;
-                ref0[d] = rd;
-                dlo[d] = coord - (r_ - T(0.5));
-                const int Td = d == 0 ? kTX : (d == 1 ? kTY : kTZ);
-                int owner = (rd < 0 ? 0 : rd) / Td;
-                owner = !above ? 0 : (!below ? tg.nt[d] - 1 : owner);
-                mine = mine && owner == tc[d];
-                ok = ok && okd;
+            for (int j = 0; j < 3; ++j) nxt[j] = points[pc * 3 + j];
+            if constexpr (HAS_PW) wn = pw[pc];
+        }
+    }
+#pragma unroll 1
+    for (int64_t p = p_lo + threadIdx.x; p < p_hi + threadIdx.x; p += kDT) {  // (uniform trip count)
+        const bool live = p < p_hi;
+        const T pt[3] = {nxt[0], nxt[1], nxt[2]};
+        const T pwi = wn;
+        {  // next point of this lane (clamped: the loop body stays branch-free)
+            const int64_t q = p + kDT < P ? p + kDT : P - 1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) nxt[j] = points[q * 3 + j];
+            if constexpr (HAS_PW) wn = pw[q];
+        }
+        int ref0[3];
+        T dlo[3];
+        bool ok = live;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            T proj = ps.R[d] * pt[0];
+            proj = proj + ps.R[d + 3] * pt[1];
+            proj = proj + ps.R[d + 6] * pt[2];
+            const T coord = (proj - xf.origin[d]) * xf.scale[d];
+            const T c = coord - T(0.5);
+            ok = ok && (c > T(-1)) && (c <= xf.nf[d]);
+            const T r = ceil_t<T>(c);
+            ref0[d] = ok ? (int)r - 1 : 0;
+            dlo[d] = coord - (r - T(0.5));
+        }
+        // the eight cells: all requested before the first is used; a neighbour outside the grid
+        // (individual drop, src/raster_pullback.jl:51) reads cell 0 and counts as 0
+        const bool lo0 = ref0[0] >= 0, hi0 = ref0[0] + 1 < n0, lo1 = ref0[1] >= 0, hi1 = ref0[1] + 1 < n1,
+                   lo2 = ref0[2] >= 0, hi2 = ref0[2] + 1 < n2;
+        const int64_t base = ((int64_t)ref0[2] * n1 + ref0[1]) * n0 + ref0[0];
+        T gv[8];
+        bool in[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int s0 = s & 1, s1 = (s >> 1) & 1, s2 = s >> 2;
+            in[s] = ok && (s0 ? hi0 : lo0) && (s1 ? hi1 : lo1) && (s2 ? hi2 : lo2);
+            const int64_t off = base + s0 + (int64_t)n0 * (s1 + (int64_t)n1 * s2);
+            gv[s] = gb[in[s] ? off : 0];
+        }
+        T gout[3] = {T(0), T(0), T(0)}, dpw_part = T(0);
+        {
+            T dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const T gi = in[s] ? gv[s] : T(0);
+                const T dweight = voxel_weight<T, 3>(dlo, s, gi);  // raster_pullback.jl:55
+                dow_part += dweight * pwi;                         // :57
+                dpw_part += dweight * ps.ow;                       // :58
+                const T factor = gi * ps.ow * pwi;                 // :60
+#pragma unroll
+                for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, dlo, s);
             }
-            if (!mine) return;
-            T gout[3] = {T(0), T(0), T(0)}, dpw_part = T(0);
-            if (ok) {
-                // padded tile coordinates of the lower neighbour: 0 .. T - 1 (0: below the grid, staged as 0)
-                const T* cell = tile_g + ((ref0[0] - x0[0] + 1) + kPX * (ref0[1] - x0[1] + 1) + kPX * kPY * (ref0[2] - x0[2] + 1));
-                T gv[8];
+            T scaled[3];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) gv[s] = cell[(s & 1) + kPX * ((s >> 1) & 1) + kPX * kPY * (s >> 2)];
-                T dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
+            for (int n = 0; n < 3; ++n) scaled[n] = ok ? dcoord[n] * xf.scale[n] : T(0);  // :67
+            dpw_part = ok ? dpw_part : T(0);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const T gi = gv[s];
-                    const T dweight = voxel_weight<T, 3>(dlo, s, gi);  // raster_pullback.jl:55
-                    dow_part += dweight * pwi;                         // :57
-                    dpw_part += dweight * ps.ow;                       // :58
-                    const T factor = gi * ps.ow * pwi;                 // :60
+            for (int n = 0; n < 3; ++n) {
 #pragma unroll
-                    for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, dlo, s);
-                }
-                T scaled[3];
-#pragma unroll
-                for (int n = 0; n < 3; ++n) scaled[n] = dcoord[n] * xf.scale[n];  // :67
-#pragma unroll
-                for (int n = 0; n < 3; ++n) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) vals[n + j * 3] += scaled[n] * pt[j];  // :69
-                    vals[9 + n] += scaled[n];                                         // :68
-                }
-                vals[12] += dow_part;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {  // rotation' * scaled (:70)
-                    T v = ps.R[0 + j * 3] * scaled[0];
-                    v = v + ps.R[1 + j * 3] * scaled[1];
-                    v = v + ps.R[2 + j * 3] * scaled[2];
-                    gout[j] = v;
-                }
+                for (int j = 0; j < 3; ++j) vals[n + j * 3] += scaled[n] * pt[j];  // :69
+                vals[9 + n] += scaled[n];                                         // :68
             }
+            vals[12] += ok ? dow_part : T(0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {  // rotation' * scaled (:70)
+                T v = ps.R[0 + j * 3] * scaled[0];
+                v = v + ps.R[1 + j * 3] * scaled[1];
+                v = v + ps.R[2 + j * 3] * scaled[2];
+                gout[j] = v;
+            }
+        }
+        if (live) {
             if (FIRST) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) ds_dpoints[p * 3 + j] = gout[j];
-                if (ds_dpw) ds_dpw[p] = dpw_part;
-            } else if (ok) {
+                for (int j = 0; j < 3; ++j) __builtin_nontemporal_store(gout[j], &ds_dpoints[p * 3 + j]);
+                if (ds_dpw) __builtin_nontemporal_store(dpw_part, &ds_dpw[p]);
+            } else {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) ds_dpoints[p * 3 + j] += gout[j];
                 if (ds_dpw) ds_dpw[p] += dpw_part;
             }
-        });
-    };
-    own_walk<T, false>(ta, rec, bl, part, nparts, ps, gd, tr, &sl->walk, visit);
-    // per-item partial sums: T per thread, f64 across the block
+        }
+    }
+    // ds_dbackground: this block's slice of the grid (16 bytes per load where the slice allows)
+    double bg_sum = 0.0;
+    {
+        const int64_t c_lo = (int64_t)blockIdx.x * cells_per_block;
+        const int64_t c_hi = c_lo + cells_per_block < gd.G ? c_lo + cells_per_block : gd.G;
+        constexpr int PER = 16 / (int)sizeof(T);
+        typedef T VecT __attribute__((ext_vector_type(PER)));
+        int64_t i = c_lo;
+        if ((((uintptr_t)(gb + c_lo)) & 15) == 0) {  // (uniform)
+            T a[PER];
+#pragma unroll
+            for (int e = 0; e < PER; ++e) a[e] = T(0);
+            for (i = c_lo + (int64_t)threadIdx.x * PER; i + PER <= c_hi; i += (int64_t)kDT * PER) {
+                const VecT v = __builtin_nontemporal_load((const VecT*)(gb + i));
+#pragma unroll
+                for (int e = 0; e < PER; ++e) a[e] += v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < PER; ++e) bg_sum += (double)a[e];
+            // the tail of the slice (fewer than PER cells): first lanes
+            i = c_lo + (c_hi - c_lo) / PER * PER + threadIdx.x;
+            if (i < c_hi) bg_sum += (double)gb[i];
+        } else {
+            for (i = c_lo + threadIdx.x; i < c_hi; i += kDT) bg_sum += (double)gb[i];
+        }
+    }
+    // per-block partial sums: T per thread, f64 across the block
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
     for (int k = 0; k < kNVal; ++k) {
         const double v = (k < kNVal - 1) ? (double)vals[k < kNVal - 1 ? k : 0] : bg_sum;
-        const double s = wave_sum<double>(v);
-        if (lane == 0) sl->red[wave][k] = s;
+        const double sm = wave_sum<double>(v);
+        if (lane == 0) red[wave][k] = sm;
     }
     __syncthreads();
     if (threadIdx.x < kNVal) {
-        double s = 0.0;
+        double sm = 0.0;
 #pragma unroll
-        for (int w = 0; w < kOW; ++w) s += sl->red[w][threadIdx.x];
-        const uint32_t slot = nparts > 1 ? (uint32_t)tg.NT + (rec.parts >> 8) + part : tile;
-        partials[(size_t)threadIdx.x * NTp + slot] = s;
+        for (int w = 0; w < kDT / kWave; ++w) sm += red[w][threadIdx.x];
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sm;
     }
 }
 
-// per-pose sums from the per-item partials, tiles in index order, parts in part order
+// per-pose sums from the per-block partials, in block order
 template <typename T>
-__global__ __launch_bounds__(1024) void k_own_reduce(OGeom tg, GridDesc<3> gd, int64_t P, int64_t B,
-                                                     const T* points, const T* pw, const T* __restrict__ rot,
-                                                     const T* __restrict__ trans, int64_t b, int bl, int reuse,
-                                                     OwnTileArgs ta, const double* __restrict__ partials, int NTp,
+__global__ __launch_bounds__(1024) void k_own_reduce(const double* __restrict__ partials, int nblocks, int64_t b,
                                                      T* __restrict__ ds_drotation, T* __restrict__ ds_dtranslation,
                                                      T* __restrict__ ds_dbackground, T* __restrict__ ds_dout_weight) {
     __shared__ double wsum[16];
     const int k = blockIdx.x;
-    const bool stale = reuse && !own_header_ok<T>(ta, gd, P, B, points, pw, rot, trans, b, bl);
     double s = 0.0;
-    if (!stale) {
-        const TileRec* recs = (const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride);
-        for (int t = threadIdx.x; t < tg.NT; t += 1024) {
-            const uint32_t parts = recs[t].parts;
-            const uint32_t np = parts & 0xffu, first = parts >> 8;
-            if (np <= 1) {
-                s += partials[(size_t)k * NTp + t];
-            } else {
-                for (uint32_t q = 0; q < np; ++q) s += partials[(size_t)k * NTp + tg.NT + first + q];
-            }
-        }
-    }
+    for (int t = threadIdx.x; t < nblocks; t += 1024) s += partials[(size_t)k * nblocks + t];
     s = wave_sum<double>(s);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -1207,11 +1121,10 @@ __global__ __launch_bounds__(1024) void k_own_reduce(OGeom tg, GridDesc<3> gd, i
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) tot += wsum[w];
-        if (stale) tot = (double)__builtin_nanf("");
         if (k < 9) ds_drotation[b * 9 + k] = (T)tot;
         else if (k < 12) ds_dtranslation[b * 3 + (k - 9)] = (T)tot;
         else if (k == 12) ds_dout_weight[b] = (T)tot;
-        else ds_dbackground[b] = (T)tot;  // (its partial sums come from the gather kernel too)
+        else ds_dbackground[b] = (T)tot;
     }
 }
 
@@ -1222,7 +1135,7 @@ struct OwnPlan {
     int64_t nSC, nL1, nL2, Bw;
     uint32_t list_cap, cap;
     int max_items, max_slabs, max_split;
-    size_t off_hdr, off_ctl, off_b0, off_b1, off_b2, off_rec, off_list, off_items, off_split, off_slabs, off_partials, total;
+    size_t off_ctl, off_b0, off_b1, off_b2, off_rec, off_list, off_items, off_split, off_slabs, total;
     size_t rec_stride, list_stride, items_stride, split_stride;
 };
 
@@ -1262,8 +1175,6 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     const int64_t lc = pl.nL1 * 16 + tg.NT;
     pl.list_cap = (uint32_t)(lc > 0x7fffffff ? 0x7fffffff : lc);
     size_t o = 0;
-    pl.off_hdr = o;
-    o += oalign(sizeof(OwnHeader));
     pl.off_ctl = o;
     o += oalign((size_t)pl.Bw * kCtlWords * 4);
     pl.off_b0 = o;
@@ -1285,9 +1196,7 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     pl.off_split = o;
     o += pl.split_stride * pl.Bw;
     pl.off_slabs = o;
-    if (op == DPR_OP_RASTER) o += oalign((size_t)pl.max_slabs * kCells * 8);
-    pl.off_partials = o;
-    if (op == DPR_OP_PULLBACK) o += oalign((size_t)(tg.NT + pl.max_slabs) * kNVal * 8);
+    o += oalign((size_t)pl.max_slabs * kCells * 8);
     pl.total = o;
     return pl;
 }
@@ -1299,10 +1208,10 @@ bool owner_supported(const int64_t* grid) {
 
 size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B) {
     OGeom tg;
-    if (!make_ogeom(grid, &tg) || P >= ((int64_t)1 << 32) * kSC / 16) return (size_t)-1;
-    // a KEEP forward and its REUSE pullback share one layout: the larger of the two
-    const OwnPlan a = make_oplan(DPR_OP_RASTER, tg, P, B), b = make_oplan(DPR_OP_PULLBACK, tg, P, B);
-    return a.total > b.total ? a.total : b.total;
+    if (!make_ogeom(grid, &tg) || P >= ((int64_t)1 << 32)) return (size_t)-1;
+    // pullback: per-block partial sums only (at most 65536 blocks)
+    if (op == DPR_OP_PULLBACK) return oalign((size_t)65536 * kNVal * 8);
+    return make_oplan(DPR_OP_RASTER, tg, P, B).total;
 }
 
 #define DPR_HIP(expr)                                                                \
@@ -1319,7 +1228,7 @@ static GridDesc<3> ogrid_desc(const int64_t* grid, int64_t G) {
     return gd;
 }
 
-static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws, bool keep) {
+static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws) {
     OwnPlanArgs pa;
     pa.ws = ws;
     pa.off_ctl = pl.off_ctl;
@@ -1327,7 +1236,6 @@ static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws, bool keep) {
     pa.off_list = pl.off_list;
     pa.off_items = pl.off_items;
     pa.off_split = pl.off_split;
-    pa.off_hdr = pl.off_hdr;
     pa.rec_stride = pl.rec_stride;
     pa.list_stride = pl.list_stride;
     pa.items_stride = pl.items_stride;
@@ -1338,7 +1246,6 @@ static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws, bool keep) {
     pa.max_split = pl.max_split;
     pa.cap = pl.cap;
     pa.fixed = oknobs().fixed;
-    pa.keep = keep ? 1 : 0;
     return pa;
 }
 static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
@@ -1348,7 +1255,6 @@ static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
     ta.off_rec = pl.off_rec;
     ta.off_list = pl.off_list;
     ta.off_items = pl.off_items;
-    ta.off_hdr = pl.off_hdr;
     ta.rec_stride = pl.rec_stride;
     ta.list_stride = pl.list_stride;
     ta.items_stride = pl.items_stride;
@@ -1357,6 +1263,7 @@ static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
     ta.nSC = pl.nSC;
     ta.b0 = (const Box0*)(ws + pl.off_b0);
     ta.b1 = (const Box1*)(ws + pl.off_b1);
+    ta.dbg_words = (size_t)pl.max_slabs * kCells * 2;
     return ta;
 }
 
@@ -1368,7 +1275,7 @@ template <typename T> static bool vec_ok(const T* points, const T* pw) {
 template <typename T>
 static int own_prepare(hipStream_t st, const OGeom& tg, const GridDesc<3>& gd, const OwnPlan& pl, char* ws,
                        int64_t P, int64_t B, const T* points, const T* pw, const T* rot, const T* trans,
-                       const T* ow, int64_t b0, int64_t nb, bool boxes, bool keep) {
+                       const T* ow, int64_t b0, int64_t nb, bool boxes) {
     uint32_t* ctl = (uint32_t*)(ws + pl.off_ctl);
     const int ctl_words = (int)(pl.Bw * kCtlWords);
     if (boxes && P > 0) {
@@ -1383,7 +1290,7 @@ static int own_prepare(hipStream_t st, const OGeom& tg, const GridDesc<3>& gd, c
     stage_mark(st);
     hipLaunchKernelGGL((k_own_plan<T>), dim3((unsigned)tg.NT, (unsigned)nb), dim3(256), 0, st, tg, gd, P, B,
                        pl.nL1, pl.nL2, (const Box1*)(ws + pl.off_b1), (const Box1*)(ws + pl.off_b2), rot,
-                       trans, ow, points, pw, b0, plan_args(pl, ws, keep));
+                       trans, ow, points, pw, b0, plan_args(pl, ws));
     stage_mark(st);
     return DPR_OK;
 }
@@ -1401,10 +1308,8 @@ int raster_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     if (!make_ogeom(grid, &tg))
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles", kMaxOwnTiles);
     if (P >= ((int64_t)1 << 32)) return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
-    const bool keep = flags & DPR_FLAG_KEEP_BINNING;
-    if (keep && B > kOwnBw)
-        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING on 3-D DPR_ALGO_CHUNKED needs B <= %d (got %lld)",
-                    kOwnBw, (long long)B);
+    // (DPR_FLAG_KEEP_BINNING: the pullback of this path reads nothing a forward could leave -- accepted)
+    (void)flags;
     const size_t need = owner_workspace_bytes(DPR_OP_RASTER, grid, P, B);
     if (!ws_ || ws_bytes < need)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED raster needs %zu workspace bytes, got %zu", need,
@@ -1420,7 +1325,7 @@ int raster_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     }
     for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
         const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
-        if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, B, points, pw, rot, trans, ow, b0, nb, b0 == 0, keep))
+        if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, B, points, pw, rot, trans, ow, b0, nb, b0 == 0))
             return rc;
         const OwnTileArgs ta = tile_args(pl, ws);
         unsigned long long* slabs = (unsigned long long*)(ws + pl.off_slabs);
@@ -1442,72 +1347,58 @@ int raster_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     return DPR_OK;
 }
 
+// compute units of the current device
+static int own_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+        n = 256;
+    return n;
+}
+static int own_pullback_blocks(int64_t P, int64_t G) {
+    int64_t nb = (int64_t)own_cu_count() * kDBlocksPerCU;
+    const int64_t by_points = (P + kDT - 1) / kDT, by_cells = (G + 4 * kDT - 1) / (4 * kDT);
+    const int64_t want = by_points > by_cells ? by_points : by_cells;
+    if (nb > want) nb = want;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
 template <typename T>
 int pullback_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B,
                    const T* g, const T* points, const T* rot, const T* trans, const T* ow, const T* pw,
                    T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw, void* ws_, size_t ws_bytes) {
-    OGeom tg;
-    if (!make_ogeom(grid, &tg))
-        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles", kMaxOwnTiles);
-    if (P >= ((int64_t)1 << 32)) return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
-    const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
-    if (reuse && B > kOwnBw)
-        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING on 3-D DPR_ALGO_CHUNKED needs B <= %d (got %lld)",
-                    kOwnBw, (long long)B);
+    // (DPR_FLAG_REUSE_BINNING: this pullback reads nothing the forward left -- accepted, nothing to validate)
+    (void)flags;
     const size_t need = owner_workspace_bytes(DPR_OP_PULLBACK, grid, P, B);
     if (!ws_ || ws_bytes < need)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED pullback needs %zu workspace bytes, got %zu", need,
                     ws_ ? ws_bytes : (size_t)0);
-    char* ws = (char*)ws_;
     const GridDesc<3> gd = ogrid_desc(grid, G);
-    const OwnPlan pl = make_oplan(DPR_OP_PULLBACK, tg, P, B);
-    // (the partial sums sit where the forward's slabs were: the lists, records and boxes in front
-    // of them are at the same offsets in both layouts)
-    double* partials = (double*)(ws + pl.off_partials);
-    const int NTp = tg.NT + pl.max_slabs;
-    const size_t lds = sizeof(OwnGatherLds) + (size_t)kPCells * sizeof(T);
-#define DPR_OWN_ATTR(HAS_PW, FIRST) \
-    if (int rc = own_lds(k_own_gather<T, HAS_PW, FIRST>, lds)) return rc;
-    if (pw) {
-        DPR_OWN_ATTR(true, true)
-        DPR_OWN_ATTR(true, false)
-    } else {
-        DPR_OWN_ATTR(false, true)
-        DPR_OWN_ATTR(false, false)
-    }
-#undef DPR_OWN_ATTR
-    const int vok = vec_ok(points, pw) ? 1 : 0;
-    for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
-        const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
-        if (reuse) {
-            stage_mark(st);
-            stage_mark(st);
-        } else if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, B, points, pw, rot, trans, ow, b0, nb, b0 == 0,
-                                           false))
-            return rc;
-        const OwnTileArgs ta = tile_args(pl, ws);
+    const int nblocks = own_pullback_blocks(P, G);
+    int64_t per_block = ((P + nblocks - 1) / nblocks + kDT - 1) / kDT * kDT;
+    if (per_block < kDT) per_block = kDT;
+    const int64_t cells_per_block = ((G + nblocks - 1) / nblocks + 3) / 4 * 4;
+    // (the partial sums sit at the start of the workspace: a forward's boxes and plan, further up in
+    // a KEEP / REUSE pair's shared buffer, are not this call's business -- it overwrites the header)
+    double* partials = (double*)ws_;
+    for (int64_t b = 0; b < B; ++b) {
         // the point gradients accumulate over poses: one pose per launch (stream order = race-free
-        // read-modify-write; every point has exactly one owner per pose)
-        for (int64_t bl = 0; bl < nb; ++bl) {
-            const int64_t b = b0 + bl;
-            const dim3 tgrid((unsigned)pl.max_items);
-#define DPR_OWN_GATHER(HAS_PW, FIRST)                                                                       \
-    hipLaunchKernelGGL((k_own_gather<T, HAS_PW, FIRST>), tgrid, dim3(kOT), lds, st, tg, gd, P, B, points, pw, \
-                       vok, g, rot, trans, ow, b, (int)bl, reuse ? 1 : 0, ta, d_pts, d_pw, partials, NTp)
-            if (pw) {
-                if (b == 0) DPR_OWN_GATHER(true, true);
-                else DPR_OWN_GATHER(true, false);
-            } else {
-                if (b == 0) DPR_OWN_GATHER(false, true);
-                else DPR_OWN_GATHER(false, false);
-            }
-#undef DPR_OWN_GATHER
-            stage_mark(st);
-            hipLaunchKernelGGL((k_own_reduce<T>), dim3(kNVal), dim3(1024), 0, st, tg, gd, P, B, points, pw, rot,
-                               trans, b, (int)bl, reuse ? 1 : 0, ta, (const double*)partials, NTp, d_rot,
-                               d_trans, d_bg, d_ow);
-            stage_mark(st);
+        // read-modify-write)
+#define DPR_OWN_PB(HAS_PW, FIRST)                                                                            \
+    hipLaunchKernelGGL((k_own_pullback<T, HAS_PW, FIRST>), dim3((unsigned)nblocks), dim3(kDT), 0, st, gd, P, \
+                       per_block, cells_per_block, points, pw, g, rot, trans, ow, b, d_pts, d_pw, partials)
+        if (pw) {
+            if (b == 0) DPR_OWN_PB(true, true);
+            else DPR_OWN_PB(true, false);
+        } else {
+            if (b == 0) DPR_OWN_PB(false, true);
+            else DPR_OWN_PB(false, false);
         }
+#undef DPR_OWN_PB
+        if (b == 0) stage_mark(st);
+        hipLaunchKernelGGL((k_own_reduce<T>), dim3(kNVal), dim3(1024), 0, st, (const double*)partials, nblocks, b,
+                           d_rot, d_trans, d_bg, d_ow);
+        if (b == 0) stage_mark(st);
     }
     DPR_HIP(hipGetLastError());
     return DPR_OK;

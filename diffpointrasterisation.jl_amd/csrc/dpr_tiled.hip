@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
             // no in-range voxel: empty gradient (written once, by the first pose)
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[pc * NI + j] = T(0);
-            ds_dpw[pc] = T(0);
+            if (ds_dpw) ds_dpw[pc] = T(0);
         }
     }
     if (HAS_PW) publish_max_abs(maxpw, max_w);
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
                     if (zero_dropped) {
 #pragma unroll
                         for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-                        ds_dpw[p] = T(0);
+                        if (ds_dpw) ds_dpw[p] = T(0);
                     }
                 }
             }
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_l
                     T* const dp_blk = ds_dpoints + base * NI;
 #pragma unroll
                     for (int j = 0; j < NI; ++j) dp_blk[lp * NI + j] = T(0);
-                    (ds_dpw + base)[lp] = T(0);
+                    if (ds_dpw) (ds_dpw + base)[lp] = T(0);
                 }
             }
         }
@@ -2587,11 +2587,11 @@ __global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) vo
         } else if (FIRST_POSE) {  // this thread is the only writer of point p for this pose
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] = dp[j];
-            ds_dpw[p] = dpw_part;
+            if (ds_dpw) ds_dpw[p] = dpw_part;
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] += dp[j];
-            ds_dpw[p] += dpw_part;
+            if (ds_dpw) ds_dpw[p] += dpw_part;
         }
     }
     // per-tile partial sums of the per-pose scalars (f64), reduced later by k_pose_reduce
@@ -2867,11 +2867,11 @@ __global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) vo
                 } else if (FIRST_POSE) {  // this thread is the only writer of point p for this pose
         #pragma unroll
                     for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] = dp[j];
-                    ds_dpw[p] = dpw_part;
+                    if (ds_dpw) ds_dpw[p] = dpw_part;
                 } else {
         #pragma unroll
                     for (int j = 0; j < NI; ++j) ds_dpoints[(size_t)p * NI + j] += dp[j];
-                    ds_dpw[p] += dpw_part;
+                    if (ds_dpw) ds_dpw[p] += dpw_part;
                 }
             }
             d0 += kMaxRunsGather;
@@ -3004,7 +3004,7 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
             if (p >= P) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = nan;
-            ds_dpw[p] = nan;
+            if (ds_dpw) ds_dpw[p] = nan;
         }
         return;
     }
@@ -3042,11 +3042,11 @@ __global__ __launch_bounds__(1024) void k_unpermute(int64_t P, int nb,
         if (FIRST_POSE) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) __builtin_nontemporal_store(g[k].v[j], &ds_dpoints[p * NI + j]);
-            __builtin_nontemporal_store(g[k].v[3], &ds_dpw[p]);
+            if (ds_dpw) __builtin_nontemporal_store(g[k].v[3], &ds_dpw[p]);
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] += g[k].v[j];
-            ds_dpw[p] += g[k].v[3];
+            if (ds_dpw) ds_dpw[p] += g[k].v[3];
         }
     }
 }
@@ -3079,7 +3079,7 @@ __global__ __launch_bounds__(256) void k_unsort(int64_t P, const uint32_t* __res
             if (q >= P) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j) ds_dpoints[q * NI + j] = nan;
-            ds_dpw[q] = nan;
+            if (ds_dpw) ds_dpw[q] = nan;
         }
         return;
     }
@@ -3095,7 +3095,7 @@ __global__ __launch_bounds__(256) void k_unsort(int64_t P, const uint32_t* __res
     for (int k = 0; k < PER; ++k) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) v[k][j] = dp_sorted[i[k] * NI + j];
-        w[k] = dpw_sorted[i[k]];
+        w[k] = ds_dpw ? dpw_sorted[i[k]] : T(0);
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
@@ -3103,7 +3103,7 @@ __global__ __launch_bounds__(256) void k_unsort(int64_t P, const uint32_t* __res
         if (q >= P) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j) ds_dpoints[q * NI + j] = v[k][j];
-        ds_dpw[q] = w[k];
+        if (ds_dpw) ds_dpw[q] = w[k];
     }
 }
 
@@ -3905,7 +3905,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
         points = (const T*)(ws + pl.off_spts);
         pw = spw;
         d_pts = (T*)(ws + pl.off_sgrad);   // gradients in sorted order, scattered back at the end
-        d_pw = (T*)(ws + pl.off_sgradw);
+        if (d_pw) d_pw = (T*)(ws + pl.off_sgradw);  // (NULL: the caller declined this gradient)
     }
     double* partials = (double*)(ws + pl.off_aux);
     constexpr int NVAL = NO * NI + NO + 2;  // + 1 loss column in residual mode
@@ -3960,7 +3960,7 @@ int pullback_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
             // (once, before the first pose: the later poses of a kept batch accumulate)
             if (P > 0 && !unperm && b == 0) {
                 DPR_HIP(hipMemsetAsync(d_pts, 0, sizeof(T) * (size_t)(P * NI), st));
-                DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
+                if (d_pw) DPR_HIP(hipMemsetAsync(d_pw, 0, sizeof(T) * (size_t)P, st));
             }
             stage_mark(st);
             stage_mark(st);

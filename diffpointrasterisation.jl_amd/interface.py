@@ -306,7 +306,8 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
                      ds_dtranslation=None, ds_dbackground=None, ds_dout_weight=None,
                      ds_dpoint_weight=None, algo: str = "auto", workspace=None,
                      reuse_binning: bool = False, max_pose_group: int = 0,
-                     coherent_points: bool = False) -> PullbackResult:
+                     coherent_points: bool = False,
+                     point_weight_grad: bool = True) -> PullbackResult:
     """The reference's `raster_pullback!` (src/interface.jl:196-308).  Optional keyword
     arguments are pre-allocated outputs (the reference's `points=`, `rotation=`, ... kwargs,
     src/interface.jl:278-291); they are OVERWRITTEN and returned by identity.  Unlike the
@@ -315,11 +316,15 @@ def raster_pullback_(ds_dout, points, rotation, translation, background=None, ou
 
     Returned layouts: points (P, N_in); rotation (B, N_out, N_in) -- a transposed view of
     the column-major (N_out, N_in, B) buffer; translation (B, N_out); background,
-    out_weight (B,); point_weight (P,)."""
+    out_weight (B,); point_weight (P,).
+
+    `point_weight_grad=False` (DPR_FLAG_NO_POINT_WEIGHT_GRAD): ds_dpoint_weight is neither
+    allocated nor written and comes back as None -- what the reference's rrule throws away
+    when `point_weight` was defaulted (ext/DiffPointRasterisationChainRulesCoreExt.jl:23,70)."""
     return _pullback(ds_dout, None, points, rotation, translation, background, out_weight,
                      point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
                      ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning,
-                     max_pose_group, coherent_points)
+                     max_pose_group, coherent_points, point_weight_grad)
 
 
 def raster_residual_pullback_(out, target, points, rotation, translation, background=None,
@@ -347,7 +352,7 @@ def raster_residual_pullback_(out, target, points, rotation, translation, backgr
 def _pullback(ds_dout, residual, points, rotation, translation, background, out_weight,
               point_weight, ds_dpoints, ds_drotation, ds_dtranslation, ds_dbackground,
               ds_dout_weight, ds_dpoint_weight, algo, workspace, reuse_binning,
-              max_pose_group=0, coherent_points=False):
+              max_pose_group=0, coherent_points=False, point_weight_grad=True):
     import numpy as np
 
     c = _canonicalise(points, rotation, translation, background, out_weight, point_weight,
@@ -403,7 +408,9 @@ def _pullback(ds_dout, residual, points, rotation, translation, background, out_
                    "ds_dbackground")
     d_ow = out_buf(None if ds_dout_weight is None else ds_dout_weight.reshape(B), (B,),
                    "ds_dout_weight")
-    d_pw = out_buf(ds_dpoint_weight, (P,), "ds_dpoint_weight")
+    if not point_weight_grad and ds_dpoint_weight is not None:
+        raise ValueError("point_weight_grad=False and a ds_dpoint_weight buffer contradict each other")
+    d_pw = out_buf(ds_dpoint_weight, (P,), "ds_dpoint_weight") if point_weight_grad else None
     d_loss = None
     if residual is not None:
         d_loss = out_buf(None if loss is None else loss.reshape(B), (B,), "loss")
@@ -414,6 +421,7 @@ def _pullback(ds_dout, residual, points, rotation, translation, background, out_
         flags = _lib.flag_max_pose_group(max_pose_group)
         flags |= _lib.FLAG_COHERENT_POINTS if coherent_points else 0
         flags |= _lib.FLAG_REUSE_BINNING if reuse_binning else 0
+        flags |= 0 if point_weight_grad else _lib.FLAG_NO_POINT_WEIGHT_GRAD
         ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
                                   workspace, flags)
         if reuse_binning and workspace is None:

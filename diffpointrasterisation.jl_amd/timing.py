@@ -14,7 +14,7 @@ STAGES = {
     ("raster", "tiled"): ["count", "scan", "scatter", "tile_splat", "halo"],
     # DPR_ALGO_CHUNKED on 3-D grids (owner-computes tiles over a box hierarchy)
     ("raster", "chunked"): ["boxes", "plan", "own_splat", "combine"],
-    ("pullback", "chunked"): ["boxes", "plan", "own_gather", "pose_reduce"],
+    ("pullback", "chunked"): ["direct_gather", "pose_reduce"],
     ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "unpermute", "pose_reduce"],
     # DPR_ALGO_TILED with coherent_points=True (local binning): pass algo="tiled_local"
     ("raster", "tiled_local"): ["clear", "bin_local", "runscan", "tile_splat", "halo"],

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define DPR_VERSION 103 /* 0.1.3: + dpr_resolve_flags_ex, batch KEEP / REUSE, 1 <= n_out <= n_in <= 3 */
+#define DPR_VERSION 104 /* 0.1.4: + DPR_FLAG_NO_POINT_WEIGHT_GRAD; 3-D DPR_ALGO_CHUNKED = owner-computes tiles over a box hierarchy */
 
 /* status codes */
 #define DPR_OK 0
@@ -168,6 +168,12 @@ extern "C" {
  * 4096 tiles order the cloud themselves first (a counting sort into 4096 cells of the model frame,
  * once per call).  A wrong claim costs speed, never correctness. */
 #define DPR_FLAG_COHERENT_POINTS 4u
+/* DPR_FLAG_NO_POINT_WEIGHT_GRAD (pullback entry points): the caller does not need
+ * ds_dpoint_weight -- the reference's rrule drops that tangent whenever `point_weight` was
+ * defaulted (ext/DiffPointRasterisationChainRulesCoreExt.jl:23,70).  The pointer may be NULL and
+ * nothing is written through it (a P-element store per call less; every algorithm honours it).
+ * The five other outputs are unchanged. */
+#define DPR_FLAG_NO_POINT_WEIGHT_GRAD 8u
 
 int dpr_version(void);
 
@@ -205,7 +211,7 @@ int dpr_resolve_flags_ex(int op, unsigned flags, int n_in, int n_out, const int6
  * DPR_ALGO_TILED, per pose -- raster: count, scan, scatter, tile_splat, halo;
  * pullback: count, scan, scatter, tile_gather, unpermute, pose_reduce.
  * DPR_ALGO_CHUNKED, 3-D grids -- raster: boxes, plan, own_splat, combine;
- * pullback: boxes, plan, own_gather, pose_reduce.
+ * pullback: direct_gather, pose_reduce.
  * DPR_ALGO_CHUNKED, 2-D grids -- raster: sort, fill, chunk_splat;
  * pullback: sort, grid_sum, chunk_gather, reduce+unsort. */
 int dpr_stage_timing_begin(void **events, int capacity);

@@ -139,6 +139,47 @@ def test_device_equals_oracle(oracle, dev, algo, npdt, tdt, n_in, n_out, n_point
     _compare(*_run_both(oracle, dev, d, npdt, algo), npdt)
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out,n_points,batch,keep", [
+    (3, 3, 30_000, 1, False), (3, 3, 30_000, 3, False), (3, 2, 30_000, 5, False), (2, 2, 3_000, 2, False),
+    (3, 3, 30_000, 1, True), (3, 2, 30_000, 5, True)])
+def test_pullback_without_the_point_weight_gradient(oracle, dev, algo, npdt, tdt, n_in, n_out, n_points,
+                                                    batch, keep):
+    """DPR_FLAG_NO_POINT_WEIGHT_GRAD (`point_weight_grad=False`): ds_dpoint_weight is neither
+    allocated nor written -- the tangent the reference's rrule drops when point_weight was defaulted
+    (ext/DiffPointRasterisationChainRulesCoreExt.jl:23,70) -- and the five other outputs are those
+    of the plain call (oracle parity), with and without the KEEP / REUSE pairing."""
+    if keep and (algo == "atomic" or (algo == "chunked" and n_out == 3 and batch > 16)):
+        pytest.skip("nothing to keep on this path")
+    d = D.make(n_points=n_points, n_in=n_in, n_out=n_out, batch=batch, grid_n=40 if n_out == 3 else 96,
+               seed=41, dtype=npdt)
+    single = batch == 1
+    args = (T(d.points, dev), T(d.rotations[0] if single else d.rotations, dev),
+            T(d.translations[0] if single else d.translations, dev), None,
+            T(d.weights[0] if single else d.weights, dev), None)
+    g = grid_to_dev(d.ds_dout[..., 0] if single else d.ds_dout, dev)
+    kw = {}
+    if keep:
+        ws = torch.empty(max(dpr_amd.workspace_bytes(op, d.grid, n_points, batch, n_in, tdt, algo, sharing=True)
+                             for op in ("raster", "pullback")), dtype=torch.uint8, device=dev)
+        out = dpr_amd.empty_grid(d.grid, None if single else batch, tdt, dev)
+        dpr_amd.raster_(out, *args, algo=algo, workspace=ws, keep_binning=True)
+        kw = dict(workspace=ws, reuse_binning=True)
+    pb = dpr_amd.raster_pullback_(g, *args, algo=algo, point_weight_grad=False, **kw)
+    assert pb.point_weight is None
+    ref = oracle.raster_pullback(d.ds_dout, d.points, d.rotations, d.translations, d.weights, None, dtype=npdt)
+    sq = (lambda a: a[0]) if single else (lambda a: a)
+    assert_close(pb.points, ref.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.rotation, sq(ref.rotation), tol(npdt, "pose"), "ds_drotation")
+    assert_close(pb.translation, sq(ref.translation), tol(npdt, "pose"), "ds_dtranslation")
+    assert_close(pb.background, sq(ref.background), tol(npdt, "pose"), "ds_dbackground")
+    assert_close(pb.out_weight, sq(ref.out_weight), tol(npdt, "pose"), "ds_dout_weight")
+    with pytest.raises(ValueError):
+        dpr_amd.raster_pullback_(g, *args, algo=algo, point_weight_grad=False,
+                                 ds_dpoint_weight=torch.empty(n_points, dtype=tdt, device=dev))
+
+
 @pytest.mark.parametrize("algo", ["auto", "atomic"])
 @pytest.mark.parametrize("npdt,tdt", DTYPES)
 @pytest.mark.parametrize("n_in,n_out", [(1, 1), (2, 1), (3, 1)])
@@ -965,8 +1006,8 @@ def test_runs_on_the_callers_stream_and_in_hip_graphs(oracle, dev, algo):
     R, t = T(d.rotations, dev), T(d.translations, dev)
     g = grid_to_dev(d.ds_dout, dev)
     out = dpr_amd.empty_grid(d.grid, 1, torch.float32, dev)
-    ws = torch.empty(max(16, dpr_amd.workspace_bytes("pullback", d.grid, d.n_points, 1, 3,
-                                                     torch.float32, algo)),
+    ws = torch.empty(max(16, *(dpr_amd.workspace_bytes(op, d.grid, d.n_points, 1, 3, torch.float32, algo)
+                               for op in ("raster", "pullback"))),  # one buffer for both calls
                      dtype=torch.uint8, device=dev)
     d_pts = torch.empty(d.n_points, 3, device=dev)
     d_pw = torch.empty(d.n_points, device=dev)

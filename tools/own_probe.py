@@ -47,7 +47,10 @@ Rt = torch.as_tensor(R[0] if single else R, device=dev).to(tdt)
 tt = torch.as_tensor(t[0] if single else t, device=dev).to(tdt)
 res = {}
 outs = {}
-for algo, kw in (("chunked", {}), ("tiled", dict(coherent_points=True))):
+ap_algos = [("chunked", {}), ("tiled", dict(coherent_points=True))]
+if os.environ.get("PROBE_ATOMIC"):
+    ap_algos.append(("atomic", {}))
+for algo, kw in ap_algos:
     ws = torch.empty(max(16, dpr_amd.workspace_bytes("pullback", grid, a.P, a.poses, 3, tdt, algo, **kw),
                          dpr_amd.workspace_bytes("raster", grid, a.P, a.poses, 3, tdt, algo, **kw)),
                      dtype=torch.uint8, device=dev)
@@ -63,6 +66,19 @@ for algo, kw in (("chunked", {}), ("tiled", dict(coherent_points=True))):
                         "sum_item_us": c[10] * 0.01, "max_item_us": c[11] * 0.01,
                         "visits_per_point": c[4] / a.P, "touch_per_point": c[5] / a.P,
                         "lane_util": c[7] / max(1, 64 * c[6]), "buckets": [int(x) for x in c[16:32]]}
+        # per-item records at the end of the slab area (= end of the raster workspace layout)
+        need = dpr_amd.workspace_bytes("raster", grid, a.P, a.poses, 3, tdt, algo)
+        nit = int(sum(c[16:32]))
+        rec = ws[need - 32 * nit: need].cpu().numpy().view(np.uint32).reshape(-1, 8)[::-1].astype(np.int64)
+        dt, vis, t0 = rec[:, 0] * 0.01, rec[:, 1], rec[:, 4]
+        t0 = (t0 - t0.min()) * 0.01
+        order = np.argsort(-dt)
+        res["items"] = {"n": nit, "sum_us": float(dt.sum()), "max_us": float(dt.max()),
+                        "span_us": float((t0 + dt).max()),
+                        "top": [[float(dt[i]), int(vis[i]), int(rec[i, 2]), int(rec[i, 3] & 0xffff), int(rec[i, 3] >> 16), int(rec[i, 5]), float(t0[i])] for i in order[:12]],
+                        "us_per_kvisit_median": float(np.median(dt[vis > 2000] / (vis[vis > 2000] / 1000.0))),
+                        "start_hist_us": np.histogram(t0, bins=10)[0].tolist(),
+                        "end_hist_us": np.histogram(t0 + dt, bins=10)[0].tolist()}
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
     for e0, e1 in evs:
         e0.record(); f(); e1.record()
