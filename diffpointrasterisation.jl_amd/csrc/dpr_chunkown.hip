@@ -960,7 +960,7 @@ size_t sort_workspace_bytes(int64_t P);
 template <typename T>
 int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
                      uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes,
-                     uint32_t* inv_perm);
+                     uint32_t* inv_perm, bool fine);
 
 // One layout for both operations (like DPR_ALGO_TILED): a workspace sized for `raster` also
 // serves the pullback of the same problem.
@@ -1046,7 +1046,7 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
         if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts, (uint32_t*)(ws + pl.off_perm),
-                                         pw, spw, ws + pl.off_sort, sort_workspace_bytes(P), nullptr))
+                                         pw, spw, ws + pl.off_sort, sort_workspace_bytes(P), nullptr, false))
             return rc;
         pts = spts;
         pws = spw;
@@ -1140,7 +1140,7 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
         if (!reuse)
             if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts,
                                              (uint32_t*)(ws + pl.off_perm), pw, spw,
-                                             ws + pl.off_sort, sort_workspace_bytes(P), nullptr))
+                                             ws + pl.off_sort, sort_workspace_bytes(P), nullptr, false))
                 return rc;
         pts = spts;
         pws = spw;

@@ -1,34 +1,41 @@
-// DPR_ALGO_CHUNKED on 3-D grids: owner-computes voxel tiles over a bounding-box hierarchy of
-// the cloud.  No per-point record is ever written: the points are read in place.
+// DPR_ALGO_CHUNKED on 3-D grids: owner-computes voxel tiles over a box hierarchy of the cloud
+// (forward) and a thread-per-point gather in cloud order (pullback).  No per-point record is ever
+// written: both read the points in place.
 //
 // For a spatially coherent cloud (dpr_sort_points_*: Hilbert order) 16 consecutive points are a
-// blob of a few voxels.  The cloud gets a two-level bounding-box hierarchy in the MODEL frame
-// (pose independent):
+// blob of a few voxels.  One streaming pass per call gives the cloud a three-level hierarchy of
+// boxes IN THE GRID FRAME of each pose -- the exact range of cells a group of points contributes
+// to, as 16-bit integers:
 //
-//   level 0   sub-chunk  = 16 consecutive points   {lo[3], hi[3]}            24 B
-//   level 1   chunk      = 64 sub-chunks = 1024 pt {lo[3], hi[3], max|pw|}   32 B
+//   level 0   sub-chunk = 16 consecutive points      {lo[3], hi[3]}  12 B
+//   level 1   chunk     = 64 sub-chunks = 1024 pts   same (+ max |point_weight|, pose independent)
+//   level 2   64 chunks = 65536 points               same
 //
-//   level 2   64 chunks  = 65536 points          {lo[3], hi[3], max|pw|}   32 B
+// (Model-frame boxes, rotated into the grid as centre +- sum_j |R_dj| h_j, would be pose independent
+// and could be kept across calls -- measured: a tile then looks at 1.98 points per point of the
+// cloud against 1.09 it needs, the rotation inflates every box by up to sqrt(3); the pass over the
+// points that builds the boxes costs the same either way and transforms the points for free in
+// the shadow of its loads.)  A voxel tile of 32 x 32 x 14 cells (with a one-cell pad 148 KB of
+// 64-bit LDS accumulators: one workgroup of 1024 threads per CU) finds the points it needs by
+// integer interval tests:
 //
-// and a voxel tile of 32 x 32 x 14 cells (with a one-cell pad 148 KB of 64-bit LDS accumulators:
-// one workgroup of 1024 threads per CU) finds the points it needs by testing boxes, rotated into
-// the grid frame as centre +- sum_j |R_dj| h_j, against its own coordinate range:
-//
-//   boxes    k_own_boxes    one streaming pass over the points (the only kernel that reads all of
-//                           them): level-0 and level-1 boxes; k_own_boxes2: level 2 from level 1
-//   plan     k_own_plan     block per (tile, pose): tests the level-1 boxes, writes the tile's
-//                           candidate list, estimates its load from the box overlaps, splits heavy
-//                           tiles into parts (every n-th candidate) and files the work items in
-//                           buckets by size (heaviest first)
+//   boxes    k_own_boxes    one streaming pass over the points (the only forward kernel that reads
+//                           all of them): level 0 and 1 for every pose of the group;
+//            k_own_boxes2   level 2 from level 1
+//   plan     k_own_plan     block per (tile, pose): walks the hierarchy top down, writes the tile's
+//                           candidate chunks, estimates its load from the box overlaps, splits
+//                           heavy tiles into parts (every n-th candidate) and files the work items
+//                           in buckets by size (heaviest first)
 //   forward  k_own_splat    block per work item.  A WAVE takes a candidate chunk, tests its 64
 //                           level-0 boxes (one per lane), queues the hits; whenever 64 sub-chunks
 //                           are queued every lane walks ONE of them (16 points, 4 per 48-byte
 //                           load) -- lanes are >= 16 points apart in the cloud, so LDS atomics of
 //                           one instruction rarely share an address.  Only contributions to cells
-//                           the tile OWNS are kept (a point near a tile face is visited by both
-//                           tiles): no halo exchange, no global atomics; out = background + tile
-//                           with plain stores.  fp32 data: exact 64-bit fixed-point sums
-//                           (dpr_device.h FixScale), fp64 / non-finite weights: f64 atomics.
+//                           the tile OWNS count (a point near a tile face is visited by both
+//                           tiles; the pad cells take the rest and are dropped): no halo exchange,
+//                           no global atomics; out = background + tile with plain stores.  fp32
+//                           data: exact 64-bit fixed-point sums (dpr_device.h FixScale), fp64 /
+//                           non-finite weights: f64 atomics.
 //            k_own_combine  split tiles only: the parts left their raw 64-bit tiles in slabs,
 //                           summed here (integer sums: exact, whatever the split)
 //   pullback k_own_pullback a thread per point in cloud order, gathers straight from ds_dout (the
@@ -37,8 +44,8 @@
 //            k_own_reduce   per-block partial sums (f64) -> ds_drotation, ds_dtranslation, ...
 //
 // Correct for ANY point order: a box that covers half the grid is listed by every tile it
-// overlaps (slow, never wrong); candidate lists that outgrow their buffer make the tile scan all
-// chunks itself.  Reference semantics: /root/reference/src/raster.jl:36-66 (forward kernel),
+// overlaps (slow, never wrong); candidate lists that outgrow their buffer make the tile take every
+// chunk as a candidate.  Reference semantics: /root/reference/src/raster.jl:36-66 (forward kernel),
 // src/raster_pullback.jl:39-72 (per-point pullback), :85-148 (batch).
 #include <hip/hip_runtime.h>
 
@@ -56,6 +63,7 @@ namespace dpr {
 constexpr int kSC = 16;              // points per sub-chunk (level-0 box, one lane's share)
 constexpr int kFan = 64;             // sub-chunks per chunk (level-1 box, one wave's box tests)
 constexpr int kL1 = kSC * kFan;      // 1024 points
+constexpr int kL2 = 64;              // chunks per level-2 box (65536 points)
 constexpr int kOT = 1024;            // threads of the tile kernels
 constexpr int kOW = kOT / kWave;     // 16 waves
 constexpr int kTX = 32, kTY = 32, kTZ = 14;
@@ -65,9 +73,6 @@ constexpr int kCells = kTX * kTY * kTZ;                     // 14336 owned cells
 // cells are never flushed (the neighbouring tile computes them itself)
 constexpr int kPX = kTX + 2, kPY = kTY + 2, kPZ = kTZ + 2;
 constexpr int kPCells = kPX * kPY * kPZ;                    // 18496
-// pullback: the ds_dout tile is staged with the same pad (the upper one is the halo a point's upper
-// neighbours need; the lower one is only read by points below the grid's first cell, as zeros)
-constexpr int kL2 = 64;              // chunks per level-2 box (65536 points)
 constexpr int kBuckets = 16;
 constexpr int kMaxParts = 32;
 constexpr int kOwnBw = 16;           // poses planned at once (one copy of the per-pose arrays each)
@@ -75,18 +80,23 @@ constexpr int kQueue = 128;          // queued sub-chunks per wave (64 + up to 6
 constexpr int kCtlWords = 32;        // per pose: [0] list cursor, [1] slab cursor (pose 0's), [2] split
                                      // tiles, [3] list overflow seen, [16..31] bucket counts
 constexpr int kMaxOwnTiles = 1 << 20;
+constexpr int kPlanHits = 1024;      // level-2 boxes a plan block can descend into (more: scan-all tile)
 
-struct alignas(8) Box0 {
-    float lo[3], hi[3];
-};
-struct alignas(16) Box1 {
-    float lo[3], hi[3], maxw, pad;
+// cells [lo, hi] (per axis, existing cells only) a group of points contributes to under one pose;
+// lo > hi: none (no point of the group has a cell in the grid)
+struct alignas(4) IBox {
+    int16_t lo[3], hi[3];
 };
 struct alignas(16) TileRec {
-    uint32_t begin;   // first entry of the candidate list, 0xffffffff: overflow (scan all chunks)
+    uint32_t begin;   // first entry of the candidate list, 0xffffffff: overflow (every chunk)
     uint32_t count;   // candidate chunks
     int sexp;         // fixed-point exponent of the tile (all parts share it), kFixNone: f64 sums
     uint32_t parts;   // nparts | first_slab << 8
+};
+struct alignas(16) OwnItem {
+    uint32_t tile, part_nparts, begin, count;
+    int sexp;
+    uint32_t first_slab, pad0, pad1;
 };
 struct OGeom {
     int nt[3];
@@ -105,61 +115,6 @@ static bool make_ogeom(const int64_t* grid, OGeom* tg) {
     return true;
 }
 
-// ---------------------------------------------------------------- box tests
-// Range of grid coordinates (src/raster.jl:88-92: coord = (R p + t + 1) * n / 2) the points of a
-// model-frame box can take, inflated by a bound on the rounding of this estimate AND of the
-// kernels' own coordinate arithmetic (8 ulp of the magnitudes involved + 1e-3 voxel): whatever
-// cell the splat / gather arithmetic picks for a point of the box lies inside.  NaN-safe: a box
-// with non-finite bounds yields NaN and is never "provably outside".  Computed in fp32 from the
-// pose the kernels use (fp64 poses are rounded: the slack covers that too); |x| is an operand
-// modifier, so the absolute values cost neither registers nor instructions.
-template <typename T>
-__device__ __forceinline__ void box_span(const float (&lo)[3], const float (&hi)[3], const Pose<T, 3, 3>& ps,
-                                         const GridDesc<3>& gd, float (&cmin)[3], float (&cmax)[3]) {
-    float c[3], h[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        c[j] = 0.5f * (lo[j] + hi[j]);
-        h[j] = 0.5f * (hi[j] - lo[j]);
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float r0 = (float)ps.R[d], r1 = (float)ps.R[d + 3], r2 = (float)ps.R[d + 6], t = (float)ps.t[d];
-        const float sc = 0.5f * (float)gd.n[d];
-        const float cc = r0 * c[0] + r1 * c[1] + r2 * c[2] + (t + 1.f);
-        const float hh = fabsf(r0) * h[0] + fabsf(r1) * h[1] + fabsf(r2) * h[2];
-        const float mg = fabsf(r0 * c[0]) + fabsf(r1 * c[1]) + fabsf(r2 * c[2]) + (fabsf(t) + 1.f);
-        const float e = (mg + hh) * (sc * 4.8e-7f) + 1e-3f;
-        cmin[d] = (cc - hh) * sc - e;
-        cmax[d] = (cc + hh) * sc + e;
-    }
-}
-
-// Coordinate range a tile needs: a point contributes to cells of the tile iff its lower neighbour
-// ref0 = ceil(coord - 1/2) - 1 lies in [x0 - 1, x0 + T - 1], i.e. coord in (x0 - 1/2, x0 + T + 1/2].
-// The tiles of a border layer extend to infinity outwards: points outside the grid (rejected by the
-// range test of the arithmetic) are then visited by a border tile, which owns them in the pullback
-// (their gradients are zeros that somebody has to store).
-struct TileRange {
-    float lo[3], hi[3];
-};
-__device__ __forceinline__ TileRange tile_range(const int (&tc)[3], const OGeom& tg) {
-    const int T[3] = {kTX, kTY, kTZ};
-    TileRange r;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        r.lo[d] = tc[d] == 0 ? -__builtin_inff() : (float)(tc[d] * T[d]) - 0.5f;
-        r.hi[d] = tc[d] == tg.nt[d] - 1 ? __builtin_inff() : (float)(tc[d] * T[d] + T[d]) + 0.5f;
-    }
-    return r;
-}
-__device__ __forceinline__ bool span_hits(const float (&cmin)[3], const float (&cmax)[3], const TileRange& r) {
-    bool miss = false;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) miss = miss || (cmax[d] < r.lo[d]) || (cmin[d] > r.hi[d]);
-    return !miss;
-}
-
 __device__ __forceinline__ void tile_coords(int tile, const OGeom& tg, int (&tc)[3], int (&x0)[3]) {
     const int T[3] = {kTX, kTY, kTZ};
 #pragma unroll
@@ -168,6 +123,12 @@ __device__ __forceinline__ void tile_coords(int tile, const OGeom& tg, int (&tc)
         tile /= tg.nt[d];
         x0[d] = tc[d] * T[d];
     }
+}
+
+// does a box reach cells of the tile at x0?
+__device__ __forceinline__ bool box_hits(const IBox& b, const int (&x0)[3]) {
+    return b.lo[0] <= x0[0] + kTX - 1 && b.hi[0] >= x0[0] && b.lo[1] <= x0[1] + kTY - 1 && b.hi[1] >= x0[1] &&
+           b.lo[2] <= x0[2] + kTZ - 1 && b.hi[2] >= x0[2];
 }
 
 // A wave-uniform floating-point value the compiler computed with vector instructions (this chip has
@@ -198,11 +159,25 @@ __device__ __forceinline__ OwnXform<T> own_xform(const Pose<T, 3, 3>& ps, const 
     }
     return xf;
 }
-
-__device__ __forceinline__ float f_down(float x) { return x; }
-__device__ __forceinline__ float f_up(float x) { return x; }
-__device__ __forceinline__ float f_down(double x) { return __double2float_rd(x); }
-__device__ __forceinline__ float f_up(double x) { return __double2float_ru(x); }
+// lower neighbour of a point (0-based, may be -1) and its deltas; false: no cell in the grid
+template <typename T>
+__device__ __forceinline__ bool own_ref(const T (&pt)[3], const Pose<T, 3, 3>& ps, const OwnXform<T>& xf,
+                                        int (&ref0)[3], T (&dlo)[3]) {
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        T proj = ps.R[d] * pt[0];
+        proj = proj + ps.R[d + 3] * pt[1];
+        proj = proj + ps.R[d + 6] * pt[2];
+        const T coord = (proj - xf.origin[d]) * xf.scale[d];
+        const T c = coord - T(0.5);
+        ok = ok && (c > T(-1)) && (c <= xf.nf[d]);
+        const T r = ceil_t<T>(c);
+        ref0[d] = (int)r - 1;  // (meaningless unless ok: the conversion saturates)
+        dlo[d] = coord - (r - T(0.5));
+    }
+    return ok;
+}
 
 // 16 bytes at a time where the caller's buffer allows it (`vec`: wave-uniform)
 template <typename T, int N> __device__ __forceinline__ void load_run(const T* __restrict__ src, bool vec, T (&v)[N]) {
@@ -224,24 +199,32 @@ template <typename T, int N> __device__ __forceinline__ void load_run(const T* _
 
 // ---------------------------------------------------------------- boxes
 // One block per chunk of 1024 points; thread t owns points 4t .. 4t + 3 of it, four threads a
-// sub-chunk.  Also clears the control words of the plan (first block).
+// sub-chunk.  The points stay in registers while the poses of the group are walked.  Also clears
+// the control words of the plan (first block).
+struct OwnBoxArgs {
+    IBox *b0, *b1;      // [pose copy][nSC], [pose copy][nL1]
+    float* mw1;         // [nL1] max |point_weight| per chunk (inf: a NaN weight)
+    int64_t nSC, nL1;
+    uint32_t* ctl;
+    int ctl_words;
+};
 template <typename T>
-__global__ __launch_bounds__(256) void k_own_boxes(int64_t P, const T* __restrict__ points,
+__global__ __launch_bounds__(256) void k_own_boxes(GridDesc<3> gd, int64_t P, const T* __restrict__ points,
                                                    const T* __restrict__ pw, int vec_ok,
-                                                   Box0* __restrict__ b0, Box1* __restrict__ b1,
-                                                   uint32_t* __restrict__ ctl, int ctl_words) {
-    __shared__ float red[4][8];
+                                                   const T* __restrict__ rot, const T* __restrict__ trans,
+                                                   int64_t bfirst, int nb, OwnBoxArgs ba) {
+    __shared__ int red[4][6];
+    __shared__ float redw[4];
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < ctl_words; i += 256) ctl[i] = 0u;
+        for (int i = threadIdx.x; i < ba.ctl_words; i += 256) ba.ctl[i] = 0u;
     const int64_t c = blockIdx.x;
     const int64_t p0 = c * kL1 + (int64_t)threadIdx.x * 4;
-    const float inf = __builtin_inff();
-    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, mw = 0.f;
-    bool bad = false;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    T v[12];
+    int npts = 0;
     if (p0 < P) {
-        T v[12];
-        const bool full = p0 + 4 <= P;
-        if (full) {
+        npts = p0 + 4 <= P ? 4 : (int)(P - p0);
+        if (npts == 4) {
             load_run<T, 12>(points + p0 * 3, vec_ok != 0, v);
         } else {
 #pragma unroll
@@ -250,124 +233,137 @@ __global__ __launch_bounds__(256) void k_own_boxes(int64_t P, const T* __restric
                 v[k] = points[(p < P ? p : P - 1) * 3 + k % 3];
             }
         }
+    }
+    if (pw) {  // (pose independent)
+        float mw = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const T x = v[q * 3 + j];
-                bad = bad || !(fabs((double)x) < (double)inf);
-                lo[j] = fminf(lo[j], f_down(x));
-                hi[j] = fmaxf(hi[j], f_up(x));
+            if (q < npts) {
+                const T w = pw[p0 + q];
+                mw = fmaxf(mw, (w == w) ? fabsf((float)w) : __builtin_inff());  // NaN weights: f64 sums (IEEE)
             }
         }
-        if (pw) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t p = p0 + q;
-                const T w = pw[p < P ? p : P - 1];
-                const float a = (w == w) ? fabsf((float)w) : inf;  // NaN weights: f64 sums (IEEE)
-                mw = fmaxf(mw, a);
+        for (int o = 1; o < kWave; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
+        if (lane == 0) redw[wave] = mw;
+        __syncthreads();
+        if (threadIdx.x == 0) ba.mw1[c] = fmaxf(fmaxf(redw[0], redw[1]), fmaxf(redw[2], redw[3]));
+    }
+#pragma unroll 1
+    for (int bl = 0; bl < nb; ++bl) {
+        const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, nullptr, bfirst + bl);
+        const OwnXform<T> xf = own_xform<T>(ps, gd);
+        int lo[3] = {32767, 32767, 32767}, hi[3] = {-32768, -32768, -32768};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T pt[3] = {v[q * 3], v[q * 3 + 1], v[q * 3 + 2]};
+            int ref0[3];
+            T dlo[3];
+            if (own_ref<T>(pt, ps, xf, ref0, dlo) && q < npts) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int a = ref0[d] < 0 ? 0 : ref0[d];
+                    const int e = ref0[d] + 1 < gd.n[d] ? ref0[d] + 1 : gd.n[d] - 1;
+                    lo[d] = a < lo[d] ? a : lo[d];
+                    hi[d] = e > hi[d] ? e : hi[d];
+                }
             }
         }
-    }
-    // sub-chunk = 4 neighbouring lanes
-    int badi = bad ? 1 : 0;
+        // sub-chunk = 4 neighbouring lanes
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
+        for (int o = 1; o <= 2; o <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, kWave));
-            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], o, kWave));
+            for (int d = 0; d < 3; ++d) {
+                const int a = __shfl_xor(lo[d], o, kWave), e = __shfl_xor(hi[d], o, kWave);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = e > hi[d] ? e : hi[d];
+            }
         }
-        badi |= __shfl_xor(badi, o, kWave);
-    }
-    if (badi) {  // a NaN / Inf coordinate: the box is everything (every tile looks at these points)
+        if ((threadIdx.x & 3) == 0 && p0 < P) {
+            IBox b;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            lo[j] = -inf;
-            hi[j] = inf;
+            for (int d = 0; d < 3; ++d) {
+                b.lo[d] = (int16_t)lo[d];
+                b.hi[d] = (int16_t)hi[d];
+            }
+            ba.b0[(size_t)bl * ba.nSC + c * kFan + threadIdx.x / 4] = b;
         }
-    }
-    if ((threadIdx.x & 3) == 0 && p0 < P) {
-        Box0 b;
+        // chunk = the block
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            b.lo[j] = lo[j];
-            b.hi[j] = hi[j];
+        for (int o = 4; o < kWave; o <<= 1) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int a = __shfl_xor(lo[d], o, kWave), e = __shfl_xor(hi[d], o, kWave);
+                lo[d] = a < lo[d] ? a : lo[d];
+                hi[d] = e > hi[d] ? e : hi[d];
+            }
         }
-        b0[c * kFan + threadIdx.x / 4] = b;
-    }
-    // chunk = the block
+        __syncthreads();  // (red of the previous pose has been read)
+        if (lane == 0) {
 #pragma unroll
-    for (int o = 4; o < kWave; o <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, kWave));
-            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], o, kWave));
+            for (int d = 0; d < 3; ++d) {
+                red[wave][d] = lo[d];
+                red[wave][3 + d] = hi[d];
+            }
         }
-    }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            IBox b;
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) {
+            for (int d = 0; d < 3; ++d) {
+                int a = red[0][d], e = red[0][3 + d];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            red[wave][j] = lo[j];
-            red[wave][3 + j] = hi[j];
+                for (int w = 1; w < 4; ++w) {
+                    a = red[w][d] < a ? red[w][d] : a;
+                    e = red[w][3 + d] > e ? red[w][3 + d] : e;
+                }
+                b.lo[d] = (int16_t)a;
+                b.hi[d] = (int16_t)e;
+            }
+            ba.b1[(size_t)bl * ba.nL1 + c] = b;
         }
-        red[wave][6] = mw;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Box1 b;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            b.lo[j] = fminf(fminf(red[0][j], red[1][j]), fminf(red[2][j], red[3][j]));
-            b.hi[j] = fmaxf(fmaxf(red[0][3 + j], red[1][3 + j]), fmaxf(red[2][3 + j], red[3][3 + j]));
-        }
-        b.maxw = fmaxf(fmaxf(red[0][6], red[1][6]), fmaxf(red[2][6], red[3][6]));
-        b.pad = 0.f;
-        b1[c] = b;
     }
 }
 
-// level-2 boxes: one wave per 64 chunks
-__global__ __launch_bounds__(256) void k_own_boxes2(int64_t nL1, const Box1* __restrict__ b1,
-                                                    Box1* __restrict__ b2) {
+// level-2 boxes: one wave per (64 chunks, pose)
+__global__ __launch_bounds__(256) void k_own_boxes2(int64_t nL1, int64_t nL2, const IBox* __restrict__ b1,
+                                                    const float* __restrict__ mw1, IBox* __restrict__ b2,
+                                                    float* __restrict__ mw2) {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t c2 = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
+    const int bl = blockIdx.y;
+    if (c2 >= nL2) return;  // (uniform)
     const int64_t c = c2 * kL2 + lane;
-    if (c2 * kL2 >= nL1) return;  // (uniform)
-    const float inf = __builtin_inff();
-    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, mw = 0.f;
+    int lo[3] = {32767, 32767, 32767}, hi[3] = {-32768, -32768, -32768};
+    float mw = 0.f;
     if (c < nL1) {
-        const Box1 b = b1[c];
+        const IBox b = b1[(size_t)bl * nL1 + c];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            lo[j] = b.lo[j];
-            hi[j] = b.hi[j];
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = b.lo[d];
+            hi[d] = b.hi[d];
         }
-        mw = b.maxw;
+        if (mw1) mw = mw1[c];
     }
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            lo[j] = fminf(lo[j], __shfl_xor(lo[j], o, kWave));
-            hi[j] = fmaxf(hi[j], __shfl_xor(hi[j], o, kWave));
+        for (int d = 0; d < 3; ++d) {
+            const int a = __shfl_xor(lo[d], o, kWave), e = __shfl_xor(hi[d], o, kWave);
+            lo[d] = a < lo[d] ? a : lo[d];
+            hi[d] = e > hi[d] ? e : hi[d];
         }
         mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
     }
     if (lane == 0) {
-        Box1 b;
+        IBox b;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            b.lo[j] = lo[j];
-            b.hi[j] = hi[j];
+        for (int d = 0; d < 3; ++d) {
+            b.lo[d] = (int16_t)lo[d];
+            b.hi[d] = (int16_t)hi[d];
         }
-        b.maxw = mw;
-        b.pad = 0.f;
-        b2[c2] = b;
+        b2[(size_t)bl * nL2 + c2] = b;
+        if (mw1 && bl == 0) mw2[c2] = mw;
     }
 }
 
@@ -376,6 +372,9 @@ struct OwnPlanArgs {
     char* ws;
     size_t off_ctl, off_rec, off_list, off_items, off_split;
     size_t rec_stride, list_stride, items_stride, split_stride;  // per pose copy (bytes)
+    const IBox *b1, *b2;  // [pose copy][nL1], [pose copy][nL2]
+    const float* mw1;     // [nL1] or nullptr (no point weights)
+    int64_t nL1, nL2;
     uint32_t list_cap;   // entries per pose
     int max_items;       // per bucket
     int max_slabs;       // per pose group
@@ -384,111 +383,132 @@ struct OwnPlanArgs {
     int fixed;           // fixed-point forward wanted
 };
 
-// block per (tile, pose copy): walks the box hierarchy top down.  Wave w of the block takes the
-// w-th quarter of the level-2 boxes, so the candidate list comes out in ascending chunk order
-// whatever the timing (two passes: count, then write at the reserved offset).
+// block per (tile, pose copy): level-2 boxes that reach the tile are collected first (wave w scans
+// the w-th quarter: a deterministic order), then the waves test the 64 chunks under each of them
+// (independent loads, two in flight per wave) and keep the hit masks in LDS; the candidate list is
+// written from the masks at the offset the block reserved.
 template <typename T>
-__global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int64_t P, int64_t B,
-                                                  int64_t nL1, int64_t nL2, const Box1* __restrict__ b1,
-                                                  const Box1* __restrict__ b2,
-                                                  const T* __restrict__ rot, const T* __restrict__ trans,
-                                                  const T* __restrict__ ow, const T* points,
-                                                  const T* pw, int64_t bfirst, OwnPlanArgs pa) {
-    __shared__ uint32_t s_cnt[4], s_base[4], s_begin;
+__global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int64_t P, const T* __restrict__ ow,
+                                                  int has_pw, int64_t bfirst, OwnPlanArgs pa) {
+    __shared__ uint32_t s_hit[kPlanHits];
+    __shared__ unsigned long long s_mask[kPlanHits];
+    __shared__ uint32_t s_off[kPlanHits];
+    __shared__ uint32_t s_cnt2[4], s_begin;
     __shared__ float s_est[4], s_mw[4];
     const int tile = blockIdx.x, bl = blockIdx.y;
     const int64_t b = bfirst + bl;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     int tc[3], x0[3];
     tile_coords(tile, tg, tc, x0);
-    const TileRange tr = tile_range(tc, tg);
-    const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, nullptr, b);
-    const int64_t per = ((nL2 + 3) / 4 + kWave - 1) / kWave * kWave;
-    const int64_t i0 = wave * per, i1 = (i0 + per < nL2) ? i0 + per : nL2;
+    const IBox* b1 = pa.b1 + (size_t)bl * pa.nL1;
+    const IBox* b2 = pa.b2 + (size_t)bl * pa.nL2;
     uint32_t* ctl = (uint32_t*)(pa.ws + pa.off_ctl) + (size_t)bl * kCtlWords;
     uint32_t* ctl0 = (uint32_t*)(pa.ws + pa.off_ctl);
-    // calls f(chunk, hit, box) for the 64 chunks under every level-2 box that meets the tile
-    auto descend = [&](auto f) {
-        for (int64_t i = i0; i < i1; i += kWave) {  // (uniform)
-            bool hit2 = false;
-            if (i + lane < i1) {
-                const Box1 bx = b2[i + lane];
-                float cmin[3], cmax[3];
-                box_span<T>(bx.lo, bx.hi, ps, gd, cmin, cmax);
-                hit2 = span_hits(cmin, cmax, tr);
-            }
-            unsigned long long m = __ballot(hit2);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int64_t c = (i + l) * kL2 + lane;
-                bool hit = false;
-                Box1 bx;
-                float cmin[3], cmax[3];
-                if (c < nL1) {
-                    bx = b1[c];
-                    box_span<T>(bx.lo, bx.hi, ps, gd, cmin, cmax);
-                    hit = span_hits(cmin, cmax, tr);
-                }
-                f(c, hit, bx, cmin, cmax);
-            }
-        }
+    // 1. level 2: wave w takes the w-th quarter, hits into its own segment of s_hit
+    const int64_t per = ((pa.nL2 + 3) / 4 + kWave - 1) / kWave * kWave;
+    const int64_t i0 = wave * per, i1 = (i0 + per < pa.nL2) ? i0 + per : pa.nL2;
+    uint32_t n2 = 0;
+    bool too_many = false;
+    for (int64_t i = i0; i < i1; i += kWave) {  // (uniform)
+        bool hit = false;
+        if (i + lane < i1) hit = box_hits(b2[i + lane], x0);
+        const unsigned long long m = __ballot(hit);
+        const uint32_t pos = n2 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (hit && pos < kPlanHits / 4) s_hit[wave * (kPlanHits / 4) + pos] = (uint32_t)(i + lane);
+        n2 += (uint32_t)__popcll(m);
+    }
+    if (n2 > kPlanHits / 4) {
+        too_many = true;
+        n2 = kPlanHits / 4;
+    }
+    if (lane == 0) s_cnt2[wave] = n2 | (too_many ? 0x80000000u : 0u);
+    __syncthreads();
+    const uint32_t c0 = s_cnt2[0] & 0x7fffffffu, c1 = s_cnt2[1] & 0x7fffffffu, c2n = s_cnt2[2] & 0x7fffffffu,
+                   c3 = s_cnt2[3] & 0x7fffffffu;
+    const bool scan_all = ((s_cnt2[0] | s_cnt2[1] | s_cnt2[2] | s_cnt2[3]) & 0x80000000u) != 0;
+    const uint32_t H = c0 + c1 + c2n + c3;
+    auto hit_id = [&](uint32_t h) -> uint32_t {  // h-th level-2 hit, waves' segments concatenated
+        if (h < c0) return s_hit[h];
+        h -= c0;
+        if (h < c1) return s_hit[kPlanHits / 4 + h];
+        h -= c1;
+        if (h < c2n) return s_hit[2 * (kPlanHits / 4) + h];
+        return s_hit[3 * (kPlanHits / 4) + (h - c2n)];
     };
-    // pass 1: count, load estimate, largest weight
-    uint32_t cnt = 0;
+    // 2. level 1 under every hit: masks, load estimate, largest weight
     float est = 0.f, mw = 0.f;
-    descend([&](int64_t c, bool hit, const Box1& bx, const float (&cmin)[3], const float (&cmax)[3]) {
-        if (hit) {
-            float f = 1.f;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float w = cmax[d] - cmin[d];
-                const float ov = fminf(cmax[d], tr.hi[d]) - fmaxf(cmin[d], tr.lo[d]);
-                float fr = ov / w;
-                fr = (fr >= 0.f && fr <= 1.f) ? fr : 1.f;  // NaN / Inf widths: the whole box
-                f *= fr;
-            }
-            const int64_t npts = (c + 1) * kL1 <= P ? kL1 : P - c * kL1;
-            est += f * (float)npts;
-            mw = fmaxf(mw, bx.maxw);
+    for (uint32_t h = wave; h < H; h += 8) {  // two hits per step: their loads overlap
+        const uint32_t ha = h, hb = h + 4;
+        const int64_t ca = (int64_t)hit_id(ha) * kL2 + lane;
+        const int64_t cb = hb < H ? (int64_t)hit_id(hb) * kL2 + lane : -1;
+        IBox xa, xb;
+        if (ca < pa.nL1) xa = b1[ca];
+        if (cb >= 0 && cb < pa.nL1) xb = b1[cb];
+        float wa = 0.f, wb = 0.f;
+        if (pa.mw1) {
+            if (ca < pa.nL1) wa = pa.mw1[ca];
+            if (cb >= 0 && cb < pa.nL1) wb = pa.mw1[cb];
         }
-        cnt += (uint32_t)__popcll(__ballot(hit));
-    });
+        auto one = [&](int64_t c, const IBox& bx, float w, uint32_t hh) {
+            const bool hit = c >= 0 && c < pa.nL1 && box_hits(bx, x0);
+            if (hit) {
+                float f = 1.f;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int Td = d == 0 ? kTX : (d == 1 ? kTY : kTZ);
+                    const int a = bx.lo[d] > x0[d] ? bx.lo[d] : x0[d];
+                    const int e = bx.hi[d] < x0[d] + Td - 1 ? bx.hi[d] : x0[d] + Td - 1;
+                    f *= (float)(e - a + 1) / (float)(bx.hi[d] - bx.lo[d] + 1);
+                }
+                const int64_t npts = (c + 1) * kL1 <= P ? kL1 : P - c * kL1;
+                est += f * (float)npts;
+                mw = fmaxf(mw, w);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) s_mask[hh] = m;
+        };
+        one(ca, xa, wa, ha);
+        if (hb < H) one(cb, xb, wb, hb);  // (uniform)
+    }
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
         est += __shfl_xor(est, o, kWave);
         mw = fmaxf(mw, __shfl_xor(mw, o, kWave));
     }
     if (lane == 0) {
-        s_cnt[wave] = cnt;
         s_est[wave] = est;
         s_mw[wave] = mw;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        uint32_t total = 0;
+        for (uint32_t h = 0; h < H; ++h) {
+            s_off[h] = total;
+            total += (uint32_t)__popcll(s_mask[h]);
+        }
         const float e = s_est[0] + s_est[1] + s_est[2] + s_est[3];
         const float m = fmaxf(fmaxf(s_mw[0], s_mw[1]), fmaxf(s_mw[2], s_mw[3]));
-        s_base[0] = 0;
-        s_base[1] = s_cnt[0];
-        s_base[2] = s_cnt[0] + s_cnt[1];
-        s_base[3] = s_cnt[0] + s_cnt[1] + s_cnt[2];
         uint32_t begin = 0;
-        if (total) {
+        if (scan_all) {
+            begin = 0xffffffffu;  // more level-2 hits than this block holds: the tile takes every chunk
+            total = (uint32_t)pa.nL1;
+            ctl[3] = 1u;
+        } else if (total) {
             begin = atomicAdd(&ctl[0], total);
             if (begin > pa.list_cap || total > pa.list_cap - begin) {
-                begin = 0xffffffffu;  // the list does not fit: the tile kernels scan every chunk
+                begin = 0xffffffffu;  // the list does not fit: the tile kernels take every chunk
+                total = (uint32_t)pa.nL1;
                 ctl[3] = 1u;
             }
         }
         // parts: every n-th candidate each
         uint32_t ev = e < 4.0e9f ? (uint32_t)e : 4000000000u;
+        if (begin == 0xffffffffu) ev = P < 4000000000ll ? (uint32_t)P : 4000000000u;
         uint32_t np = 1;
         if (ev > pa.cap) {
             np = (ev + pa.cap - 1) / pa.cap;
             if (np > (uint32_t)kMaxParts) np = kMaxParts;
-            const uint32_t units = begin == 0xffffffffu ? (uint32_t)nL1 : total;
-            if (np > units) np = units ? units : 1;
+            if (np > total) np = total ? total : 1;
         }
         uint32_t first_slab = 0;
         if (np > 1) {
@@ -505,7 +525,8 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         // fixed-point exponent of the tile: |contribution| <= |out_weight| * max|pw| of the
         // candidates, at most 1024 contributions per candidate to one cell
         const float owv = ow ? fabsf((float)ow[b]) : 1.f;
-        const float maxw = (sizeof(T) == 4) ? owv * (pw ? m : 1.f) : __builtin_inff();
+        float maxw = __builtin_inff();
+        if (sizeof(T) == 4) maxw = owv * (has_pw ? (begin == 0xffffffffu ? __builtin_inff() : m) : 1.f);
         const uint64_t nmax = (uint64_t)(total ? total : 1) * kL1;
         const int sexp = fix_exponent(maxw, nmax < 0x7fffffffu ? (uint32_t)nmax : 0x7fffffffu, pa.fixed);
         TileRec rec;
@@ -519,21 +540,31 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         int bucket = epart < 512 ? 0 : (32 - __clz((int)epart)) - 9;
         if (bucket > kBuckets - 1) bucket = kBuckets - 1;
         const uint32_t slot = atomicAdd(&ctl[16 + bucket], np);
-        uint2* items = (uint2*)(pa.ws + pa.off_items + (size_t)bl * pa.items_stride) + (size_t)bucket * pa.max_items;
-        for (uint32_t k = 0; k < np; ++k)
-            if (slot + k < (uint32_t)pa.max_items) items[slot + k] = make_uint2((uint32_t)tile, k | (np << 16));
+        OwnItem* items = (OwnItem*)(pa.ws + pa.off_items + (size_t)bl * pa.items_stride) + (size_t)bucket * pa.max_items;
+        for (uint32_t k = 0; k < np; ++k) {
+            if (slot + k >= (uint32_t)pa.max_items) break;
+            OwnItem it;
+            it.tile = (uint32_t)tile;
+            it.part_nparts = k | (np << 16);
+            it.begin = begin;
+            it.count = total;
+            it.sexp = sexp;
+            it.first_slab = first_slab;
+            it.pad0 = it.pad1 = 0u;
+            items[slot + k] = it;
+        }
         s_begin = begin;
     }
     __syncthreads();
     const uint32_t begin = s_begin;
     if (begin == 0xffffffffu) return;
-    uint32_t* list = (uint32_t*)(pa.ws + pa.off_list + (size_t)bl * pa.list_stride) + begin + s_base[wave];
-    uint32_t run = 0;
-    descend([&](int64_t c, bool hit, const Box1&, const float (&)[3], const float (&)[3]) {
-        const unsigned long long mask = __ballot(hit);
-        if (hit) list[run + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)c;
-        run += (uint32_t)__popcll(mask);
-    });
+    // 3. the candidate list from the masks
+    uint32_t* list = (uint32_t*)(pa.ws + pa.off_list + (size_t)bl * pa.list_stride) + begin;
+    for (uint32_t h = wave; h < H; h += 4) {
+        const unsigned long long m = s_mask[h];
+        if ((m >> lane) & 1ull)
+            list[s_off[h] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = hit_id(h) * kL2 + (uint32_t)lane;
+    }
 }
 
 // ---------------------------------------------------------------- shared by the tile kernels
@@ -543,14 +574,12 @@ struct OwnTileArgs {
     size_t rec_stride, list_stride, items_stride;
     int max_items;
     int64_t nL1, nSC;
-    const Box0* b0;
-    const Box1* b1;
+    const IBox* b0;    // [pose copy][nSC]
     size_t dbg_words;  // (stats build: 32-bit words of the slab area, per-item records at its end)
 };
 
 // work item of this block: buckets from the heaviest down
-__device__ __forceinline__ bool own_item(const OwnTileArgs& ta, int bl, uint32_t idx, uint32_t& tile,
-                                         uint32_t& part, uint32_t& nparts) {
+__device__ __forceinline__ bool own_item(const OwnTileArgs& ta, int bl, uint32_t idx, OwnItem& it) {
     const uint32_t* ctl = (const uint32_t*)(ta.ws + ta.off_ctl) + (size_t)bl * kCtlWords;
     uint32_t cnt[kBuckets];
 #pragma unroll
@@ -565,10 +594,7 @@ __device__ __forceinline__ bool own_item(const OwnTileArgs& ta, int bl, uint32_t
         }
     }
     if (bucket < 0) return false;
-    const uint2 it = ((const uint2*)(ta.ws + ta.off_items + (size_t)bl * ta.items_stride))[(size_t)bucket * ta.max_items + idx];
-    tile = it.x;
-    part = it.y & 0xffffu;
-    nparts = it.y >> 16;
+    it = ((const OwnItem*)(ta.ws + ta.off_items + (size_t)bl * ta.items_stride))[(size_t)bucket * ta.max_items + idx];
     return true;
 }
 
@@ -587,20 +613,21 @@ struct OwnWalkLds {
 // (< 64 sub-chunks) goes to a pool of the block, which the waves share out again in batches of 64:
 // without it every wave of the ~1000-sub-chunk items of the headline config ended on a half-empty
 // batch (36 % idle lanes).  One block barrier inside, reached exactly once by every wave.
-template <typename T, bool PREFETCH_BOXES, typename Visit>
-__device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const TileRec& rec, int bl, uint32_t part,
-                                         uint32_t nparts, const Pose<T, 3, 3>& ps, const GridDesc<3>& gd,
-                                         const TileRange& tr, OwnWalkLds* wl, Visit visit) {
+template <typename Visit>
+__device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const OwnItem& item, int bl, const int (&x0)[3],
+                                         OwnWalkLds* wl, Visit visit) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     uint32_t* queue = wl->queue[wave];
+    const uint32_t part = item.part_nparts & 0xffffu, nparts = item.part_nparts >> 16;
     // a tile whose candidate list did not fit its buffer (an incoherent cloud) takes EVERY chunk
     // as a candidate: slow, never wrong
-    const bool overflow = rec.begin == 0xffffffffu;
-    const uint32_t* list = (const uint32_t*)(ta.ws + ta.off_list + (size_t)bl * ta.list_stride) + (overflow ? 0u : rec.begin);
-    const uint32_t units = overflow ? (uint32_t)ta.nL1 : rec.count;
+    const bool overflow = item.begin == 0xffffffffu;
+    const uint32_t* list = (const uint32_t*)(ta.ws + ta.off_list + (size_t)bl * ta.list_stride) + (overflow ? 0u : item.begin);
+    const IBox* b0 = ta.b0 + (size_t)bl * ta.nSC;
+    const uint32_t units = item.count;
     uint32_t qn = 0;
     int64_t sc_mine = 0;
-    Box0 bx;
+    IBox bx;
     // next candidate chunk of this wave: its level-0 boxes are requested here, tested later
     auto acquire = [&]() -> bool {
         uint32_t k = 0;
@@ -610,13 +637,11 @@ __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const TileRec& r
         if (u >= units) return false;
         const uint32_t c = overflow ? (uint32_t)u : list[u];
         sc_mine = (int64_t)c * kFan + lane;
-        // (PREFETCH_BOXES: requested now, tested after the batch in between -- six registers a kernel
-        // whose batch needs them all does without)
-        if (PREFETCH_BOXES && sc_mine < ta.nSC) bx = ta.b0[sc_mine];
+        if (sc_mine < ta.nSC) bx = b0[sc_mine];
         return true;
     };
     bool have_c = acquire();
-    int stage = 0;  // 0: candidates, 1: leftovers to the pool, 2: pooled batches
+    int stage = 0;  // 0: candidates, 2: pooled batches
     uint32_t pool_pos = 0, pool_total = 0;
 #ifdef DPR_OWN_STATS
     uint32_t st_batches = 0, st_take = 0, st_tests = 0;
@@ -639,13 +664,7 @@ __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const TileRec& r
         }
         if (stage == 0) {
             if (have_c) {
-                bool hit = false;
-                if (sc_mine < ta.nSC) {
-                    if (!PREFETCH_BOXES) bx = ta.b0[sc_mine];
-                    float cmin[3], cmax[3];
-                    box_span<T>(bx.lo, bx.hi, ps, gd, cmin, cmax);
-                    hit = span_hits(cmin, cmax, tr);
-                }
+                const bool hit = sc_mine < ta.nSC && box_hits(bx, x0);
                 const unsigned long long mask = __ballot(hit);
                 if (hit) queue[qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)sc_mine;
                 qn += (uint32_t)__popcll(mask);
@@ -742,12 +761,12 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
     double* acc = (double*)(smem + sizeof(OwnWalkLds));  // kPCells cells
     const int bl = blockIdx.y;
     const int64_t b = bfirst + bl;
-    uint32_t tile, part, nparts;
-    if (!own_item(ta, bl, blockIdx.x, tile, part, nparts)) return;
+    OwnItem rec;
+    if (!own_item(ta, bl, blockIdx.x, rec)) return;
+    const uint32_t tile = rec.tile, part = rec.part_nparts & 0xffffu, nparts = rec.part_nparts >> 16;
 #ifdef DPR_OWN_STATS
     const uint64_t st_t0 = wall_clock64();
 #endif
-    const TileRec rec = ((const TileRec*)(ta.ws + ta.off_rec + (size_t)bl * ta.rec_stride))[tile];
     int tc[3], x0[3];
     tile_coords((int)tile, tg, tc, x0);
     const double bgv = bg ? (double)bg[b] : 0.0;
@@ -770,7 +789,6 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
         for (int k = 0; k < 8; ++k) wl->pad[k] = 0u;
     }
     const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
-    const TileRange tr = tile_range(tc, tg);
     const FixScale fs = fix_scale_from_exponent(rec.sexp);
     const OwnXform<T> xf = own_xform<T>(ps, gd);
     __syncthreads();
@@ -783,19 +801,7 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
             own_points<T, HAS_PW>(sc, have, P, points, pw, vec_ok != 0, [&](int, bool live, const T (&pt)[3], T pwi) {
                 int ref0[3];
                 T dlo[3];
-                bool ok = live;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    T proj = ps.R[d] * pt[0];
-                    proj = proj + ps.R[d + 3] * pt[1];
-                    proj = proj + ps.R[d + 6] * pt[2];
-                    const T coord = (proj - xf.origin[d]) * xf.scale[d];
-                    const T c = coord - T(0.5);
-                    ok = ok && (c > T(-1)) && (c <= xf.nf[d]);
-                    const T r = ceil_t<T>(c);
-                    ref0[d] = ok ? (int)r - 1 : 0;
-                    dlo[d] = coord - (r - T(0.5));
-                }
+                const bool ok = own_ref<T>(pt, ps, xf, ref0, dlo) && live;
                 // padded tile coordinates of the lower neighbour: 0 .. T
                 const uint32_t l0 = (uint32_t)(ref0[0] - x0[0] + 1), l1 = (uint32_t)(ref0[1] - x0[1] + 1),
                                l2 = (uint32_t)(ref0[2] - x0[2] + 1);
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
                 }
             });
         };
-        own_walk<T, true>(ta, rec, bl, part, nparts, ps, gd, tr, wl, visit);
+        own_walk(ta, rec, bl, x0, wl, visit);
     };
     if (fs.mul != 0.0) run(std::true_type{});  // (uniform)
     else run(std::false_type{});
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
     // flush the owned cells: thread -> 4 cells along x
     const bool to_slab = nparts > 1;
     // (part of a split tile: the raw 64-bit cells go to this part's slab; k_own_combine sums)
-    unsigned long long* slab = slabs + (size_t)((rec.parts >> 8) + part) * kCells;
+    unsigned long long* slab = slabs + (size_t)(rec.first_slab + part) * kCells;
     for (int q = threadIdx.x; q < kCells / 4; q += kOT) {
         const int x = (q % (kTX / 4)) * 4, y = (q / (kTX / 4)) % kTY, z = q / (kTX / 4 * kTY);
         const double* src = acc + ((x + 1) + kPX * (y + 1) + kPX * kPY * (z + 1));
@@ -991,19 +997,8 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
         }
         int ref0[3];
         T dlo[3];
-        bool ok = live;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            T proj = ps.R[d] * pt[0];
-            proj = proj + ps.R[d + 3] * pt[1];
-            proj = proj + ps.R[d + 6] * pt[2];
-            const T coord = (proj - xf.origin[d]) * xf.scale[d];
-            const T c = coord - T(0.5);
-            ok = ok && (c > T(-1)) && (c <= xf.nf[d]);
-            const T r = ceil_t<T>(c);
-            ref0[d] = ok ? (int)r - 1 : 0;
-            dlo[d] = coord - (r - T(0.5));
-        }
+        const bool ok = own_ref<T>(pt, ps, xf, ref0, dlo) && live;
+        if (!ok) ref0[0] = ref0[1] = ref0[2] = 0;
         // the eight cells: all requested before the first is used; a neighbour outside the grid
         // (individual drop, src/raster_pullback.jl:51) reads cell 0 and counts as 0
         const bool lo0 = ref0[0] >= 0, hi0 = ref0[0] + 1 < n0, lo1 = ref0[1] >= 0, hi1 = ref0[1] + 1 < n1,
@@ -1135,7 +1130,7 @@ struct OwnPlan {
     int64_t nSC, nL1, nL2, Bw;
     uint32_t list_cap, cap;
     int max_items, max_slabs, max_split;
-    size_t off_ctl, off_b0, off_b1, off_b2, off_rec, off_list, off_items, off_split, off_slabs, total;
+    size_t off_ctl, off_b0, off_b1, off_b2, off_mw1, off_mw2, off_rec, off_list, off_items, off_split, off_slabs, total;
     size_t rec_stride, list_stride, items_stride, split_stride;
 };
 
@@ -1178,18 +1173,22 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     pl.off_ctl = o;
     o += oalign((size_t)pl.Bw * kCtlWords * 4);
     pl.off_b0 = o;
-    o += oalign((size_t)(pl.nSC + 1) * sizeof(Box0));
+    o += oalign((size_t)(pl.nSC + 1) * sizeof(IBox) * pl.Bw);
     pl.off_b1 = o;
-    o += oalign((size_t)(pl.nL1 + 1) * sizeof(Box1));
+    o += oalign((size_t)(pl.nL1 + 1) * sizeof(IBox) * pl.Bw);
     pl.off_b2 = o;
-    o += oalign((size_t)(pl.nL2 + 1) * sizeof(Box1));
+    o += oalign((size_t)(pl.nL2 + 1) * sizeof(IBox) * pl.Bw);
+    pl.off_mw1 = o;
+    o += oalign((size_t)(pl.nL1 + 1) * 4);
+    pl.off_mw2 = o;
+    o += oalign((size_t)(pl.nL2 + 1) * 4);
     pl.rec_stride = oalign((size_t)tg.NT * sizeof(TileRec));
     pl.off_rec = o;
     o += pl.rec_stride * pl.Bw;
     pl.list_stride = oalign((size_t)pl.list_cap * 4);
     pl.off_list = o;
     o += pl.list_stride * pl.Bw;
-    pl.items_stride = oalign((size_t)kBuckets * pl.max_items * sizeof(uint2));
+    pl.items_stride = oalign((size_t)kBuckets * pl.max_items * sizeof(OwnItem));
     pl.off_items = o;
     o += pl.items_stride * pl.Bw;
     pl.split_stride = oalign((size_t)pl.max_split * 4);
@@ -1246,6 +1245,11 @@ static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws) {
     pa.max_split = pl.max_split;
     pa.cap = pl.cap;
     pa.fixed = oknobs().fixed;
+    pa.b1 = (const IBox*)(ws + pl.off_b1);
+    pa.b2 = (const IBox*)(ws + pl.off_b2);
+    pa.mw1 = nullptr;
+    pa.nL1 = pl.nL1;
+    pa.nL2 = pl.nL2;
     return pa;
 }
 static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
@@ -1261,8 +1265,7 @@ static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
     ta.max_items = pl.max_items;
     ta.nL1 = pl.nL1;
     ta.nSC = pl.nSC;
-    ta.b0 = (const Box0*)(ws + pl.off_b0);
-    ta.b1 = (const Box1*)(ws + pl.off_b1);
+    ta.b0 = (const IBox*)(ws + pl.off_b0);
     ta.dbg_words = (size_t)pl.max_slabs * kCells * 2;
     return ta;
 }
@@ -1271,26 +1274,36 @@ template <typename T> static bool vec_ok(const T* points, const T* pw) {
     return (((uintptr_t)points) & 15) == 0 && (((uintptr_t)pw) & 15) == 0;
 }
 
-// boxes (first pose group of a call) + plan of poses [b0, b0 + nb)
+// boxes + plan of poses [b0, b0 + nb)
 template <typename T>
 static int own_prepare(hipStream_t st, const OGeom& tg, const GridDesc<3>& gd, const OwnPlan& pl, char* ws,
-                       int64_t P, int64_t B, const T* points, const T* pw, const T* rot, const T* trans,
-                       const T* ow, int64_t b0, int64_t nb, bool boxes) {
+                       int64_t P, const T* points, const T* pw, const T* rot, const T* trans, const T* ow,
+                       int64_t b0, int64_t nb) {
     uint32_t* ctl = (uint32_t*)(ws + pl.off_ctl);
     const int ctl_words = (int)(pl.Bw * kCtlWords);
-    if (boxes && P > 0) {
-        hipLaunchKernelGGL((k_own_boxes<T>), dim3((unsigned)pl.nL1), dim3(256), 0, st, P, points, pw,
-                           vec_ok(points, pw) ? 1 : 0, (Box0*)(ws + pl.off_b0), (Box1*)(ws + pl.off_b1), ctl,
-                           ctl_words);
-        hipLaunchKernelGGL(k_own_boxes2, dim3((unsigned)((pl.nL2 + 3) / 4)), dim3(256), 0, st, pl.nL1,
-                           (const Box1*)(ws + pl.off_b1), (Box1*)(ws + pl.off_b2));
+    float* mw1 = pw ? (float*)(ws + pl.off_mw1) : (float*)nullptr;
+    if (P > 0) {
+        OwnBoxArgs ba;
+        ba.b0 = (IBox*)(ws + pl.off_b0);
+        ba.b1 = (IBox*)(ws + pl.off_b1);
+        ba.mw1 = mw1;
+        ba.nSC = pl.nSC;
+        ba.nL1 = pl.nL1;
+        ba.ctl = ctl;
+        ba.ctl_words = ctl_words;
+        hipLaunchKernelGGL((k_own_boxes<T>), dim3((unsigned)pl.nL1), dim3(256), 0, st, gd, P, points, pw,
+                           vec_ok(points, pw) ? 1 : 0, rot, trans, b0, (int)nb, ba);
+        hipLaunchKernelGGL(k_own_boxes2, dim3((unsigned)((pl.nL2 + 3) / 4), (unsigned)nb), dim3(256), 0, st,
+                           pl.nL1, pl.nL2, (const IBox*)(ws + pl.off_b1), (const float*)mw1,
+                           (IBox*)(ws + pl.off_b2), (float*)(ws + pl.off_mw2));
     } else {
         DPR_HIP(hipMemsetAsync(ctl, 0, (size_t)ctl_words * 4, st));
     }
     stage_mark(st);
-    hipLaunchKernelGGL((k_own_plan<T>), dim3((unsigned)tg.NT, (unsigned)nb), dim3(256), 0, st, tg, gd, P, B,
-                       pl.nL1, pl.nL2, (const Box1*)(ws + pl.off_b1), (const Box1*)(ws + pl.off_b2), rot,
-                       trans, ow, points, pw, b0, plan_args(pl, ws));
+    OwnPlanArgs pa = plan_args(pl, ws);
+    pa.mw1 = mw1;
+    hipLaunchKernelGGL((k_own_plan<T>), dim3((unsigned)tg.NT, (unsigned)nb), dim3(256), 0, st, tg, gd, P, ow,
+                       pw ? 1 : 0, b0, pa);
     stage_mark(st);
     return DPR_OK;
 }
@@ -1325,7 +1338,7 @@ int raster_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     }
     for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
         const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
-        if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, B, points, pw, rot, trans, ow, b0, nb, b0 == 0))
+        if (int rc = own_prepare<T>(st, tg, gd, pl, ws, P, points, pw, rot, trans, ow, b0, nb))
             return rc;
         const OwnTileArgs ta = tile_args(pl, ws);
         unsigned long long* slabs = (unsigned long long*)(ws + pl.off_slabs);

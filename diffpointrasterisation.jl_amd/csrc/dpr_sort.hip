@@ -25,15 +25,20 @@
 
 namespace dpr {
 
-template <typename T, int NI>
+// FINE: 30-bit keys in 3-D (1024^3 cells, four radix passes) -- what the public dpr_sort_points_*
+// uses: the box hierarchy of the owner-computes 3-D path (dpr_owner.hip) culls by groups of 16
+// consecutive points, and with 256^3 cells the points inside a cell (4.7 of them at the centre of
+// the 10 M-point / 256^3 headline cloud) come in arbitrary order, a group of 16 is a line of 3-4
+// cells rather than a 1.5-voxel blob, and a tile looks at 2.0 points per point it needs instead of
+// 1.6.  Coarse 24-bit keys (three passes) stay for the sorts INSIDE calls, which are timed: chunks
+// of thousands of points only need cells of a voxel or so.
+template <typename T, int NI, bool FINE>
 __global__ __launch_bounds__(256) void k_hilbert_keys(int64_t P, const T* __restrict__ points,
                                                       uint32_t* __restrict__ keys,
                                                       uint32_t* __restrict__ idx) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
-    // 24-bit keys (three radix passes): 256^3 / 4096^2 cells order a cloud finely enough for
-    // chunks of thousands of points and for tiles of tens of voxels
-    constexpr int BITS = NI == 3 ? 8 : 12;
+    constexpr int BITS = NI == 3 ? (FINE ? 10 : 8) : 12;
     uint32_t X[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -107,7 +112,7 @@ size_t sort_workspace_bytes(int64_t P) {
 template <typename T>
 int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
                      uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes,
-                     uint32_t* inv_perm) {
+                     uint32_t* inv_perm, bool fine) {
     if (n_in != 2 && n_in != 3)
         return fail(DPR_ERR_UNSUPPORTED_DIMS, "dpr_sort_points: n_in must be 2 or 3 (got %d)", n_in);
     if (P < 0 || P >= ((int64_t)1 << 32))
@@ -133,12 +138,16 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
     void* temp = ws + 3 * salign((size_t)P * 4);
     size_t temp_bytes = radix_temp_bytes(P);
     const dim3 grid((unsigned)((P + 255) / 256));
-    if (n_in == 3)
-        hipLaunchKernelGGL((k_hilbert_keys<T, 3>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+    if (n_in == 3 && fine)
+        hipLaunchKernelGGL((k_hilbert_keys<T, 3, true>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+    else if (n_in == 3)
+        hipLaunchKernelGGL((k_hilbert_keys<T, 3, false>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+    else if (fine)
+        hipLaunchKernelGGL((k_hilbert_keys<T, 2, true>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
     else
-        hipLaunchKernelGGL((k_hilbert_keys<T, 2>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+        hipLaunchKernelGGL((k_hilbert_keys<T, 2, false>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm,
-                                             (size_t)P, 0, 24, st);
+                                             (size_t)P, 0, (fine && n_in == 3) ? 30 : 24, st);
     if (e != hipSuccess)
         return fail(DPR_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
     const dim3 ggrid((unsigned)((P + 256 * kGatherPer - 1) / (256 * kGatherPer)));
@@ -154,9 +163,9 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
 }
 
 template int sort_points_impl<float>(void*, int, int64_t, const float*, float*, uint32_t*,
-                                     const float*, float*, void*, size_t, uint32_t*);
+                                     const float*, float*, void*, size_t, uint32_t*, bool);
 template int sort_points_impl<double>(void*, int, int64_t, const double*, double*, uint32_t*,
-                                      const double*, double*, void*, size_t, uint32_t*);
+                                      const double*, double*, void*, size_t, uint32_t*, bool);
 
 }  // namespace dpr
 
@@ -168,7 +177,7 @@ int dpr_sort_points_f32(void* stream, int n_in, int64_t P, const float* points,
                         float* points_sorted, uint32_t* perm, const float* point_weight,
                         float* point_weight_sorted, void* workspace, size_t workspace_bytes) {
     return dpr::sort_points_impl<float>(stream, n_in, P, points, points_sorted, perm, point_weight,
-                                        point_weight_sorted, workspace, workspace_bytes, nullptr);
+                                        point_weight_sorted, workspace, workspace_bytes, nullptr, true);
 }
 
 int dpr_sort_points_f64(void* stream, int n_in, int64_t P, const double* points,
@@ -176,6 +185,6 @@ int dpr_sort_points_f64(void* stream, int n_in, int64_t P, const double* points,
                         double* point_weight_sorted, void* workspace, size_t workspace_bytes) {
     return dpr::sort_points_impl<double>(stream, n_in, P, points, points_sorted, perm,
                                          point_weight, point_weight_sorted, workspace,
-                                         workspace_bytes, nullptr);
+                                         workspace_bytes, nullptr, true);
 }
 }

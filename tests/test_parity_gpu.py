@@ -969,7 +969,7 @@ def test_sort_points_is_a_morton_permutation(oracle, dev, npdt, tdt, n_in):
     assert sorted(perm_h.tolist()) == list(range(P))
     np.testing.assert_array_equal(sp.cpu().numpy(), pts[perm_h])
     np.testing.assert_array_equal(spw.cpu().numpy(), pw[perm_h])
-    bits = 8 if n_in == 3 else 12
+    bits = 10 if n_in == 3 else 12  # (the public sort: 30-bit keys in 3-D)
     x = (pts[perm_h].astype(npdt) * npdt(0.5) + npdt(0.5)) * npdt(1 << bits)
     q = np.where(~(x > 0), 0, np.where(x >= (1 << bits) - 1, (1 << bits) - 1, np.nan_to_num(x).astype(np.int64))).astype(np.int64)
     key = _hilbert_keys(q, bits)

@@ -59,7 +59,7 @@ for algo, kw in ap_algos:
     f(); torch.cuda.synchronize()
     outs[algo] = out.clone()
     if algo == "chunked" and os.environ.get("DPR_LIB_OVERRIDE", "").endswith("stats.so"):
-        c = ws[256:256 + 128].cpu().numpy().view(np.uint32)
+        c = ws[0:128].cpu().numpy().view(np.uint32)
         res["stats"] = {"list_entries": int(c[0]), "slabs": int(c[1]), "split_tiles": int(c[2]), "overflow": int(c[3]),
                         "visits": int(c[4]), "touching": int(c[5]), "batches": int(c[6]), "lanes_taken": int(c[7]),
                         "items_with_work": int(c[8]), "l0_test_rounds": int(c[9]),
