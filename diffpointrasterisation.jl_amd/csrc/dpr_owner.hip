@@ -375,7 +375,7 @@ struct OwnPlanArgs {
     const IBox *b1, *b2;  // [pose copy][nL1], [pose copy][nL2]
     const float* mw1;     // [nL1] or nullptr (no point weights)
     int64_t nL1, nL2;
-    uint32_t list_cap;   // entries per pose
+    uint32_t list_cap;   // entries per tile
     int max_items;       // per bucket
     int max_slabs;       // per pose group
     int max_split;       // per pose
@@ -488,18 +488,13 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         }
         const float e = s_est[0] + s_est[1] + s_est[2] + s_est[3];
         const float m = fmaxf(fmaxf(s_mw[0], s_mw[1]), fmaxf(s_mw[2], s_mw[3]));
-        uint32_t begin = 0;
-        if (scan_all) {
-            begin = 0xffffffffu;  // more level-2 hits than this block holds: the tile takes every chunk
+        // every tile has its own fixed slot of the list buffer (a cursor shared by all the blocks
+        // of a launch made them queue up on one address: 1216 returning atomics = 20 us)
+        uint32_t begin = (uint32_t)tile * pa.list_cap;
+        if (scan_all || total > pa.list_cap) {
+            begin = 0xffffffffu;  // more candidates than the slot holds: the tile takes every chunk
             total = (uint32_t)pa.nL1;
             ctl[3] = 1u;
-        } else if (total) {
-            begin = atomicAdd(&ctl[0], total);
-            if (begin > pa.list_cap || total > pa.list_cap - begin) {
-                begin = 0xffffffffu;  // the list does not fit: the tile kernels take every chunk
-                total = (uint32_t)pa.nL1;
-                ctl[3] = 1u;
-            }
         }
         // parts: every n-th candidate each
         uint32_t ev = e < 4.0e9f ? (uint32_t)e : 4000000000u;
@@ -599,20 +594,26 @@ __device__ __forceinline__ bool own_item(const OwnTileArgs& ta, int bl, uint32_t
 }
 
 // LDS the discovery loop needs (the tile kernels put it in front of their tile)
+constexpr int kLanesPerSC = 4;                   // lanes that share a sub-chunk (4 points each)
+constexpr int kBatchSC = kWave / kLanesPerSC;    // 16 sub-chunks per batch of a wave
+constexpr int kPtsPerLane = kSC / kLanesPerSC;   // 4
 struct OwnWalkLds {
-    uint32_t queue[kOW][kQueue];  // per wave: sub-chunks waiting for a full batch of 64
-    uint32_t pool[kOT];           // what the waves had left over (< 64 each), shared out again
+    uint32_t queue[kOW][kQueue];  // per wave: sub-chunks waiting for a full batch
+    uint32_t pool[kOT];           // what the waves had left over (< 16 each), shared out again
     uint32_t next, pool_n;
     uint32_t pad[62];
 };
 
 // The discovery loop of a tile kernel.  Waves draw candidate chunks of the item from a counter in
 // LDS, test the 64 level-0 boxes of a chunk (one per lane; the boxes of the NEXT candidate are
-// requested before the current batch is worked on), queue the hits and call `visit(sc, have)` with
-// 64 queued sub-chunks at a time (one per lane).  What a wave has left when the candidates run out
-// (< 64 sub-chunks) goes to a pool of the block, which the waves share out again in batches of 64:
-// without it every wave of the ~1000-sub-chunk items of the headline config ended on a half-empty
-// batch (36 % idle lanes).  One block barrier inside, reached exactly once by every wave.
+// requested before the current batch is worked on), queue the hits and call `visit(sc, quarter,
+// have)` with 16 queued sub-chunks at a time: four neighbouring lanes share a sub-chunk, four
+// points each (one 48-byte load; the four lanes read 192 contiguous bytes).  A batch is four points
+// deep -- with one lane per sub-chunk it was sixteen, 16-32 us during which the waves that had run
+// out of candidates waited, and the leftovers (up to 63 sub-chunks per wave, re-batched from a
+// pool) cost another sixteen on half the waves: half of an item's time (r05 experiments).  What a
+// wave has left when the candidates run out (< 16 sub-chunks) goes to a pool of the block, which
+// the waves share out again.  One block barrier inside, reached exactly once by every wave.
 template <typename Visit>
 __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const OwnItem& item, int bl, const int (&x0)[3],
                                          OwnWalkLds* wl, Visit visit) {
@@ -647,18 +648,17 @@ __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const OwnItem& i
     uint32_t st_batches = 0, st_take = 0, st_tests = 0;
 #endif
     for (;;) {
-        if (qn >= (uint32_t)kWave || (stage == 2 && qn > 0)) {
-            const uint32_t take = qn >= (uint32_t)kWave ? kWave : qn;
+        if (qn >= (uint32_t)kBatchSC || (stage == 2 && qn > 0)) {
+            const uint32_t take = qn >= (uint32_t)kBatchSC ? kBatchSC : qn;
             const uint32_t base = qn - take;
-            // lanes take entries a stride of 17 apart: queue neighbours are neighbours in space
-            const uint32_t e = ((uint32_t)lane * 17u) & (kWave - 1);
+            const uint32_t e = (uint32_t)lane / kLanesPerSC;
             const bool have = e < take;
             const uint32_t sc = queue[base + (have ? e : 0u)];  // (idle lanes: a valid sub-chunk, not worked on)
 #ifdef DPR_OWN_STATS
             ++st_batches;
-            st_take += take;
+            st_take += take * kLanesPerSC;
 #endif
-            visit(sc, have);
+            visit(sc, lane % kLanesPerSC, have);
             qn = base;
             continue;
         }
@@ -674,22 +674,28 @@ __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const OwnItem& i
                 have_c = acquire();
                 continue;
             }
-            // the candidates are gone: what is left (< 64) goes to the block's pool
+            // the candidates are gone: what is left (< 16) goes to the block's pool
             uint32_t pos = 0;
             if (lane == 0 && qn) pos = atomicAdd(&wl->pool_n, qn);
             pos = __builtin_amdgcn_readfirstlane(pos);
             if ((uint32_t)lane < qn) wl->pool[pos + lane] = queue[lane];
             qn = 0;
+#ifdef DPR_OWN_STATS
+            if (threadIdx.x == 0) wl->pad[5] = (uint32_t)wall_clock64();
+#endif
             __syncthreads();
+#ifdef DPR_OWN_STATS
+            if (threadIdx.x == 0) wl->pad[6] = (uint32_t)wall_clock64();
+#endif
             pool_total = wl->pool_n;
-            pool_pos = (uint32_t)wave * kWave;
+            pool_pos = (uint32_t)wave * kBatchSC;
             stage = 2;
         }
         if (pool_pos >= pool_total) break;
-        const uint32_t n = pool_total - pool_pos < (uint32_t)kWave ? pool_total - pool_pos : (uint32_t)kWave;
+        const uint32_t n = pool_total - pool_pos < (uint32_t)kBatchSC ? pool_total - pool_pos : (uint32_t)kBatchSC;
         if ((uint32_t)lane < n) queue[lane] = wl->pool[pool_pos + lane];
         qn = n;
-        pool_pos += kOW * kWave;
+        pool_pos += kOW * kBatchSC;
     }
 #ifdef DPR_OWN_STATS
     if (lane == 0) {
@@ -700,50 +706,35 @@ __device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const OwnItem& i
 #endif
 }
 
-// points per 48-byte round of a lane: 4 (fp32) / 2 (fp64)
-template <typename T> __host__ __device__ constexpr int own_ppr() { return 16 / (int)sizeof(T); }
-
-// the 16 points of a lane's sub-chunk, PPR per 48-byte round, the next round requested before the
-// current one is worked on; body(point index in the sub-chunk, live, pt[3], w)
+// the four points of a lane's quarter of a sub-chunk: body(point index in the sub-chunk, live, pt[3], w)
 template <typename T, bool HAS_PW, typename Body>
-__device__ __forceinline__ void own_points(uint32_t sc, bool have, int64_t P, const T* __restrict__ points,
-                                           const T* __restrict__ pw, bool vec, Body body) {
-    constexpr int PPR = own_ppr<T>();
+__device__ __forceinline__ void own_points(uint32_t sc, int quarter, bool have, int64_t P,
+                                           const T* __restrict__ points, const T* __restrict__ pw, bool vec,
+                                           Body body) {
+    constexpr int N = kPtsPerLane;
     // (a lane without a sub-chunk was handed a valid one by own_walk: it loads like the others and
     // treats every point as dead)
-    const int64_t p0 = (int64_t)sc * kSC;
-    const bool full = p0 + kSC <= P;  // false only for the last sub-chunk of the cloud
-    const int npts = have ? (full ? kSC : (int)(P - p0)) : 0;
-    const T* src = points + p0 * 3;
-    T cur[PPR * 3], nxt[PPR * 3], wc[PPR], wn[PPR];
-    auto fetch = [&](int r, T (&v)[PPR * 3], T (&w)[PPR]) {
-        if (full) {
-            load_run<T, PPR * 3>(src + r * PPR * 3, vec, v);
-            if constexpr (HAS_PW) load_run<T, PPR>(pw + p0 + r * PPR, vec, w);
-        } else {
+    const int64_t p0 = (int64_t)sc * kSC + quarter * N;
+    const bool full = p0 + N <= P;  // false only in the last sub-chunk of the cloud
+    const int npts = have ? (full ? N : (p0 < P ? (int)(P - p0) : 0)) : 0;
+    T v[N * 3], w[N];
+    if (full) {
+        load_run<T, N * 3>(points + p0 * 3, vec, v);
+        if constexpr (HAS_PW) load_run<T, N>(pw + p0, vec, w);
+    } else {
 #pragma unroll
-            for (int q = 0; q < PPR; ++q) {
-                const int64_t p = p0 + r * PPR + q;
-                const int64_t pc = p < P ? p : P - 1;
+        for (int q = 0; q < N; ++q) {
+            const int64_t p = p0 + q;
+            const int64_t pc = p < P ? p : P - 1;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) v[q * 3 + j] = points[pc * 3 + j];
-                if constexpr (HAS_PW) w[q] = pw[pc];
-            }
+            for (int j = 0; j < 3; ++j) v[q * 3 + j] = points[pc * 3 + j];
+            if constexpr (HAS_PW) w[q] = pw[pc];
         }
-    };
-    fetch(0, nxt, wn);
-#pragma unroll 1
-    for (int r = 0; r < kSC / PPR; ++r) {
+    }
 #pragma unroll
-        for (int k = 0; k < PPR * 3; ++k) cur[k] = nxt[k];
-#pragma unroll
-        for (int k = 0; k < PPR; ++k) wc[k] = wn[k];
-        if (r + 1 < kSC / PPR) fetch(r + 1, nxt, wn);
-#pragma unroll
-        for (int q = 0; q < PPR; ++q) {
-            const T pt[3] = {cur[q * 3], cur[q * 3 + 1], cur[q * 3 + 2]};
-            body(r * PPR + q, r * PPR + q < npts, pt, HAS_PW ? wc[q] : T(1));
-        }
+    for (int q = 0; q < N; ++q) {
+        const T pt[3] = {v[q * 3], v[q * 3 + 1], v[q * 3 + 2]};
+        body(quarter * N + q, q < npts, pt, HAS_PW ? w[q] : T(1));
     }
 }
 
@@ -766,6 +757,9 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
     const uint32_t tile = rec.tile, part = rec.part_nparts & 0xffffu, nparts = rec.part_nparts >> 16;
 #ifdef DPR_OWN_STATS
     const uint64_t st_t0 = wall_clock64();
+#define DPR_STAMP(k) do { if (threadIdx.x == 0) wl->pad[8 + (k)] = (uint32_t)(wall_clock64() - st_t0); } while (0)
+#else
+#define DPR_STAMP(k) do { } while (0)
 #endif
     int tc[3], x0[3];
     tile_coords((int)tile, tg, tc, x0);
@@ -791,14 +785,19 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
     const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
     const FixScale fs = fix_scale_from_exponent(rec.sexp);
     const OwnXform<T> xf = own_xform<T>(ps, gd);
+    DPR_STAMP(0);
     __syncthreads();
+    DPR_STAMP(1);
 #ifdef DPR_OWN_STATS
     uint32_t st_vis = 0, st_touch = 0;
 #endif
+#ifdef DPR_OWN_EXP
+    double exp_sink = 0.0;
+#endif
     auto run = [&](auto fix_tag) {
         constexpr bool FIX = decltype(fix_tag)::value;
-        auto visit = [&](uint32_t sc, bool have) {
-            own_points<T, HAS_PW>(sc, have, P, points, pw, vec_ok != 0, [&](int, bool live, const T (&pt)[3], T pwi) {
+        auto visit = [&](uint32_t sc, int quarter, bool have) {
+            own_points<T, HAS_PW>(sc, quarter, have, P, points, pw, vec_ok != 0, [&](int, bool live, const T (&pt)[3], T pwi) {
                 int ref0[3];
                 T dlo[3];
                 const bool ok = own_ref<T>(pt, ps, xf, ref0, dlo) && live;
@@ -806,19 +805,29 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
                 const uint32_t l0 = (uint32_t)(ref0[0] - x0[0] + 1), l1 = (uint32_t)(ref0[1] - x0[1] + 1),
                                l2 = (uint32_t)(ref0[2] - x0[2] + 1);
                 const bool touches = ok && l0 <= (uint32_t)kTX && l1 <= (uint32_t)kTY && l2 <= (uint32_t)kTZ;
-#ifdef DPR_OWN_STATS
+#if defined(DPR_OWN_STATS) && DPR_OWN_STATS >= 2  /* (per-point counters slow the kernel down 2x) */
                 st_vis += live ? 1u : 0u;
                 st_touch += touches ? 1u : 0u;
 #endif
+#if defined(DPR_OWN_EXP) && DPR_OWN_EXP == 2  /* transform + test only */
+                exp_sink += touches ? (double)dlo[0] : 0.0;
+                if (false) {
+#else
                 if (touches) {
+#endif
                     const T w = HAS_PW ? ps.ow * pwi : ps.ow;  // src/raster.jl:52
                     double* cell = acc + (l0 + kPX * l1 + kPX * kPY * l2);
                     // all eight neighbours have a cell (pad cells, and owned cells beyond the grid
                     // edge, are never flushed: the individual drop of src/raster.jl:62)
 #pragma unroll
-                    for (int s = 0; s < 8; ++s)
+                    for (int s = 0; s < 8; ++s) {
+#if defined(DPR_OWN_EXP) && DPR_OWN_EXP == 1  /* no LDS atomics: where does the time go? */
+                        exp_sink += (double)voxel_weight<T, 3>(dlo, s, w) * fs.mul + (double)(size_t)cell;
+#else
                         cell_add<FIX, T>(cell + ((s & 1) + kPX * ((s >> 1) & 1) + kPX * kPY * (s >> 2)),
                                          voxel_weight<T, 3>(dlo, s, w), fs);
+#endif
+                    }
                 }
             });
         };
@@ -853,8 +862,20 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
             dbg[3] = part | (nparts << 16);
             dbg[4] = (uint32_t)st_t0;
             dbg[5] = rec.count;
+            // phases (ticks of 10 ns): setup | zero+barrier | wave 0 to the pool barrier | its wait there | pooled batches + final barrier
+            const uint32_t t_end_walk = (uint32_t)(wall_clock64() - st_t0);
+            atomicAdd(&ctl[12], wl->pad[8]);
+            atomicAdd(&ctl[13], wl->pad[9] - wl->pad[8]);
+            atomicAdd(&ctl[14], (wl->pad[5] - (uint32_t)st_t0) - wl->pad[9]);
+            atomicAdd(&ctl[15], wl->pad[6] - wl->pad[5]);
+            atomicAdd(&ctl[1 + 2], 0u);
+            dbg[6] = t_end_walk - (wl->pad[6] - (uint32_t)st_t0);
+            dbg[7] = wl->pad[8];
         }
     }
+#endif
+#ifdef DPR_OWN_EXP
+    if (exp_sink == 1.2345) acc[threadIdx.x] = exp_sink;
 #endif
     __syncthreads();
     // flush the owned cells: thread -> 4 cells along x
@@ -974,87 +995,104 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
 #pragma unroll
     for (int k = 0; k < kNVal - 1; ++k) vals[k] = T(0);
     const int n0 = gd.n[0], n1 = gd.n[1], n2 = gd.n[2];
+    // Software pipeline, one point deep: the transform of point i + 1 and its eight gathers are issued
+    // BEFORE the arithmetic of point i (and the coordinates of point i + 2 before that), so a wave
+    // covers its own gather latency with ~250 instructions of work instead of leaving it to the
+    // other waves of the SIMD (4-5 of them at ~90 registers: 0.18 -> ? ms at 10 M points, r05).
+    struct Stage {
+        T pt[3], pwi, dlo[3], gv[8];
+        uint32_t in;  // bit s: neighbour s is a cell of the grid
+        bool ok, live;
+        int64_t p;
+    };
+    const int64_t n_it = (p_hi - p_lo + kDT - 1) / kDT;  // (uniform)
     T nxt[3] = {T(0), T(0), T(0)}, wn = T(1);
-    {
-        const int64_t p = p_lo + threadIdx.x;
-        const int64_t pc = p < P ? p : (P > 0 ? P - 1 : 0);
-        if (P > 0) {
+    auto fetch_point = [&](int64_t p) {  // (clamped: the loop body stays branch-free)
+        const int64_t q = p < P ? p : P - 1;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) nxt[j] = points[pc * 3 + j];
-            if constexpr (HAS_PW) wn = pw[pc];
-        }
-    }
-#pragma unroll 1
-    for (int64_t p = p_lo + threadIdx.x; p < p_hi + threadIdx.x; p += kDT) {  // (uniform trip count)
-        const bool live = p < p_hi;
-        const T pt[3] = {nxt[0], nxt[1], nxt[2]};
-        const T pwi = wn;
-        {  // next point of this lane (clamped: the loop body stays branch-free)
-            const int64_t q = p + kDT < P ? p + kDT : P - 1;
+        for (int j = 0; j < 3; ++j) nxt[j] = points[q * 3 + j];
+        if constexpr (HAS_PW) wn = pw[q];
+    };
+    auto front = [&](int64_t p, Stage& st) {  // transform + gathers of the point in `nxt`
+        st.p = p;
+        st.live = p < p_hi;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) nxt[j] = points[q * 3 + j];
-            if constexpr (HAS_PW) wn = pw[q];
-        }
+        for (int j = 0; j < 3; ++j) st.pt[j] = nxt[j];
+        st.pwi = wn;
         int ref0[3];
-        T dlo[3];
-        const bool ok = own_ref<T>(pt, ps, xf, ref0, dlo) && live;
-        if (!ok) ref0[0] = ref0[1] = ref0[2] = 0;
+        st.ok = own_ref<T>(st.pt, ps, xf, ref0, st.dlo) && st.live;
+        if (!st.ok) ref0[0] = ref0[1] = ref0[2] = 0;
         // the eight cells: all requested before the first is used; a neighbour outside the grid
         // (individual drop, src/raster_pullback.jl:51) reads cell 0 and counts as 0
         const bool lo0 = ref0[0] >= 0, hi0 = ref0[0] + 1 < n0, lo1 = ref0[1] >= 0, hi1 = ref0[1] + 1 < n1,
                    lo2 = ref0[2] >= 0, hi2 = ref0[2] + 1 < n2;
         const int64_t base = ((int64_t)ref0[2] * n1 + ref0[1]) * n0 + ref0[0];
-        T gv[8];
-        bool in[8];
+        st.in = 0u;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int s0 = s & 1, s1 = (s >> 1) & 1, s2 = s >> 2;
-            in[s] = ok && (s0 ? hi0 : lo0) && (s1 ? hi1 : lo1) && (s2 ? hi2 : lo2);
+            const bool in = st.ok && (s0 ? hi0 : lo0) && (s1 ? hi1 : lo1) && (s2 ? hi2 : lo2);
+            st.in |= in ? (1u << s) : 0u;
             const int64_t off = base + s0 + (int64_t)n0 * (s1 + (int64_t)n1 * s2);
-            gv[s] = gb[in[s] ? off : 0];
+            st.gv[s] = gb[in ? off : 0];
         }
+    };
+    auto back = [&](const Stage& st) {  // the point's arithmetic and its stores
         T gout[3] = {T(0), T(0), T(0)}, dpw_part = T(0);
-        {
-            T dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
+        T dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const T gi = in[s] ? gv[s] : T(0);
-                const T dweight = voxel_weight<T, 3>(dlo, s, gi);  // raster_pullback.jl:55
-                dow_part += dweight * pwi;                         // :57
-                dpw_part += dweight * ps.ow;                       // :58
-                const T factor = gi * ps.ow * pwi;                 // :60
+        for (int s = 0; s < 8; ++s) {
+            const T gi = ((st.in >> s) & 1u) ? st.gv[s] : T(0);
+            const T dweight = voxel_weight<T, 3>(st.dlo, s, gi);  // raster_pullback.jl:55
+            dow_part += dweight * st.pwi;                         // :57
+            dpw_part += dweight * ps.ow;                          // :58
+            const T factor = gi * ps.ow * st.pwi;                 // :60
 #pragma unroll
-                for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, dlo, s);
-            }
-            T scaled[3];
-#pragma unroll
-            for (int n = 0; n < 3; ++n) scaled[n] = ok ? dcoord[n] * xf.scale[n] : T(0);  // :67
-            dpw_part = ok ? dpw_part : T(0);
-#pragma unroll
-            for (int n = 0; n < 3; ++n) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) vals[n + j * 3] += scaled[n] * pt[j];  // :69
-                vals[9 + n] += scaled[n];                                         // :68
-            }
-            vals[12] += ok ? dow_part : T(0);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {  // rotation' * scaled (:70)
-                T v = ps.R[0 + j * 3] * scaled[0];
-                v = v + ps.R[1 + j * 3] * scaled[1];
-                v = v + ps.R[2 + j * 3] * scaled[2];
-                gout[j] = v;
-            }
+            for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, st.dlo, s);
         }
-        if (live) {
+        T scaled[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) scaled[n] = st.ok ? dcoord[n] * xf.scale[n] : T(0);  // :67
+        dpw_part = st.ok ? dpw_part : T(0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vals[n + j * 3] += scaled[n] * st.pt[j];  // :69
+            vals[9 + n] += scaled[n];                                            // :68
+        }
+        vals[12] += st.ok ? dow_part : T(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // rotation' * scaled (:70)
+            T v = ps.R[0 + j * 3] * scaled[0];
+            v = v + ps.R[1 + j * 3] * scaled[1];
+            v = v + ps.R[2 + j * 3] * scaled[2];
+            gout[j] = v;
+        }
+        if (st.live) {
             if (FIRST) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) __builtin_nontemporal_store(gout[j], &ds_dpoints[p * 3 + j]);
-                if (ds_dpw) __builtin_nontemporal_store(dpw_part, &ds_dpw[p]);
+                for (int j = 0; j < 3; ++j) __builtin_nontemporal_store(gout[j], &ds_dpoints[st.p * 3 + j]);
+                if (ds_dpw) __builtin_nontemporal_store(dpw_part, &ds_dpw[st.p]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) ds_dpoints[p * 3 + j] += gout[j];
-                if (ds_dpw) ds_dpw[p] += dpw_part;
+                for (int j = 0; j < 3; ++j) ds_dpoints[st.p * 3 + j] += gout[j];
+                if (ds_dpw) ds_dpw[st.p] += dpw_part;
             }
+        }
+    };
+    if (n_it > 0 && P > 0) {
+        Stage cur, nx;
+        const int64_t pa = p_lo + threadIdx.x;
+        fetch_point(pa);
+        front(pa, cur);
+        fetch_point(pa + kDT);
+#pragma unroll 1
+        for (int64_t i = 0; i < n_it; ++i) {
+            const int64_t p1 = pa + (i + 1) * kDT;
+            front(p1, nx);            // (beyond the slice: dead, its gathers read cell 0)
+            fetch_point(p1 + kDT);
+            back(cur);
+            cur = nx;
         }
     }
     // ds_dbackground: this block's slice of the grid (16 bytes per load where the slice allows)
@@ -1165,10 +1203,11 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     pl.max_slabs = oknobs().max_slabs;
     pl.max_split = pl.max_slabs / 2 + 1;
     pl.max_items = tg.NT + pl.max_slabs;
-    // a chunk of a coherent cloud overlaps ~6 tiles; 16 per chunk + one per tile, else the tile
-    // kernels scan the chunks themselves
-    const int64_t lc = pl.nL1 * 16 + tg.NT;
-    pl.list_cap = (uint32_t)(lc > 0x7fffffff ? 0x7fffffff : lc);
+    // candidate chunks per tile: 64 times the average of a cloud that fills the grid, 256 .. 8192;
+    // a tile with more takes every chunk as a candidate (its level-0 tests still cull exactly)
+    int64_t lc = (64 * pl.nL1 / tg.NT + 63) / 64 * 64;
+    lc = lc < 256 ? 256 : (lc > 8192 ? 8192 : lc);
+    pl.list_cap = (uint32_t)lc;
     size_t o = 0;
     pl.off_ctl = o;
     o += oalign((size_t)pl.Bw * kCtlWords * 4);
@@ -1185,7 +1224,7 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     pl.rec_stride = oalign((size_t)tg.NT * sizeof(TileRec));
     pl.off_rec = o;
     o += pl.rec_stride * pl.Bw;
-    pl.list_stride = oalign((size_t)pl.list_cap * 4);
+    pl.list_stride = oalign((size_t)pl.list_cap * 4 * tg.NT);
     pl.off_list = o;
     o += pl.list_stride * pl.Bw;
     pl.items_stride = oalign((size_t)kBuckets * pl.max_items * sizeof(OwnItem));

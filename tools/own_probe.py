@@ -64,6 +64,8 @@ for algo, kw in ap_algos:
                         "visits": int(c[4]), "touching": int(c[5]), "batches": int(c[6]), "lanes_taken": int(c[7]),
                         "items_with_work": int(c[8]), "l0_test_rounds": int(c[9]),
                         "sum_item_us": c[10] * 0.01, "max_item_us": c[11] * 0.01,
+                        "phase_sum_us": {"setup": c[12] * 0.01, "zero+barrier": c[13] * 0.01,
+                                         "wave0_main": c[14] * 0.01, "wave0_wait_pool_barrier": c[15] * 0.01},
                         "visits_per_point": c[4] / a.P, "touch_per_point": c[5] / a.P,
                         "lane_util": c[7] / max(1, 64 * c[6]), "buckets": [int(x) for x in c[16:32]]}
         # per-item records at the end of the slab area (= end of the raster workspace layout)
@@ -71,6 +73,8 @@ for algo, kw in ap_algos:
         nit = int(sum(c[16:32]))
         rec = ws[need - 32 * nit: need].cpu().numpy().view(np.uint32).reshape(-1, 8)[::-1].astype(np.int64)
         dt, vis, t0 = rec[:, 0] * 0.01, rec[:, 1], rec[:, 4]
+        res.setdefault("phases2", {})["pool+final_sum_us"] = float(rec[:, 6].sum() * 0.01)
+        res["phases2"]["setup_sum_us"] = float(rec[:, 7].sum() * 0.01)
         t0 = (t0 - t0.min()) * 0.01
         order = np.argsort(-dt)
         res["items"] = {"n": nit, "sum_us": float(dt.sum()), "max_us": float(dt.max()),
