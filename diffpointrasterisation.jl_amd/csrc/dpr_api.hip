@@ -415,6 +415,10 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
                 if (rs.target)                                                                   \
                     return fail(DPR_ERR_UNSUPPORTED_ALGO,                                        \
                                 "the residual pullback has no 3-D DPR_ALGO_CHUNKED variant");    \
+                if (grid[0] < 2) /* (its x-pair gathers need two cells per row) */               \
+                    return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans,  \
+                                                      ow, pw, d_pts, d_rot, d_trans, d_bg, d_ow, \
+                                                      d_pw, rs);                                 \
                 return pullback_owner<T>(st, flags, grid, G, P, B, g, points, rot, trans, ow,    \
                                          pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
                                          ws_bytes);                                              \
