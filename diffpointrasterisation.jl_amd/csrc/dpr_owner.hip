@@ -1003,10 +1003,11 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
         T pt[3], pwi, dlo[3], gv[8];
         uint32_t in;  // bit r: row r = (s1, s2) of the neighbourhood is inside the grid
         int xsel;     // which halves of the loaded x-pairs are the lower / upper neighbour
-        bool ok, live;
+        bool ok, live, edge;
         int64_t p;
     };
     const int64_t n_it = (p_hi - p_lo + kDT - 1) / kDT;  // (uniform)
+    const uint32_t row1 = (uint32_t)n0, row2 = (uint32_t)n0 * (uint32_t)n1;  // (G < 2^31: 32-bit cell offsets)
     T nxt[3] = {T(0), T(0), T(0)}, wn = T(1);
     auto fetch_point = [&](int64_t p) {  // (clamped: the loop body stays branch-free)
         const int64_t q = p < P ? p : P - 1;
@@ -1024,41 +1025,52 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
         st.ok = own_ref<T>(st.pt, ps, xf, ref0, st.dlo) && st.live;
         if (!st.ok) ref0[0] = ref0[1] = ref0[2] = 0;
         // the eight cells as FOUR loads of an x-pair (the two x-neighbours are adjacent in memory:
-        // half the gather instructions, 0.164 -> ? ms), all requested before the first is used.  The
-        // pair starts at xb = clamp(ref0.x, 0, n0 - 2), so it never leaves its row; a neighbour
+        // half the gather instructions, 0.164 -> 0.139 ms), all requested before the first is used.
+        // The pair starts at xb = clamp(ref0.x, 0, n0 - 2), so it never leaves its row; a neighbour
         // outside the grid (individual drop, src/raster_pullback.jl:51) counts as 0: in y / z the row
-        // index is clamped and the value masked, in x `xsel` says which half of the pair is which
+        // is redirected to cell 0 and masked, in x `xsel` says which half of the pair is which
         const bool lo1 = ref0[1] >= 0, hi1 = ref0[1] + 1 < n1, lo2 = ref0[2] >= 0, hi2 = ref0[2] + 1 < n2;
         const int xb = ref0[0] < 0 ? 0 : (ref0[0] > n0 - 2 ? n0 - 2 : ref0[0]);
         st.xsel = ref0[0] - xb;  // -1: pair = (x+1, x+2) -> only hi = pair[0]; 0: (lo, hi); 1: only lo = pair[1]
+        const uint32_t base = ((uint32_t)ref0[2] * (uint32_t)n1 + (uint32_t)ref0[1]) * (uint32_t)n0 + (uint32_t)xb;
         st.in = 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int s1 = r & 1, s2 = r >> 1;
             const bool in = st.ok && (s1 ? hi1 : lo1) && (s2 ? hi2 : lo2);
             st.in |= in ? (1u << r) : 0u;
-            const int64_t off = ((int64_t)(ref0[2] + s2) * n1 + (ref0[1] + s1)) * n0 + xb;
+            const uint32_t off = base + (s1 ? row1 : 0u) + (s2 ? row2 : 0u);  // (wraps harmlessly when !in)
             typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T))));
-            const Pair pr = *(const Pair*)(gb + (in ? off : 0));
+            const Pair pr = *(const Pair*)(gb + (in ? off : 0u));
             st.gv[2 * r] = pr[0];
             st.gv[2 * r + 1] = pr[1];
         }
+        st.edge = st.in != 0xfu || st.xsel != 0;
     };
     auto back = [&](const Stage& st) {  // the point's arithmetic and its stores
+        // nearly every wave holds interior points only: the loaded pairs ARE the eight values; a wave
+        // with a point on the border of the grid (or outside) sorts them out with selects
+        T gi[8];
+        if (__ballot(st.edge) == 0ull) {  // (uniform)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) gi[s] = st.gv[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int r = s >> 1;
+                const T gx = (s & 1) ? (st.xsel == 0 ? st.gv[2 * r + 1] : (st.xsel < 0 ? st.gv[2 * r] : T(0)))
+                                     : (st.xsel == 0 ? st.gv[2 * r] : (st.xsel > 0 ? st.gv[2 * r + 1] : T(0)));
+                gi[s] = ((st.in >> r) & 1u) ? gx : T(0);
+            }
+        }
         T gout[3] = {T(0), T(0), T(0)}, dpw_part = T(0);
         T dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int r = s >> 1;
-            // neighbour s = (s0, row r): lower x-neighbour = pair[0] (xsel 0) or pair[1] (xsel 1), upper
-            // = pair[1] (xsel 0) or pair[0] (xsel -1); the other combinations are outside the grid
-            const T gx = (s & 1) ? (st.xsel == 0 ? st.gv[2 * r + 1] : (st.xsel < 0 ? st.gv[2 * r] : T(0)))
-                                 : (st.xsel == 0 ? st.gv[2 * r] : (st.xsel > 0 ? st.gv[2 * r + 1] : T(0)));
-            const T gi = ((st.in >> r) & 1u) ? gx : T(0);
-            const T dweight = voxel_weight<T, 3>(st.dlo, s, gi);  // raster_pullback.jl:55
-            dow_part += dweight * st.pwi;                         // :57
-            dpw_part += dweight * ps.ow;                          // :58
-            const T factor = gi * ps.ow * st.pwi;                 // :60
+            const T dweight = voxel_weight<T, 3>(st.dlo, s, gi[s]);  // raster_pullback.jl:55
+            dow_part += dweight * st.pwi;                            // :57
+            dpw_part += dweight * ps.ow;                             // :58
+            const T factor = gi[s] * ps.ow * st.pwi;                 // :60
 #pragma unroll
             for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, st.dlo, s);
         }
@@ -1066,11 +1078,13 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
 #pragma unroll
         for (int n = 0; n < 3; ++n) scaled[n] = st.ok ? dcoord[n] * xf.scale[n] : T(0);  // :67
         dpw_part = st.ok ? dpw_part : T(0);
+        // (the per-pose sums have no summation order in common with the reference's serial loop:
+        // explicit FMAs, the library is built with -ffp-contract=off)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) vals[n + j * 3] += scaled[n] * st.pt[j];  // :69
-            vals[9 + n] += scaled[n];                                            // :68
+            for (int j = 0; j < 3; ++j) vals[n + j * 3] = fma_t(scaled[n], st.pt[j], vals[n + j * 3]);  // :69
+            vals[9 + n] += scaled[n];                                                                  // :68
         }
         vals[12] += st.ok ? dow_part : T(0);
 #pragma unroll
@@ -1093,6 +1107,7 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
         }
     };
     if (n_it > 0 && P > 0) {
+        // (two stages used alternately would save the copy below and cost 35 registers: 5 -> 3 waves per SIMD)
         Stage cur, nx;
         const int64_t pa = p_lo + threadIdx.x;
         fetch_point(pa);
@@ -1101,7 +1116,7 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
 #pragma unroll 1
         for (int64_t i = 0; i < n_it; ++i) {
             const int64_t p1 = pa + (i + 1) * kDT;
-            front(p1, nx);            // (beyond the slice: dead, its gathers read cell 0)
+            front(p1, nx);  // (beyond the slice: dead, its gathers read cell 0)
             fetch_point(p1 + kDT);
             back(cur);
             cur = nx;
