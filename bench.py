@@ -125,8 +125,8 @@ def load_traffic_profile(cfg, algo_f, order):
     """HBM bytes per forward call from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in
     separate rocprofv3 passes of this same command and corrected as MI355X_MICROARCH.md
     prescribes); measured offline, committed under profiles/ -- bench.py cannot profile itself."""
-    for name in ("r04_c3_hbm_traffic.json", "r03_c3_hbm_traffic.json", "r02_c3_hbm_traffic.json",
-                 "r01_c3_hbm_traffic.json"):
+    for name in ("r05_c3_hbm_traffic.json", "r04_c3_hbm_traffic.json", "r03_c3_hbm_traffic.json",
+                 "r02_c3_hbm_traffic.json", "r01_c3_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -167,14 +167,18 @@ def cpu_baseline(cfg, np_points, np_R, np_t, np_g, budget_s=20.0):
         return t1 - t0, t2 - t1
 
     n = min(P, 200_000)
-    f, b = run(n)  # calibration (includes the fixed grid fill / grid sum cost)
+    f, b = run(n)  # calibration = the warm-up pass (includes the fixed grid fill / grid sum cost)
     rate = n / max(f + b, 1e-9)
-    n2 = int(min(P, max(n, rate * budget_s)))
-    f, b = run(n2)
+    # best of 3 after one warm-up -- the budget covers the three passes
+    n2 = int(min(P, max(n, rate * budget_s / 3.0)))
+    passes = [run(n2) for _ in range(3)]
+    f, b = min(passes, key=lambda fb: fb[0] + fb[1])
     poses = nb
     res = {
         "value": round(n2 * poses / (f + b) / 1e6, 4), "unit": "M points/s", "cores": threads,
         "kind": "port",
+        "timing": "best of 3 passes after one warm-up pass (BASELINE.md section 4)",
+        "passes_s": [round(x + y, 3) for x, y in passes],
         "sample": f"first {n2} of {P} points x {poses} pose(s), same grid/poses; fwd {f:.2f}s on "
                   f"{threads} threads (atomic scatter)"
                   + (f", bwd {b:.2f}s (threads over pose chunks; a single pose is serial, "
@@ -354,7 +358,9 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
         points = dpr_amd.sort_points(points)[0]
     co = dict(coherent_points=True) if args.coherent else {}
     single_call = not batched  # single-pose signature (rotation is a matrix)
-    R = to(np_R[0] if single_call else np_R)
+    # (the pose does not change between the steps: it is handed over once in the C ABI's memory order,
+    # what a Julia host's Vector{SMatrix} is anyway -- no transpose kernels inside the timed step)
+    R = dpr_amd.column_major_rotation(to(np_R[0] if single_call else np_R))
     t = to(np_t[0] if single_call else np_t)
     gen = torch.Generator(device=device)
     gen.manual_seed(2 + (0 if shard == "points" else rank))
@@ -480,9 +486,10 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
     # the count comes from one timed step (max over ranks), so every rank runs the same number.
     step()  # first call: code objects are loaded lazily
     t_one = timed(1)
-    # COLD figure first: the same K steps as the timed region below, started from idle clocks
-    # (no spin-up in front) -- what rounds 1-2 reported as ms_per_step; kept next to the
-    # spun-up figure so that rounds stay comparable.
+    # NO-SPIN-UP figure first: the same K steps as the timed region below without the ~100 ms of
+    # load in front (only the first call and one probe step precede it, so the clocks are partly
+    # up) -- what rounds 1-2 reported as ms_per_step; kept next to the spun-up figure so that
+    # rounds stay comparable.
     ms_cold = timed(args.steps) / args.steps * 1e3 if not lean else None
     n_spin = max(0, min(2000, int(args.spin_up_ms * 1e-3 / max(t_one, 1e-6)))) if args.spin_up else 0
     if n_spin > 0:
@@ -517,11 +524,11 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
     torch.cuda.synchronize()
     def avg_ms(samples):
         """Median of the event-timed calls (robust against a stray stall -- one 47 ms hiccup in 20
-        calls of 0.08 ms once made the mean 2.4 ms -- without dropping samples).  Returns (median, 0)."""
-        return float(np.median(np.asarray(samples, dtype=np.float64))), 0
+        calls of 0.08 ms once made the mean 2.4 ms -- without dropping samples)."""
+        return float(np.median(np.asarray(samples, dtype=np.float64)))
 
-    ms_fwd, drop_f = avg_ms([e0.elapsed_time(e1) for e0, e1, _ in evs])
-    ms_bwd, drop_b = avg_ms([e1.elapsed_time(e2) for _, e1, e2 in evs])
+    ms_fwd = avg_ms([e0.elapsed_time(e1) for e0, e1, _ in evs])
+    ms_bwd = avg_ms([e1.elapsed_time(e2) for _, e1, e2 in evs])
     a_fwd, a_bwd = algorithmic_bytes(cfg, max(B_local, 1), P_local)
     gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
     roof = {
@@ -563,7 +570,7 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
                 fwd(keep=False)
                 e1.record()
             torch.cuda.synchronize()
-            ms_alone = avg_ms([e0.elapsed_time(e1) for e0, e1 in fevs])[0]
+            ms_alone = avg_ms([e0.elapsed_time(e1) for e0, e1 in fevs])
             roof["forward_stand_alone"] = {"ms": round(ms_alone, 4),
                                            "achieved": round(gbs(a_fwd, ms_alone), 2),
                                            "frac": round(gbs(a_fwd, ms_alone) / HBM_PEAK_GBS, 4)}
@@ -580,7 +587,9 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "timing": f"median of {len(loops)} loop(s) of {args.steps} steps, each between barrier + synchronize",
         "ms_per_step_loops": [round(x / args.steps * 1e3, 4) for x in loops],
-        **({"ms_per_step_cold": round(ms_cold, 4)} if ms_cold is not None else {}),
+        **({"ms_per_step_cold": round(ms_cold, 4),
+            "ms_per_step_cold_is": "the same K steps timed before the clock spin-up (after the first call "
+                                   "and one probe step only): 'no spin-up', not 'from idle'"} if ms_cold is not None else {}),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dt,
         "data": "synthetic",
         "config": {
@@ -598,6 +607,10 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
             "untimed_before_the_timed_steps": f"first call + 1 probe step"
                 + ("" if lean else f" + {args.steps} steps timed from idle clocks (ms_per_step_cold)")
                 + f" + {n_spin} spin-up steps (~{args.spin_up_ms:.0f} ms of load so that the clocks are up) + {args.warmup} warm-up steps",
+            **({"ranks_seen": int(dist.get_world_size()),
+                "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version())
+                                 if backend == "nccl" else f"({backend}: rehearsal, no RCCL)")}
+               if dist is not None else {}),
             **({"same_job_on_one_gpu": f"python bench.py --config {cfg} --gpus 1"
                                         + (f" --poses {B_global}" if args.poses else "")
                                         + "  (the default --gpus 1 run is the metric's config C3, a different job)"}
@@ -610,6 +623,9 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
             step(False)
         # (a secondary figure: median of 3 loops, like the headline)
         el = float(np.median([timed(args.steps, False) for _ in range(3 if world == 1 else 1)]))
+        line["config"]["drop_in_ms_per_step"] = round(el / args.steps * 1e3, 4)
+        line["config"]["drop_in_is"] = ("the same step through the plain dpr_raster_* / dpr_raster_pullback_* "
+                                        "entry points (no KEEP / REUSE flags): the `no_share` entry")
         line["no_share"] = {"timing": "median of 3 loops" if world == 1 else "one loop",
                             "ms_per_step": round(el / args.steps * 1e3, 4),
                             "value": round(units / (el / args.steps) / 1e6, 3),
@@ -623,20 +639,30 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
         sorted_pts, _perm = dpr_amd.sort_points(points)  # dpr_sort_points_f32
         points_random = points
         points = sorted_pts
-        # the caller of dpr_sort_points may say so: DPR_FLAG_COHERENT_POINTS (local binning)
+        # the caller of dpr_sort_points may say so: DPR_FLAG_COHERENT_POINTS.  DPR_ALGO_AUTO then
+        # decides anew for the pair (on a 3-D grid the pullback of one pose gathers directly in cloud
+        # order and the pair shares nothing; include/dpr.h)
         coherent_kw = dict(coherent_points=True)
-        ws_c = torch.empty(max(16, dpr_amd.workspace_bytes("pullback", grid, P, 1, n_in, tdt, algo_f,
-                                                           coherent_points=True)),
+        if args.algo != "auto":
+            algo_fc = algo_bc = args.algo
+        else:
+            algo_fc, algo_bc = (dpr_amd.resolve_algo(op, grid, P, 1, n_in, sharing=do_bwd, coherent_points=True)
+                                for op in ("raster", "pullback"))
+        share_c = (do_bwd and algo_fc == algo_bc and not args.no_share_binning
+                   and dpr_amd.sharing_effective(grid, P, 1, n_in, coherent_points=True))
+        ws_c = torch.empty(max(16, *(dpr_amd.workspace_bytes(op, grid, P, 1, n_in, tdt, a, coherent_points=True,
+                                                             sharing=share_c)
+                                     for op, a in (("raster", algo_fc), ("pullback", algo_bc)))),
                            dtype=torch.uint8, device=device)
 
         def fwd_c(keep=None):
-            dpr_amd.raster_(out, points, R, t, algo=algo_f, workspace=ws_c,
-                            keep_binning=share if keep is None else keep, **coherent_kw)
+            dpr_amd.raster_(out, points, R, t, algo=algo_fc, workspace=ws_c,
+                            keep_binning=share_c if keep is None else keep, **coherent_kw)
 
         def bwd_c():
             dpr_amd.raster_pullback_(g, points, R, t, ds_dpoints=fused[: P * n_in].view(P, n_in),
-                                     ds_dpoint_weight=fused[P * n_in:], algo=algo_b,
-                                     workspace=ws_c, reuse_binning=share, **coherent_kw)
+                                     ds_dpoint_weight=fused[P * n_in:], algo=algo_bc,
+                                     workspace=ws_c, reuse_binning=share_c, **coherent_kw)
 
         def step_c():
             fwd_c()
@@ -655,18 +681,31 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
             torch.cuda.synchronize()
             els.append((time.perf_counter() - t0) / args.steps)
         el = float(np.median(els))
-        names_c = "tiled_local" if algo_f == "tiled" else algo_f
-        st_fm = dpr_amd.stage_times(fwd_c, "raster", names_c, reps)
+        sname_c = lambda a: "tiled_local" if a == "tiled" else a
+        st_fm = dpr_amd.stage_times(fwd_c, "raster", sname_c(algo_fc), reps)
         coh = {"point_order": "Hilbert-sorted (dpr_sort_points once, not timed) + DPR_FLAG_COHERENT_POINTS",
+               "algo": {"raster": algo_fc, "pullback": algo_bc if do_bwd else None},
+               "pullback_reuses_forward_binning": bool(share_c),
                "timing": f"median of 3 loops of {args.steps} steps",
                "value": round(P / el / 1e6, 3), "unit": "M points/s",
                "ms_per_step": round(el * 1e3, 4), "raster_ms": round(st_fm["total"], 4),
                "raster_frac_of_hbm_peak": round(gbs(a_fwd, st_fm["total"]) / HBM_PEAK_GBS, 4),
                "raster_stages": {k: round(v, 4) for k, v in st_fm.items()}}
+        roof_c = {"bound": "hbm", "kernel": "raster! (all launches of one forward call)",
+                  "achieved": round(gbs(a_fwd, st_fm["total"]), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(gbs(a_fwd, st_fm["total"]) / HBM_PEAK_GBS, 4), "traffic": None,
+                  "algorithmic_bytes": a_fwd, "ms": round(st_fm["total"], 4)}
+        traffic_c = load_traffic_profile(cfg, algo_fc, "hilbert+coherent")
+        if traffic_c:
+            roof_c["traffic"], roof_c["traffic_source"] = traffic_c["bytes"], traffic_c["source"]
         if do_bwd:
-            st_bm = dpr_amd.stage_times(bwd_c, "pullback", "tiled_local" if algo_b == "tiled" else algo_b,
-                                        reps, prepare=fwd_c)
+            st_bm = dpr_amd.stage_times(bwd_c, "pullback", sname_c(algo_bc), reps, prepare=fwd_c)
             coh["pullback_ms"] = round(st_bm["total"], 4)
+            coh["pullback_stages"] = {k: round(v, 4) for k, v in st_bm.items()}
+            roof_c["pullback"] = {"algorithmic_bytes": a_bwd, "ms": round(st_bm["total"], 4),
+                                  "achieved": round(gbs(a_bwd, st_bm["total"]), 2),
+                                  "frac": round(gbs(a_bwd, st_bm["total"]) / HBM_PEAK_GBS, 4)}
+        coh["roofline"] = roof_c
         line["coherent_input"] = coh
         points = points_random
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not lean:

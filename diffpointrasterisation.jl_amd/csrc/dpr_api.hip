@@ -134,6 +134,19 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
     return P * (B >= 16 ? 10 : 25) <= G;
 }
 
+// DPR_ALGO_CHUNKED pullback on 3-D grids: a thread per point in cloud order gathering straight from
+// ds_dout (dpr_owner.hip).  On a cloud the caller vouches is coherent a wave's gathers share cache
+// lines, nothing is binned, staged or un-permuted: 10 M points -> 256^3 0.136 ms against 0.25 ms for
+// the tiled pipeline on the same cloud and 0.17 ms for its binning-reusing half of a KEEP / REUSE
+// pair (profiles/r05_experiments.md) -- so such a pair has nothing to share either.  One pose: the
+// point gradients of a batch accumulate pose by pose through memory there, while the direct kernel
+// of DPR_ALGO_ATOMIC keeps them in registers.
+static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
+                               unsigned flags) {
+    return op == DPR_OP_PULLBACK && n_out == 3 && (flags & DPR_FLAG_COHERENT_POINTS) && B == 1 &&
+           grid[0] >= 2 && P >= 30000 && P < ((int64_t)1 << 32) && owner_supported(grid);
+}
+
 // (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both
 // (/root/reference/src/raster.jl:5-13, src/util.jl:26-27).  The three shapes its tests use --
 // (2,2), (3,3), (3,2) -- have every algorithm; the others ((1,1), (2,1), (3,1)) run on the direct
@@ -189,6 +202,9 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     }
     if (algo != DPR_ALGO_AUTO) return algo;
     const bool coherent = (*flags & DPR_FLAG_COHERENT_POINTS) != 0;
+    // a coherent cloud on a 3-D grid, one pose: the pullback gathers directly and reads nothing a
+    // forward could keep -- the pair has nothing to share, each call picks its own best path
+    if ((*flags & 3u) && direct3d_preferred(DPR_OP_PULLBACK, n_out, grid, P, B, *flags)) *flags &= ~3u;
     if (*flags & 3u) {
         if (chunkown_preferred(-1, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
         // tiled: one pose, or a batch on a grid too large for pose groups (every pose keeps its
@@ -201,8 +217,10 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     }
     // many poses onto a 2-D grid: chunk-owned tiles with the pose loop inside
     if (chunkown_preferred(op, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
-    // forward over several poses of a coherent cloud on a large 3-D grid: chunk lists
+    // forward over several poses of a coherent cloud on a large 3-D grid: owner-computes tiles
     if (chunked3d_preferred(op, n_out, grid, G, P, B, *flags)) return DPR_ALGO_CHUNKED;
+    // pullback of one pose of a coherent cloud on a 3-D grid: direct gathers in cloud order
+    if (direct3d_preferred(op, n_out, grid, P, B, *flags)) return DPR_ALGO_CHUNKED;
     // pullback over many (>= 32) poses of a coherent cloud on a grid without pose groups: the direct
     // kernel (point in registers across the poses, cache-friendly gathers on sorted input) is
     // never more than ~6 % behind the tiled pipeline there and up to 1.9x ahead (clustered cloud,

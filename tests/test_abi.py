@@ -177,6 +177,14 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3, sharing=True) == "chunked"
     # pre-sorted clouds skip the sort: the chunk-owner path pays off from a single pose on
     assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 1, 3, coherent_points=True) == "chunked"
+    # one pose of a coherent cloud on a 3-D grid: the pullback gathers directly in cloud order (3-D
+    # DPR_ALGO_CHUNKED) and reads nothing a forward could keep -- the pair does not share
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 1, 3, coherent_points=True) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 1, 3, coherent_points=True, sharing=True) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 1, 3, coherent_points=True, sharing=True) == "tiled"
+    assert not dpr_amd.sharing_effective((256,) * 3, 10_000_000, 1, 3, coherent_points=True)
+    assert dpr_amd.sharing_effective((256,) * 3, 10_000_000, 1, 3)
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000, 1, 3, coherent_points=True) == "atomic"
     # more than 32768 tiles: the tiled path works in slabs -- the forward from 1e6 points on, the
     # pullback stays with the direct kernel; a tile layer beyond 16384 tiles -> direct kernels
     assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "tiled"

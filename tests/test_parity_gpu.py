@@ -1233,6 +1233,31 @@ def test_tiled_fp32_non_finite_weights_fall_back_to_ieee_sums(oracle, dev, bad, 
         assert_close(out[fin], ref[fin], 5e-5)
 
 
+def test_pre_canonicalised_rotation(oracle, dev):
+    """`column_major_rotation` hands the pose over in the C ABI's memory order once; the calls then
+    skip their transpose kernels.  Same results as the tensor form, single pose and batch, forward
+    and pullback; a snapshot (later writes to the source tensor are not seen)."""
+    d = D.make(n_points=5_000, n_in=3, n_out=3, batch=2, grid_n=16, seed=51, dtype=np.float64)
+    pts = T(d.points, dev)
+    g = grid_to_dev(d.ds_dout, dev)
+    for single in (True, False):
+        R = T(d.rotations[0] if single else d.rotations, dev).clone()
+        t = T(d.translations[0] if single else d.translations, dev)
+        Rc = dpr_amd.column_major_rotation(R)
+        assert Rc.shape == tuple(R.shape) and Rc.ndim == R.ndim
+        a, b = dpr_amd.raster(d.grid, pts, R, t), dpr_amd.raster(d.grid, pts, Rc, t)
+        assert_close(a, b.cpu().numpy(), 1e-13)  # (global atomics: equal up to the summation order)
+        gg = g[..., 0] if single else g
+        pa = dpr_amd.raster_pullback_(gg, pts, R, t, algo="atomic")
+        pb = dpr_amd.raster_pullback_(gg, pts, Rc, t, algo="atomic")
+        assert torch.equal(pa.points, pb.points)
+        assert_close(pa.rotation, pb.rotation.cpu().numpy(), 1e-12)  # (per-pose sums: float atomics)
+        R.mul_(0.5)  # the snapshot keeps the old pose
+        assert_close(dpr_amd.raster(d.grid, pts, Rc, t), a.cpu().numpy(), 1e-13)
+    with pytest.raises(dpr_amd.DimensionMismatch):
+        dpr_amd.raster(d.grid, pts, dpr_amd.column_major_rotation(T(d.rotations[0, :2], dev)), T(d.translations[0], dev))
+
+
 def test_autograd_rule_with_mixed_dtypes_and_strided_views(dev):
     """raster_ad keeps the forward's binning for its backward pass; the device-side check of that
     pairing compares buffer addresses, so the rule must hand the SAME canonical tensors to both
