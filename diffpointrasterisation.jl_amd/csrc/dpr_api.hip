@@ -123,12 +123,17 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
 // 50 M -> 512^3 fp64 share of config C5, where the lists measured 13.5 vs 16.7 ms on the Gaussian
 // cloud.  Not for a KEEP/REUSE pair (the tiled pair with a shared binning wins the step) and not
 // for the pullback (per-pose gather with read-modify-write of the point gradients).
+// which forward the 3-D algorithm runs: chunk lists (small tiles) for a sparse cloud over several
+// poses, owner-computes large tiles otherwise
+static bool chunked3d_lists(const int64_t* grid, int64_t G, int64_t P, int64_t B) {
+    return B >= 4 && P * 10 <= G && chunked_supported(3, grid);
+}
 static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t G, int64_t P,
                                 int64_t B, unsigned flags) {
     if (op != DPR_OP_RASTER || n_out != 3 || (flags & 3u) || !(flags & DPR_FLAG_COHERENT_POINTS))
         return false;
     if (B < 4 || P < 30000 || P >= ((int64_t)1 << 32)) return false;
-    if (!owner_supported(grid)) return false;
+    if (!owner_supported(grid) || !chunked_supported(n_out, grid)) return false;
     // (fewer than 16 poses: only the very sparse cloud -- on a clustered one the lists lose 2x at
     // one point per 17-21 voxels and 4 poses, where they win 1.3x on a Gaussian or uniform cloud)
     return P * (B >= 16 ? 10 : 25) <= G;
@@ -136,15 +141,20 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
 
 // DPR_ALGO_CHUNKED pullback on 3-D grids: a thread per point in cloud order gathering straight from
 // ds_dout (dpr_owner.hip).  On a cloud the caller vouches is coherent a wave's gathers share cache
-// lines, nothing is binned, staged or un-permuted: 10 M points -> 256^3 0.136 ms against 0.25 ms for
-// the tiled pipeline on the same cloud and 0.17 ms for its binning-reusing half of a KEEP / REUSE
-// pair (profiles/r05_experiments.md) -- so such a pair has nothing to share either.  One pose: the
-// point gradients of a batch accumulate pose by pose through memory there, while the direct kernel
-// of DPR_ALGO_ATOMIC keeps them in registers.
+// lines, nothing is binned, staged or un-permuted: 10 M points -> 256^3 0.136 ms (Gaussian; 0.11
+// uniform and clustered clouds) against 0.24-0.28 ms for the tiled pipeline on the same clouds and
+// 0.17 ms for its binning-reusing half of a KEEP / REUSE pair (profiles/r05_experiments.md) -- so
+// such a pair has nothing to share either.  Batches run pose by pose (the point gradients accumulate
+// through memory): ahead of the tiled path and of the direct kernel of DPR_ALGO_ATOMIC from 1e6
+// points on up to ~32 poses (1e7 x 16 -> 256^3: 2.9 vs 4.4 / 8.2 ms; 1e6 x 16: 0.85 vs 1.11 / 1.12);
+// from 32 poses on the ATOMIC kernel's registers across the poses win (1e6 x 64: 2.9 vs 3.4), and a
+// small cloud pays per pose for the grid sum and two launches (3e5 x 16 -> 128^3: 0.45 vs 0.28 tiled).
 static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P, int64_t B,
                                unsigned flags) {
-    return op == DPR_OP_PULLBACK && n_out == 3 && (flags & DPR_FLAG_COHERENT_POINTS) && B == 1 &&
-           grid[0] >= 2 && P >= 30000 && P < ((int64_t)1 << 32) && owner_supported(grid);
+    if (op != DPR_OP_PULLBACK || n_out != 3 || !(flags & DPR_FLAG_COHERENT_POINTS) || grid[0] < 2 ||
+        P >= ((int64_t)1 << 32) || !owner_supported(grid))
+        return false;
+    return (B == 1 && P >= 30000) || (B >= 2 && B < 32 && P >= 1000000);
 }
 
 // (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both
@@ -311,6 +321,9 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
             if constexpr (NO == 2)                                                             \
                 return raster_chunkown<T, NI>(st, flags, grid, G, P, B, out, points, rot, trans, \
                                               bg, ow, pw, ws, ws_bytes);                       \
+            else if (chunked3d_lists(grid, G, P, B))                                           \
+                return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot,   \
+                                                 trans, bg, ow, pw, ws, ws_bytes);             \
             else                                                                               \
                 return raster_owner<T>(st, flags, grid, G, P, B, out, points, rot, trans, bg,  \
                                        ow, pw, ws, ws_bytes);                                  \
@@ -490,7 +503,8 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
             if (n == (size_t)-1) fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: P must be < 2^32");
             return n;
         }
-        const size_t n = owner_workspace_bytes(op, grid, P, B);
+        size_t n = owner_workspace_bytes(op, grid, P, B);
+        if (op == DPR_OP_RASTER && chunked3d_lists(grid, G, P, B)) n = chunked_workspace_bytes(n_out, grid, P, B);
         if (n == (size_t)-1)
             fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs too many tiles or P >= 2^32");
         return n;

@@ -1,9 +1,13 @@
-// DPR_ALGO_CHUNKED: owner-computes voxel tiles fed by CHUNK LISTS instead of binned records.
+// DPR_ALGO_CHUNKED on 3-D grids, forward over SEVERAL POSES of a cloud that is SPARSE on the grid:
+// small owner-computes voxel tiles (32 x 16 x 8 cells, 32 KB of LDS: four workgroups per CU) fed by
+// CHUNK LISTS.  The other regimes of the 3-D algorithm are in dpr_owner.hip (large LDS tiles over a
+// box hierarchy for clouds that fill the grid; the direct pullback); this kernel family stays for
+// the regime where a tile holds a few hundred points and an item's fixed cost decides: 1e5 points x
+// 64 poses -> 128^3 runs 0.45 ms here against 1.0 ms for the large tiles and for the tiled path
+// (profiles/r03_auto_regret.txt coherent section, profiles/r05_experiments.md).
 //
-// For spatially coherent point order (e.g. Morton-sorted in the model frame -- pose
-// independent, so the sort is amortised over poses and iterations) 64 consecutive points
-// touch only a handful of tiles of the output grid.  Instead of permuting the points per pose
-// (DPR_ALGO_TILED), only the chunk ids are binned:
+// For spatially coherent point order 64 consecutive points touch only a handful of tiles.  Only
+// the chunk ids are binned:
 //
 //   sets         k_chunk_sets    per (chunk, pose): the exact set of tiles its points touch
 //                                (wave-level union, chunk = one wave); per-tile counters
@@ -14,16 +18,9 @@
 //                                ONLY the contributions that land in voxels the tile owns in
 //                                an LDS tile of f64 accumulators; out = background + acc with
 //                                plain stores.  No halo exchange, no global atomics.
-//   pullback     k_chunk_gather  block per tile: ds_dout tile (+1 halo) in LDS; handles the
-//                                points whose primary tile it is; stores ds_dpoints in place
-//                                (original order == coherent order -> mergeable writes)
-//   divert       k_chunk_divert_* chunks touching more than 16 tiles (incoherent input) go
-//                                through direct global atomics / gathers; always correct,
-//                                slow only for input that should not use this algorithm.
-//
-// Points are read (1 + tiles-per-chunk) times, but the point array of the headline configs
-// (120 MB) lives in the 256 MiB Infinity Cache, and nothing per-point is ever written in the
-// forward pass.
+//   divert       k_chunk_divert_fwd chunks touching more than 16 tiles (incoherent input) go
+//                                through direct global atomics; always correct, slow only for
+//                                input that should not use this algorithm.
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -360,280 +357,12 @@ __global__ __launch_bounds__(256) void k_chunk_divert_fwd(
     }
 }
 
-// ------------------------------------------------------------------ pullback
-template <typename T, int NI, int NO, bool HAS_PW, bool FIRST_POSE>
-__global__ __launch_bounds__(kCThreads) void k_chunk_gather(
-    GridDesc<NO> gd, CGeom<NO> tg, int64_t P, const T* __restrict__ points,
-    const T* __restrict__ pw, const T* __restrict__ g, const T* __restrict__ rot,
-    const T* __restrict__ trans, const T* __restrict__ ow, int64_t b, int64_t bl,
-    const uint32_t* __restrict__ list_start, const uint32_t* __restrict__ tile_order,
-    const uint32_t* __restrict__ list, int64_t cap, T* __restrict__ ds_dpoints,
-    T* __restrict__ ds_dpw, double* __restrict__ partials) {
-    constexpr int NVH = ctile_voxels_halo<NO>();
-    constexpr int NVAL = NO * NI + NO + 2;
-    constexpr int NW = kCThreads / kWave;
-    __shared__ T tile_g[NVH];
-    __shared__ double red[NW][NVAL];
-    const int tile = (int)tile_order[bl * tg.NT + blockIdx.x];
-    int x0[NO], tc[NO];
-    ctile_origin<NO>(tile, tg, x0, tc);
-    const T* gb = g + b * gd.G;
-    double bg_sum = 0.0;
-    {
-        constexpr int IT = (NVH + kCThreads - 1) / kCThreads;
-        T v[IT];
-        bool own[IT];
-#pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int i = threadIdx.x + k * kCThreads;
-            int rem = i, off = 0, stride = 1;
-            bool ok = i < NVH, owned = true;
-#pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                const int l = rem % (CTile<NO>::T[d] + 1);
-                rem /= CTile<NO>::T[d] + 1;
-                const int gcoord = x0[d] + l;
-                ok = ok && gcoord < gd.n[d];
-                owned = owned && l < CTile<NO>::T[d];
-                off += gcoord * stride;
-                stride *= gd.n[d];
-            }
-            const T x = gb[ok ? off : 0];
-            v[k] = ok ? x : T(0);
-            own[k] = owned && ok;
-        }
-#pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            const int i = threadIdx.x + k * kCThreads;
-            if (i < NVH) tile_g[i] = v[k];
-            if (own[k]) bg_sum += (double)v[k];
-        }
-    }
-    __syncthreads();
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
-    T vals[NVAL - 1];
-#pragma unroll
-    for (int k = 0; k < NVAL - 1; ++k) vals[k] = T(0);
-    const uint32_t* start = list_start + bl * (tg.NT + 1);
-    const uint32_t l0 = start[tile], l1 = start[tile + 1];
-    const uint32_t* lst = list + bl * cap;
-    const int sub = threadIdx.x / kChunk, lane_in_chunk = threadIdx.x % kChunk;
-    for (uint32_t i = l0 + sub; i < l1; i += kCThreads / kChunk) {
-        const int64_t p = (int64_t)lst[i] * kChunk + lane_in_chunk;
-        if (p >= P) continue;
-        T pt[NI];
-        load_point<T, NI>(points, p, pt);
-        int ref0[NO];
-        T dlo[NO];
-        const bool valid = ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
-        // every point belongs to exactly one tile: the one holding max(ref0, 0); points
-        // without an in-range voxel are cleared by the first tile of their chunk's box
-        bool mine = true;
-        int lb[NO];
-#pragma unroll
-        for (int d = 0; d < NO; ++d) {
-            const int r = ref0[d] < 0 ? 0 : ref0[d];
-            mine = mine && (r / CTile<NO>::T[d] == tc[d]);
-            lb[d] = ref0[d] - x0[d];
-        }
-        if (!valid) {
-            continue;  // cleared by k_chunk_divert_bwd (state-independent pass over all chunks)
-        }
-        if (!mine) continue;
-        const T pwi = HAS_PW ? pw[p] : T(1);
-        T gv[1 << NO];
-#pragma unroll
-        for (int s = 0; s < (1 << NO); ++s) {
-            int idx = 0, stride = 1;
-            bool ok = true;
-#pragma unroll
-            for (int d = 0; d < NO; ++d) {
-                const int sd = (s >> d) & 1;
-                const bool low_ok = lb[d] >= 0;
-                ok = ok && (sd || low_ok);
-                idx += ((sd || low_ok) ? lb[d] + sd : 0) * stride;
-                stride *= CTile<NO>::T[d] + 1;
-            }
-            const T gi = tile_g[idx];
-            gv[s] = ok ? gi : T(0);  // cells beyond the grid were staged as 0
-        }
-        T scaled[NO], dow_part = T(0), dpw_part = T(0);
-        {
-            T dcoord[NO];
-#pragma unroll
-            for (int n = 0; n < NO; ++n) dcoord[n] = T(0);
-#pragma unroll
-            for (int s = 0; s < (1 << NO); ++s) {
-                const T gi = gv[s];
-                const T dweight = voxel_weight<T, NO>(dlo, s, gi);  // raster_pullback.jl:55
-                dow_part += dweight * pwi;                          // :57
-                dpw_part += dweight * ps.ow;                        // :58
-                const T factor = gi * ps.ow * pwi;                  // :60
-#pragma unroll
-                for (int n = 0; n < NO; ++n) dcoord[n] += factor * interp_weight<T, NO>(n, dlo, s);
-            }
-#pragma unroll
-            for (int n = 0; n < NO; ++n) scaled[n] = dcoord[n] * (T(gd.n[n]) / T(2));  // :67
-        }
-#pragma unroll
-        for (int n = 0; n < NO; ++n) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) vals[n + j * NO] += scaled[n] * pt[j];  // :69
-            vals[NO * NI + n] += scaled[n];                                     // :68
-        }
-        vals[NO * NI + NO] += dow_part;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {  // rotation' * scaled (:70)
-            T v = ps.R[0 + j * NO] * scaled[0];
-#pragma unroll
-            for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
-            if (FIRST_POSE)
-                ds_dpoints[p * NI + j] = v;
-            else
-                ds_dpoints[p * NI + j] += v;
-        }
-        if (FIRST_POSE)
-            ds_dpw[p] = dpw_part;
-        else
-            ds_dpw[p] += dpw_part;
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < NVAL; ++k) {
-        const double v = (k < NVAL - 1) ? (double)vals[k < NVAL - 1 ? k : 0] : bg_sum;
-        const double s = wave_sum<double>(v);
-        if (lane == 0) red[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NVAL) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
-        partials[(size_t)threadIdx.x * tg.NT + tile] = s;
-    }
-}
-
-template <typename T, int NI, int NO>
-__global__ __launch_bounds__(1024) void k_cpose_reduce(const double* __restrict__ partials, int NT,
-                                                       int64_t b, T* __restrict__ ds_drotation,
-                                                       T* __restrict__ ds_dtranslation,
-                                                       T* __restrict__ ds_dbackground,
-                                                       T* __restrict__ ds_dout_weight) {
-    __shared__ double wsum[16];
-    const int k = blockIdx.x;
-    double s = 0.0;
-    for (int t = threadIdx.x; t < NT; t += 1024) s += partials[(size_t)k * NT + t];
-    s = wave_sum<double>(s);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) tot += wsum[w];
-        if (k < NO * NI)
-            ds_drotation[b * (NO * NI) + k] = (T)tot;
-        else if (k < NO * NI + NO)
-            ds_dtranslation[b * NO + (k - NO * NI)] = (T)tot;
-        else if (k == NO * NI + NO)
-            ds_dout_weight[b] = (T)tot;
-        else
-            ds_dbackground[b] = (T)tot;
-    }
-}
-
-// Pass over ALL chunks after the tile kernel of pose b:
-//   * points without an in-range voxel get their (first-pose) zero gradient here
-//   * diverted chunks (state 2) are processed with direct gathers; their per-pose sums are
-//     added atomically on top of what k_cpose_reduce stored.
-template <typename T, int NI, int NO, bool FIRST_POSE>
-__global__ __launch_bounds__(256) void k_chunk_divert_bwd(
-    GridDesc<NO> gd, int64_t P, int64_t n_chunks, const T* __restrict__ points,
-    const T* __restrict__ pw, const T* __restrict__ g, const T* __restrict__ rot,
-    const T* __restrict__ trans, const T* __restrict__ ow, int64_t b, int64_t bl,
-    const uint8_t* __restrict__ nset, T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
-    T* __restrict__ ds_drotation, T* __restrict__ ds_dtranslation,
-    T* __restrict__ ds_dout_weight) {
-    constexpr int NV = NO * NI + NO + 1;
-    constexpr int NW = 256 / kWave;
-    __shared__ T red[NW][NV];
-    const int64_t c = (int64_t)blockIdx.x * NW + threadIdx.x / kWave;
-    const int state = c < n_chunks ? nset[bl * n_chunks + c] : 0;
-    const int64_t p = c * kChunk + (threadIdx.x & (kWave - 1));
-    const bool live = c < n_chunks && p < P;
-    const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b);
-    T pt[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) pt[j] = T(0);
-    if (live) load_point<T, NI>(points, p, pt);
-    int ref0[NO];
-    T dlo[NO];
-    const bool valid = live && ref_and_deltas<T, NI, NO>(pt, ps, gd, ref0, dlo);
-    if (live && !valid && FIRST_POSE) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-        ds_dpw[p] = T(0);
-    }
-    if (__syncthreads_or(state == kDiverted) == 0) return;  // no diverted chunk in this block
-    T vals[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) vals[k] = T(0);
-    if (valid && state == kDiverted) {
-        const T pwi = pw ? pw[p] : T(1);
-        const T* gb = g + b * gd.G;
-        T scaled[NO], dow_part, dpw_part;
-        point_backward<T, NI, NO>(ref0, dlo, gd, ps.ow, pwi, [&](int off) { return gb[off]; },
-                                  scaled, dow_part, dpw_part);
-#pragma unroll
-        for (int n = 0; n < NO; ++n) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) vals[n + j * NO] = scaled[n] * pt[j];
-            vals[NO * NI + n] = scaled[n];
-        }
-        vals[NO * NI + NO] = dow_part;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            T v = ps.R[0 + j * NO] * scaled[0];
-#pragma unroll
-            for (int n = 1; n < NO; ++n) v = v + ps.R[n + j * NO] * scaled[n];
-            if (FIRST_POSE)
-                ds_dpoints[p * NI + j] = v;
-            else
-                ds_dpoints[p * NI + j] += v;
-        }
-        if (FIRST_POSE)
-            ds_dpw[p] = dpw_part;
-        else
-            ds_dpw[p] += dpw_part;
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const T s = wave_sum<T>(vals[k]);
-        if (lane == 0) red[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        T s = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) s += red[w][threadIdx.x];
-        const int k = threadIdx.x;
-        if (s != T(0)) {
-            if (k < NO * NI)
-                atomic_add<T>(ds_drotation + b * (NO * NI) + k, s);
-            else if (k < NO * NI + NO)
-                atomic_add<T>(ds_dtranslation + b * NO + (k - NO * NI), s);
-            else
-                atomic_add<T>(ds_dout_weight + b, s);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ host side
 static size_t calign(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct CPlan {
     int64_t n_chunks, cap, Bw;  // Bw = poses held in the workspace at once
-    size_t off_sets, off_nset, off_count, off_start, off_order, off_list, off_partials, total;
+    size_t off_sets, off_nset, off_count, off_start, off_order, off_list, total;
 };
 
 static CPlan make_cplan(int NT, int64_t P, int64_t B) {
@@ -657,8 +386,6 @@ static CPlan make_cplan(int NT, int64_t P, int64_t B) {
     o += calign((size_t)pl.Bw * NT * 4);
     pl.off_list = o;
     o += calign((size_t)pl.Bw * pl.cap * 4);
-    pl.off_partials = o;
-    o += calign((size_t)NT * 16 * 8);
     pl.total = o;
     return pl;
 }
@@ -733,9 +460,7 @@ int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     if (!make_cgeom<NO>(grid, &tg))
         return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles",
                     kCMaxTiles);
-    if ((flags & DPR_FLAG_KEEP_BINNING) && B != 1)
-        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_KEEP_BINNING needs B == 1 (got %lld)",
-                    (long long)B);
+    (void)flags;  // (DPR_FLAG_KEEP_BINNING: the 3-D pullback reads nothing a forward could leave)
     const CPlan pl = make_cplan(tg.NT, P, B);
     if (!ws_ || ws_bytes < pl.total)
         return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED raster needs %zu workspace bytes, got %zu",
@@ -766,87 +491,10 @@ int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     return DPR_OK;
 }
 
-template <typename T, int NI, int NO>
-int pullback_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
-                     int64_t B, const T* g, const T* points, const T* rot, const T* trans,
-                     const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
-                     T* d_pw, void* ws_, size_t ws_bytes) {
-    CGeom<NO> tg;
-    if (!make_cgeom<NO>(grid, &tg))
-        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs more than %d tiles",
-                    kCMaxTiles);
-    const bool reuse = flags & DPR_FLAG_REUSE_BINNING;
-    if (reuse && B != 1)
-        return fail(DPR_ERR_INVALID_ARG, "DPR_FLAG_REUSE_BINNING needs B == 1 (got %lld)",
-                    (long long)B);
-    const CPlan pl = make_cplan(tg.NT, P, B);
-    if (!ws_ || ws_bytes < pl.total)
-        return fail(DPR_ERR_WORKSPACE,
-                    "DPR_ALGO_CHUNKED pullback needs %zu workspace bytes, got %zu", pl.total,
-                    ws_ ? ws_bytes : (size_t)0);
-    char* ws = (char*)ws_;
-    const GridDesc<NO> gd = cgrid_desc<NO>(grid, G);
-    double* partials = (double*)(ws + pl.off_partials);
-    constexpr int NVAL = NO * NI + NO + 2;
-    for (int64_t b0 = 0; b0 < B; b0 += pl.Bw) {
-        const int64_t nb = (B - b0 < pl.Bw) ? B - b0 : pl.Bw;
-        if (reuse) {
-            stage_mark(st);
-            stage_mark(st);
-        } else if (int rc = build_lists<T, NI, NO>(st, gd, tg, pl, ws, P, points, rot, trans, b0,
-                                                   nb))
-            return rc;
-        // the point gradients accumulate over poses: one pose per launch
-        for (int64_t bl = 0; bl < nb; ++bl) {
-            const int64_t b = b0 + bl;
-#define DPR_GATHER(HAS_PW, FIRST)                                                                 \
-    hipLaunchKernelGGL((k_chunk_gather<T, NI, NO, HAS_PW, FIRST>), dim3((unsigned)tg.NT),         \
-                       dim3(kCThreads), 0, st, gd, tg, P, points, pw, g, rot, trans, ow, b, bl,   \
-                       (const uint32_t*)(ws + pl.off_start), (const uint32_t*)(ws + pl.off_order), \
-                       (const uint32_t*)(ws + pl.off_list), pl.cap, d_pts, d_pw, partials)
-            if (pw) {
-                if (b == 0) DPR_GATHER(true, true);
-                else DPR_GATHER(true, false);
-            } else {
-                if (b == 0) DPR_GATHER(false, true);
-                else DPR_GATHER(false, false);
-            }
-#undef DPR_GATHER
-            stage_mark(st);
-            hipLaunchKernelGGL((k_cpose_reduce<T, NI, NO>), dim3(NVAL), dim3(1024), 0, st,
-                               (const double*)partials, tg.NT, b, d_rot, d_trans, d_bg, d_ow);
-            stage_mark(st);
-            if (b == 0)
-                hipLaunchKernelGGL((k_chunk_divert_bwd<T, NI, NO, true>),
-                                   dim3((unsigned)((pl.n_chunks + 3) / 4)), dim3(256), 0, st, gd,
-                                   P, pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
-                                   (const uint8_t*)(ws + pl.off_nset), d_pts, d_pw, d_rot,
-                                   d_trans, d_ow);
-            else
-                hipLaunchKernelGGL((k_chunk_divert_bwd<T, NI, NO, false>),
-                                   dim3((unsigned)((pl.n_chunks + 3) / 4)), dim3(256), 0, st, gd,
-                                   P, pl.n_chunks, points, pw, g, rot, trans, ow, b, bl,
-                                   (const uint8_t*)(ws + pl.off_nset), d_pts, d_pw, d_rot,
-                                   d_trans, d_ow);
-            stage_mark(st);
-        }
-    }
-    DPR_HIP(hipGetLastError());
-    return DPR_OK;
-}
-
-#define DPR_INST(T, NI, NO)                                                                        \
-    template int raster_chunked<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, \
-                                           int64_t, T*, const T*, const T*, const T*, const T*,    \
-                                           const T*, const T*, void*, size_t);                     \
-    template int pullback_chunked<T, NI, NO>(hipStream_t, unsigned, const int64_t*, int64_t,       \
-                                             int64_t, int64_t, const T*, const T*, const T*,       \
-                                             const T*, const T*, const T*, T*, T*, T*, T*, T*,     \
-                                             T*, void*, size_t);
-DPR_INST(float, 2, 2)
-DPR_INST(float, 3, 3)
-DPR_INST(float, 3, 2)
-DPR_INST(double, 2, 2)
-DPR_INST(double, 3, 3)
-DPR_INST(double, 3, 2)
+template int raster_chunked<float, 3, 3>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, int64_t, float*,
+                                         const float*, const float*, const float*, const float*,
+                                         const float*, const float*, void*, size_t);
+template int raster_chunked<double, 3, 3>(hipStream_t, unsigned, const int64_t*, int64_t, int64_t, int64_t,
+                                          double*, const double*, const double*, const double*,
+                                          const double*, const double*, const double*, void*, size_t);
 }  // namespace dpr

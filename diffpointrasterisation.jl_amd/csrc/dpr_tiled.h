@@ -45,7 +45,15 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
                       const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
                       T* d_pw, void* ws, size_t ws_bytes, Residual<T> rs);
 
-// DPR_ALGO_CHUNKED on 3-D grids: owner-computes tiles over a box hierarchy (dpr_owner.hip)
+// DPR_ALGO_CHUNKED on 3-D grids, sparse clouds over several poses: chunk lists (dpr_chunked.hip)
+bool chunked_supported(int n_out, const int64_t* grid);
+size_t chunked_workspace_bytes(int n_out, const int64_t* grid, int64_t P, int64_t B);
+template <typename T, int NI, int NO>
+int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                   int64_t B, T* out, const T* points, const T* rot, const T* trans, const T* bg,
+                   const T* ow, const T* pw, void* ws, size_t ws_bytes);
+
+// DPR_ALGO_CHUNKED on 3-D grids: owner-computes tiles over a box hierarchy, direct pullback (dpr_owner.hip)
 bool owner_supported(const int64_t* grid);
 size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B);
 

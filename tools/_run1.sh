@@ -1,13 +1,11 @@
 set -e
-python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "pre_canon or mixed_dtypes or slabs or 1024 or 2d_grid" > gpurun_out/tall.log 2>&1 || (tail -40 gpurun_out/tall.log; exit 1)
-tail -3 gpurun_out/tall.log
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err || (tail -20 gpurun_out/bench_default.err; exit 1)
-python3 - <<'PY'
+for cfg in "1000000 256 16" "1000000 256 64" "10000000 256 4" "10000000 256 16" "3000000 256 8" "300000 128 16"; do
+  set -- $cfg
+  PROBE_ATOMIC=1 python tools/own_probe.py --P $1 --grid $2 --poses $3 --bwd --reps 3 > gpurun_out/p9.log 2>&1 || (tail -30 gpurun_out/p9.log; exit 1)
+  python3 - <<PY
 import json
-d=json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('value','ms_per_step','ms_per_step_loops')})
-print(d['roofline']['ms'], d['roofline']['frac'], d['roofline'].get('pullback'))
-print(d['coherent_input'])
-print(d['no_share'], d['config'].get('drop_in_ms_per_step'))
-print(d['cpu_baseline'])
+t=open('gpurun_out/p9.log').read()
+d=json.loads(t[t.index('{'):t.rindex('}')+1])
+print("$cfg", 'bwd: chunked', round(d['chunked']['bwd_ms'],4), 'tiled', round(d['tiled']['bwd_ms'],4), 'atomic', round(d['atomic']['bwd_ms'],4))
 PY
+done
