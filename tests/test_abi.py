@@ -156,7 +156,8 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3) == "tiled"
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "tiled"
-    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 500_000, 16, 3, coherent_points=True) == "atomic"
     # (batches of a coherent cloud, 1e6 points and more, fewer than 32 poses: the direct 3-D pullback, pose by pose)
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 4, 3, coherent_points=True) == "chunked"
