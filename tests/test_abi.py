@@ -161,7 +161,7 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     # (batches of a coherent cloud, 1e6 points and more, fewer than 32 poses: the direct 3-D pullback, pose by pose)
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 4, 3, coherent_points=True) == "chunked"
-    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 500_000, 4, 3, coherent_points=True) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 700_000, 4, 3, coherent_points=True) == "tiled"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 64, 3, coherent_points=True) == "atomic"
     assert dpr_amd.resolve_algo("pullback", (512, 512), 20_000, 64, 3) == "atomic"
     # many poses onto a 2-D grid: chunk-owned LDS tiles with the pose loop inside
