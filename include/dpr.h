@@ -91,12 +91,21 @@ extern "C" {
                               LDS-staged ds_dout, gradients in registers across poses, no
                               atomics.  The points are Hilbert-sorted into the workspace first
                               unless DPR_FLAG_COHERENT_POINTS says they already are.
-                              3-D grids: chunks of 64 points are listed per voxel tile, tiles
-                              read the points in place, all poses in one launch (what AUTO
-                              picks for a FORWARD call without KEEP / REUSE flags over >= 4
-                              poses of a cloud flagged DPR_FLAG_COHERENT_POINTS that is SPARSE
-                              on the grid: P >= 30000 and P * 10 <= G from 16 poses on,
-                              P * 25 <= G for 4..15 poses; G = voxels per pose).
+                              3-D grids: three kernel families behind one name.  FORWARD:
+                              voxel tiles of 32 x 32 x 14 cells that own their cells outright
+                              (no halo exchange, no global atomics, exact 64-bit fixed-point sums
+                              for fp32 data) and find their points through a hierarchy of
+                              grid-frame boxes over groups of 16 / 1024 / 65536 consecutive
+                              points, built per call by one pass over the cloud -- no per-point
+                              record is written; a cloud that is SPARSE on the grid (P * 10 <= G)
+                              over >= 4 poses runs small 32 x 16 x 8 tiles fed by per-tile lists
+                              of 64-point chunks instead.  PULLBACK: a thread per point in cloud
+                              order gathers its eight ds_dout cells straight from memory (no
+                              workspace beyond 7 MB of partial sums); batches pose by pose.
+                              What AUTO picks with DPR_FLAG_COHERENT_POINTS: the forward for
+                              >= 4 poses of a sparse cloud (P >= 30000, P * 10 <= G from 16 poses
+                              on, P * 25 <= G for 4..15 poses), the pullback for one pose from
+                              30000 points on and for 2..31 poses from 1e6 points on.
                               Correct for any point order; fast only for coherent input. */
 
 /* SUMMATION ORDER.  The reference promises none for its float atomics (src/raster.jl:64) and sums
@@ -118,9 +127,14 @@ extern "C" {
  *                        at 1e-16 relative
  *   DPR_ALGO_CHUNKED     2-D: exact fixed-point sums per chunk   registers across the poses, fixed      2-D: the 4096 terms of a (chunk, pose) as a
  *                        (fp32), then float atomics into the     order: bit-reproducible for a given    fixed tree in T (fp32 data; fp64: f64 across
- *                        image across chunks: run to run,        point order (2-D); 3-D lists: read-    threads), the partials per (chunk, pose) in f64
- *                        rounding level.  3-D lists: f64 LDS     modify-write per pose in index order   in a fixed order: bit-reproducible for a given
- *                        atomics + diverted global atomics                                              point order
+ *                        image across chunks: run to run,        point order (2-D); 3-D: one thread     threads), the partials per (chunk, pose) in f64
+ *                        rounding level.  3-D owner tiles:       per point, poses added in index        in a fixed order.  3-D: per-thread sums in T over
+ *                        fp32 EXACT (64-bit fixed point, split   order through memory: bit-             a fixed slice of the cloud, f64 across threads
+ *                        tiles summed as integers) -- the same   reproducible                           and blocks in a fixed order: bit-reproducible
+ *                        bits for any point order; fp64: f64                                            for a given point order
+ *                        LDS atomics, rounding level.  3-D
+ *                        chunk lists (sparse clouds): f64 LDS
+ *                        atomics + diverted global atomics
  *
  * "Rounding level" = the differences any two summation orders of the same terms show in the
  * accumulation type; no output depends on the order beyond that.  The contributions themselves
@@ -130,8 +144,8 @@ extern "C" {
 /* flags (the *_ex entry points).  DPR_ALGO_TILED: any B -- with B > 1 every pose keeps its own
  * binning (the per-pose part of the workspace is laid out B times; pose groups are off);
  * DPR_ALGO_CHUNKED on 2-D grids: any B (what is kept there is the sorted copy of the cloud and its
- * permutation); 3-D DPR_ALGO_CHUNKED: B == 1 only (the chunk lists); DPR_ALGO_ATOMIC has nothing to
- * keep (error):
+ * permutation); 3-D DPR_ALGO_CHUNKED: accepted and ignored (its pullback reads nothing a forward
+ * could leave); DPR_ALGO_ATOMIC has nothing to keep (error):
  * KEEP_BINNING  (raster)   leave the per-tile binning of the points (incl. original
  *                          indices) in the workspace for the pullback of the same call pair
  * REUSE_BINNING (pullback) the workspace still holds the binning written by the preceding
@@ -340,8 +354,9 @@ int dpr_raster_residual_pullback_ex_f64(void *stream, int algo, unsigned flags, 
                                         void *workspace, size_t workspace_bytes);
 
 /* Pose-independent spatial pre-sort of the model-frame points along a Hilbert curve (any run
- * of consecutive sorted points is a compact blob) -- not in the reference; every algorithm here
- * is faster on coherent input and the sort only depends on the points.  points_sorted[i] = points[perm[i]] (and point weights likewise; pass NULL for
+ * of consecutive sorted points is a compact blob; 3-D: 30-bit keys, 1024^3 cells over [-1, 1)^3) --
+ * not in the reference; every algorithm here is faster on coherent input and the sort only depends
+ * on the points.  points_sorted[i] = points[perm[i]] (and point weights likewise; pass NULL for
  * both weight pointers when unused).  Gradients of the sorted cloud go back with
  * ds_dpoints[perm[i]] = ds_dpoints_sorted[i].  n_in = 2 or 3; P < 2^32. */
 size_t dpr_sort_points_workspace_bytes(int64_t P);

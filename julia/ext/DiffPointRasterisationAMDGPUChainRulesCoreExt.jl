@@ -52,7 +52,8 @@ function ChainRulesCore.rrule(
             DiffPointRasterisation.raster_pullback!(g, points, rotation, translation, optional_args...)
         else
             consumed[] = true
-            raster_pullback_reuse!(g, points, rot_d, tr_d, ow_d, pw_d, ws)
+            # (point_weight defaulted: its tangent is dropped below -- not computed either)
+            raster_pullback_reuse!(g, points, rot_d, tr_d, ow_d, pw_d, ws; want_pw=length(optional_args) >= 3)
         end
         ds_dpoints = reinterpret(reshape, SVector{N_in,T}, pb.points)
         single = (dropdims(pb.rotation; dims=3), vec(pb.translation),
@@ -89,7 +90,7 @@ function ChainRulesCore.rrule(
             DiffPointRasterisation.raster_pullback!(g, points, rotation, translation, optional_args...)
         else
             consumed[] = true
-            raster_pullback_reuse_batch!(g, points, rot_d, tr_d, ow_d, pw_d, ws)
+            raster_pullback_reuse_batch!(g, points, rot_d, tr_d, ow_d, pw_d, ws; want_pw=length(optional_args) >= 3)
         end
         ds_dpoints = reinterpret(reshape, SVector{N_in,T}, pb.points)
         L = N_out * N_in

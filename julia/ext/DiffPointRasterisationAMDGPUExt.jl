@@ -268,6 +268,10 @@ end
 # headline step is exactly this pairing; its `no_share` entry is the generic rrule.
 # Loaded only when ChainRulesCore is (a second weak dependency of this extension).
 const DPR_ALGO_AUTO, DPR_FLAG_KEEP_BINNING, DPR_FLAG_REUSE_BINNING = Cint(0), Cuint(1), Cuint(2)
+# The rrule drops the point_weight tangent whenever that argument was defaulted
+# (/root/reference/ext/DiffPointRasterisationChainRulesCoreExt.jl:23,70): the pullback is then told
+# not to compute or store it (`want_pw = false`: NULL pointer + this flag, include/dpr.h).
+const DPR_FLAG_NO_POINT_WEIGHT_GRAD = Cuint(8)
 
 function raster_keep!(out::ROCArray{T,N_out}, points::ROCVector{<:StaticVector{N_in,T}},
                       rotation, translation, background, out_weight, point_weight, ws) where {T,N_in,N_out}
@@ -289,21 +293,24 @@ function raster_keep!(out::ROCArray{T,N_out}, points::ROCVector{<:StaticVector{N
 end
 
 function raster_pullback_reuse!(ds_dout::ROCArray{T,N_out}, points::ROCVector{<:StaticVector{N_in,T}},
-                                rot, tr, ow, pw, ws) where {T,N_in,N_out}
+                                rot, tr, ow, pw, ws; want_pw::Bool=true) where {T,N_in,N_out}
     P = length(points)
     o_pts = similar(ds_dout, T, (N_in, P))
     o_rot, o_tr = similar(ds_dout, T, (N_out, N_in, 1)), similar(ds_dout, T, (N_out, 1))
-    o_bg, o_ow, o_pw = similar(ds_dout, T, 1), similar(ds_dout, T, 1), similar(ds_dout, T, P)
+    o_bg, o_ow = similar(ds_dout, T, 1), similar(ds_dout, T, 1)
+    o_pw = want_pw ? similar(ds_dout, T, P) : nothing
+    flags = DPR_FLAG_REUSE_BINNING | (want_pw ? Cuint(0) : DPR_FLAG_NO_POINT_WEIGHT_GRAD)
     grid = collect(Int64, size(ds_dout))
     stream = AMDGPU.stream()
     sym = T === Float32 ? :dpr_raster_pullback_ex_f32 : :dpr_raster_pullback_ex_f64
     GC.@preserve ds_dout points rot tr ow pw o_pts o_rot o_tr o_bg o_ow o_pw ws begin
         check(ccall((sym, libdpr), Cint,
             (Ptr{Cvoid}, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
-            stream.stream, DPR_ALGO_AUTO, DPR_FLAG_REUSE_BINNING, N_in, N_out, grid, P, 1,
+            stream.stream, DPR_ALGO_AUTO, flags, N_in, N_out, grid, P, 1,
             devptr(ds_dout, T), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(ow, T),
             devptr(pw, T), devptr(o_pts, T), devptr(o_rot, T), devptr(o_tr, T), devptr(o_bg, T),
-            devptr(o_ow, T), devptr(o_pw, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws)))
+            devptr(o_ow, T), want_pw ? devptr(o_pw, T) : Ptr{T}(C_NULL), Ptr{Cvoid}(UInt(pointer(ws))),
+            length(ws)))
     end
     keep_until_done(stream, rot, tr, ow, pw, ws)
     return (; points=o_pts, rotation=o_rot, translation=o_tr, background=o_bg, out_weight=o_ow,
@@ -334,22 +341,25 @@ function raster_keep_batch!(out::ROCArray{T,N_out_p1}, points::ROCVector{<:Stati
 end
 
 function raster_pullback_reuse_batch!(ds_dout::ROCArray{T,N_out_p1}, points::ROCVector{<:StaticVector{N_in,T}},
-                                      rot, tr, ow, pw, ws) where {T,N_in,N_out_p1}
+                                      rot, tr, ow, pw, ws; want_pw::Bool=true) where {T,N_in,N_out_p1}
     N_out = N_out_p1 - 1
     P, B = length(points), size(ds_dout, N_out_p1)
     o_pts = similar(ds_dout, T, (N_in, P))
     o_rot, o_tr = similar(ds_dout, T, (N_out, N_in, B)), similar(ds_dout, T, (N_out, B))
-    o_bg, o_ow, o_pw = similar(ds_dout, T, B), similar(ds_dout, T, B), similar(ds_dout, T, P)
+    o_bg, o_ow = similar(ds_dout, T, B), similar(ds_dout, T, B)
+    o_pw = want_pw ? similar(ds_dout, T, P) : nothing
+    flags = DPR_FLAG_REUSE_BINNING | (want_pw ? Cuint(0) : DPR_FLAG_NO_POINT_WEIGHT_GRAD)
     grid = collect(Int64, size(ds_dout)[1:N_out])
     stream = AMDGPU.stream()
     sym = T === Float32 ? :dpr_raster_pullback_ex_f32 : :dpr_raster_pullback_ex_f64
     GC.@preserve ds_dout points rot tr ow pw o_pts o_rot o_tr o_bg o_ow o_pw ws begin
         check(ccall((sym, libdpr), Cint,
             (Ptr{Cvoid}, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
-            stream.stream, DPR_ALGO_AUTO, DPR_FLAG_REUSE_BINNING, N_in, N_out, grid, P, B,
+            stream.stream, DPR_ALGO_AUTO, flags, N_in, N_out, grid, P, B,
             devptr(ds_dout, T), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(ow, T),
             devptr(pw, T), devptr(o_pts, T), devptr(o_rot, T), devptr(o_tr, T), devptr(o_bg, T),
-            devptr(o_ow, T), devptr(o_pw, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws)))
+            devptr(o_ow, T), want_pw ? devptr(o_pw, T) : Ptr{T}(C_NULL), Ptr{Cvoid}(UInt(pointer(ws))),
+            length(ws)))
     end
     keep_until_done(stream, rot, tr, ow, pw, ws)
     return (; points=o_pts, rotation=o_rot, translation=o_tr, background=o_bg, out_weight=o_ow,

@@ -1,0 +1,162 @@
+"""GPU parity tests of the 3-D DPR_ALGO_CHUNKED paths (csrc/dpr_owner.hip, csrc/dpr_chunked.hip)
+against the CPU oracle: owner-computes tiles over the box hierarchy (forward), chunk lists for
+sparse clouds over several poses (forward), the direct thread-per-point pullback.  Edge cases of the
+machinery: clouds that are not a multiple of 16 / 1024 points, heavy tiles split into parts and
+combined from slabs, candidate lists that overflow their slot (every chunk becomes a candidate),
+grids one or two cells wide, non-finite points and weights, batches beyond one plan group.
+Semantics: /root/reference/src/raster.jl:36-66, src/raster_pullback.jl:39-72, :85-148."""
+import numpy as np
+import pytest
+import torch
+
+import dpr_amd
+from tests import data as D
+from tests.test_parity_gpu import T, assert_close, grid_to_dev, tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    dpr_amd.lib()
+    return torch.device("cuda:0")
+
+
+def hilbert_like_order(pts):
+    """A coherent order without the library's sort: lexicographic on coarse cells (any coherent order
+    exercises the same paths)."""
+    q = np.floor((np.clip(pts, -1, 1) * 0.5 + 0.5) * 64).astype(np.int64)
+    return np.lexsort((pts[:, 0], q[:, 0], q[:, 1], q[:, 2]))
+
+
+def run_case(oracle, dev, npdt, tdt, grid, n_points, batch, order="sorted", pw="rand", seed=0, scale=0.4,
+             fwd_tol=None):
+    rng = np.random.default_rng(seed)
+    d = D.make(n_points=max(n_points, 1), n_in=3, n_out=3, batch=batch, grid_n=grid, seed=seed, dtype=npdt)
+    pts = (scale / 0.4 * d.points[:n_points]).astype(npdt)
+    if order == "sorted" and n_points > 1:
+        pts = np.ascontiguousarray(pts[hilbert_like_order(pts)])
+    w = None
+    if pw == "rand":
+        w = (rng.uniform(0.2, 2.0, size=n_points) * rng.choice([-1.0, 1.0], size=n_points)).astype(npdt)
+    ref_out = oracle.raster(d.grid, pts, d.rotations, d.translations, d.backgrounds, d.weights, w, dtype=npdt)
+    ref_pb = oracle.raster_pullback(d.ds_dout, pts, d.rotations, d.translations, d.weights, w, dtype=npdt)
+    args = (T(pts, dev), T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev),
+            T(w, dev))
+    out = dpr_amd.raster(d.grid, *args, algo="chunked")
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), *args, algo="chunked")
+    assert_close(out, ref_out, fwd_tol or tol(npdt, "out"), "out")
+    assert_close(pb.points, ref_pb.points, tol(npdt, "points"), "ds_dpoints")
+    assert_close(pb.point_weight, ref_pb.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    for name in ("rotation", "translation", "background", "out_weight"):
+        assert_close(getattr(pb, name), getattr(ref_pb, name), tol(npdt, "pose"), name)
+    return d, pts, w, out, pb
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+@pytest.mark.parametrize("n_points", [0, 1, 15, 16, 17, 1023, 1024, 1025, 4097, 70_001])
+def test_cloud_sizes_around_the_box_granularity(oracle, dev, npdt, tdt, n_points):
+    run_case(oracle, dev, npdt, tdt, (40, 33, 29), n_points, 2, seed=n_points)
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+@pytest.mark.parametrize("grid", [(1, 40, 40), (2, 37, 19), (3, 3, 3), (70, 1, 1), (33, 65, 15), (96, 96, 96)])
+def test_odd_grid_shapes(oracle, dev, npdt, tdt, grid):
+    """One and two cells along x (the pullback's x-pair gathers need two: a one-cell row falls back to the
+    direct kernels of DPR_ALGO_ATOMIC), tiles with remainders in every axis."""
+    run_case(oracle, dev, npdt, tdt, grid, 20_000, 3, seed=3)
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+@pytest.mark.parametrize("pw", [None, "rand"])
+def test_heavy_tiles_are_split_into_parts_and_combined(oracle, dev, npdt, tdt, pw):
+    """150 000 points within +-0.1: two or three tiles of the 128^3 grid hold them all, far above the
+    8192 visits at which a tile is split; the parts' raw 64-bit tiles are summed from slabs -- for
+    fp32 data as integers: the same bits whatever the split and the order of the points."""
+    d, pts, w, out, _ = run_case(oracle, dev, npdt, tdt, (128, 128, 128), 150_000, 2, pw=pw, seed=5, scale=0.035)
+    if npdt == np.float32:  # exact sums: the split leaves no trace -- any order of the points gives the same bits
+        perm = np.random.default_rng(3).permutation(len(pts))
+        out2 = dpr_amd.raster(d.grid, T(np.ascontiguousarray(pts[perm]), dev), T(d.rotations, dev),
+                              T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev),
+                              None if w is None else T(np.ascontiguousarray(w[perm]), dev), algo="chunked")
+        assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+def test_incoherent_cloud_overflows_the_candidate_lists(oracle, dev, npdt, tdt):
+    """300 000 points in RANDOM order on 128^3 (160 tiles): every chunk of 1024 points covers the whole
+    grid, a tile's 293 candidates do not fit its slot of 256 -- the tile takes every chunk as a
+    candidate.  Slow, never wrong; the direct pullback does not care."""
+    run_case(oracle, dev, npdt, tdt, (128, 128, 128), 300_000, 1, order="random", seed=7)
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+def test_more_poses_than_one_plan_group_and_sparse_regime(oracle, dev, npdt, tdt):
+    """37 poses: three plan groups of 16 on the owner path (dense cloud); the same batch of a cloud that
+    is sparse on its grid runs the chunk lists (P * 10 <= G, B >= 4)."""
+    run_case(oracle, dev, npdt, tdt, (48, 40, 36), 30_000, 37, seed=9)   # dense: owner-computes tiles
+    run_case(oracle, dev, npdt, tdt, (64, 64, 64), 20_000, 5, seed=10)   # sparse: chunk lists
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_non_finite_points_and_weights(oracle, dev, bad):
+    """A NaN / Inf coordinate is a point without a cell (zero gradient, no contribution); a NaN / Inf
+    weight switches its tiles to f64 sums and lands where the reference's arithmetic puts it."""
+    npdt = np.float32
+    d = D.make(n_points=40_000, n_in=3, n_out=3, batch=1, grid_n=48, seed=11, dtype=npdt)
+    pts = np.ascontiguousarray(d.points[hilbert_like_order(d.points)])
+    pts[[5, 1024, 30_000], [0, 1, 2]] = bad
+    w = np.random.default_rng(1).uniform(0.5, 1.5, size=len(pts)).astype(npdt)
+    ref = oracle.raster(d.grid, pts, d.rotations, d.translations, None, d.weights, w, dtype=npdt)
+    out = dpr_amd.raster(d.grid, T(pts, dev), T(d.rotations, dev), T(d.translations, dev), None, T(d.weights, dev),
+                         T(w, dev), algo="chunked")
+    assert_close(out, ref, 5e-5, "out with non-finite points")
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout, dev), T(pts, dev), T(d.rotations, dev),
+                                  T(d.translations, dev), None, T(d.weights, dev), T(w, dev), algo="chunked")
+    refpb = oracle.raster_pullback(d.ds_dout, pts, d.rotations, d.translations, d.weights, w, dtype=npdt)
+    assert_close(pb.points, refpb.points, 1e-4, "ds_dpoints")
+    assert float(pb.points[5].abs().sum()) == 0.0
+    w2 = w.copy()
+    w2[777] = bad
+    ref2 = oracle.raster(d.grid, pts, d.rotations, d.translations, None, d.weights, w2, dtype=npdt)
+    out2 = dpr_amd.raster(d.grid, T(pts, dev), T(d.rotations, dev), T(d.translations, dev), None,
+                          T(d.weights, dev), T(w2, dev), algo="chunked").cpu().numpy()
+    assert np.array_equal(np.isnan(out2), np.isnan(ref2))
+    assert np.array_equal(np.isposinf(out2), np.isposinf(ref2))
+    fin = np.isfinite(ref2)
+    assert_close(out2[fin], ref2[fin], 5e-5, "finite cells")
+
+
+def test_owner_forward_is_independent_of_the_point_order(dev):
+    """fp32: 64-bit fixed-point sums per tile, parts of split tiles added as integers -- `out` is the
+    same bit pattern for any order of the points (and so for any split into parts)."""
+    d = D.make(n_points=120_000, n_in=3, n_out=3, batch=1, grid_n=64, seed=13, dtype=np.float32)
+    pts = np.ascontiguousarray(d.points[hilbert_like_order(d.points)])
+    perm = np.random.default_rng(2).permutation(len(pts))
+    a = dpr_amd.raster(d.grid, T(pts, dev), T(d.rotations, dev), T(d.translations, dev), None, T(d.weights, dev),
+                       None, algo="chunked")
+    b = dpr_amd.raster(d.grid, T(np.ascontiguousarray(pts[perm]), dev), T(d.rotations, dev), T(d.translations, dev),
+                       None, T(d.weights, dev), None, algo="chunked")
+    assert torch.equal(a, b)
+
+
+def test_auto_takes_the_direct_pullback_for_a_coherent_cloud(oracle, dev):
+    """DPR_ALGO_AUTO + DPR_FLAG_COHERENT_POINTS, one pose on a 3-D grid: the pullback is the direct
+    kernel, a KEEP / REUSE pair shares nothing (flags dropped) and still works."""
+    d = D.make(n_points=60_000, n_in=3, n_out=3, batch=1, grid_n=64, seed=15, dtype=np.float32)
+    pts = np.ascontiguousarray(d.points[hilbert_like_order(d.points)])
+    assert dpr_amd.resolve_algo("pullback", d.grid, len(pts), 1, 3, coherent_points=True) == "chunked"
+    assert not dpr_amd.sharing_effective(d.grid, len(pts), 1, 3, coherent_points=True)
+    ws = torch.empty(max(dpr_amd.workspace_bytes(op, d.grid, len(pts), 1, 3, torch.float32, "auto",
+                                                 coherent_points=True, sharing=True)
+                         for op in ("raster", "pullback")) + 16, dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(d.grid, None, torch.float32, dev)
+    args = (T(pts, dev), T(d.rotations[0], dev), T(d.translations[0], dev))
+    dpr_amd.raster_(out, *args, workspace=ws, keep_binning=True, coherent_points=True)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(d.ds_dout[..., 0], dev), *args, workspace=ws, reuse_binning=True,
+                                  coherent_points=True)
+    ref = oracle.raster_pullback(d.ds_dout, pts, d.rotations, d.translations, dtype=np.float32)
+    assert_close(pb.points, ref.points, 1e-4, "ds_dpoints")
+    assert_close(pb.rotation, ref.rotation[0], 1e-3, "ds_drotation")
+    assert_close(out, oracle.raster(d.grid, pts, d.rotations, d.translations, dtype=np.float32)[..., 0], 5e-5, "out")
