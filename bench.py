@@ -546,6 +546,25 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
         roof["pullback"] = {"algorithmic_bytes": a_bwd, "ms": round(ms_bwd, 4),
                             "achieved": round(gbs(a_bwd, ms_bwd), 2),
                             "frac": round(gbs(a_bwd, ms_bwd) / HBM_PEAK_GBS, 4)}
+    if do_bwd and B_local > 0 and not lean:
+        # what the reference's rrule needs when point_weight was defaulted (the benchmark's case): no
+        # ds_dpoint_weight (DPR_FLAG_NO_POINT_WEIGHT_GRAD) -- a P-element store less
+        def bwd_nopw():
+            return dpr_amd.raster_pullback_(g, points, R, t, ds_dpoints=fused[: P_local * n_in].view(P_local, n_in),
+                                            algo=algo_b, workspace=ws, reuse_binning=share, point_weight_grad=False, **co)
+        nevs = [(ev(), ev()) for _ in range(reps)]
+        for e0, e1 in nevs:
+            fwd()
+            e0.record()
+            bwd_nopw()
+            e1.record()
+        torch.cuda.synchronize()
+        ms_nopw = avg_ms([e0.elapsed_time(e1) for e0, e1 in nevs])
+        a_nopw = a_bwd - s_elem * P_local
+        roof["pullback"]["without_point_weight_grad"] = {
+            "flag": "DPR_FLAG_NO_POINT_WEIGHT_GRAD", "ms": round(ms_nopw, 4),
+            "algorithmic_bytes": a_nopw, "algorithmic_bytes_is": "A_bwd without the P-element ds_dpoint_weight store",
+            "achieved": round(gbs(a_nopw, ms_nopw), 2), "frac": round(gbs(a_nopw, ms_nopw) / HBM_PEAK_GBS, 4)}
     if batched:
         roof["note"] = ("batched poses re-read the points per pose (group): the per-call "
                         "algorithmic bytes count them once, BASELINE.md section 3")

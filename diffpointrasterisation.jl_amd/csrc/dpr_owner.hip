@@ -1165,6 +1165,208 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
     }
 }
 
+// The same for a BATCH of poses, pose loop inside: a thread keeps K points and their gradient sums
+// in registers while the poses go by, so the cloud is read once and the point gradients are stored
+// once -- launched pose by pose (k_own_pullback with FIRST = false) every pose re-reads the cloud and
+// read-modify-writes 16 bytes per point: 6.3 GB per pose against 1.3 GB of gathers at 50 M fp64
+// points.  The per-pose sums cannot stay in registers across the poses (13 per pose): each pose's 13
+// sums over the thread's K points are reduced across the wave (DPP row shifts for fp32) and added to
+// the block's accumulators in LDS by one lane -- 13 reductions per K points and pose.
+constexpr int kDBatch = 64;  // poses per launch (their block accumulators: 64 x 14 doubles of LDS)
+// (K = 4 / 2 would halve the share of the reductions but needs ~230 / ~175 registers: 2 waves per SIMD)
+template <typename T> __host__ __device__ constexpr int own_batch_k() { return sizeof(T) == 4 ? 2 : 1; }
+
+template <typename T, bool HAS_PW>
+__global__ __launch_bounds__(kDT) void k_own_pullback_batch(GridDesc<3> gd, int64_t P, int64_t per_block,
+                                                            int64_t cells_per_block,
+                                                            const T* __restrict__ points, const T* __restrict__ pw,
+                                                            const T* __restrict__ g, const T* __restrict__ rot,
+                                                            const T* __restrict__ trans, const T* __restrict__ ow,
+                                                            int64_t b0, int nb, int accumulate,
+                                                            T* __restrict__ ds_dpoints, T* __restrict__ ds_dpw,
+                                                            double* __restrict__ partials) {
+    constexpr int K = own_batch_k<T>();
+    __shared__ double acc[kDBatch][kNVal];
+    for (int i = threadIdx.x; i < nb * kNVal; i += kDT) (&acc[0][0])[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t p_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t p_hi = p_lo + per_block < P ? p_lo + per_block : P;
+    const int n0 = gd.n[0], n1 = gd.n[1], n2 = gd.n[2];
+    const uint32_t row1 = (uint32_t)n0, row2 = (uint32_t)n0 * (uint32_t)n1;
+    struct Stage {
+        T dlo[3], gv[8];
+        uint32_t in;
+        int xsel;
+        bool ok, edge;
+    };
+#pragma unroll 1
+    for (int64_t base = p_lo; base < p_hi; base += (int64_t)kDT * K) {  // (uniform)
+        T pt[K][3], pwi[K], gacc[K][4];
+        bool live[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int64_t p = base + threadIdx.x + (int64_t)j * kDT;
+            live[j] = p < p_hi;
+            const int64_t q = p < P ? p : P - 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pt[j][c] = points[q * 3 + c];
+            pwi[j] = HAS_PW ? pw[q] : T(1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gacc[j][c] = T(0);
+        }
+#pragma unroll 1
+        for (int bl = 0; bl < nb; ++bl) {
+            const int64_t b = b0 + bl;
+            const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
+            const OwnXform<T> xf = own_xform<T>(ps, gd);
+            const T* gb = g + b * gd.G;
+            T vals[kNVal - 1];
+#pragma unroll
+            for (int k = 0; k < kNVal - 1; ++k) vals[k] = T(0);
+            auto front = [&](int j, Stage& st) {
+                int ref0[3];
+                st.ok = own_ref<T>(pt[j], ps, xf, ref0, st.dlo) && live[j];
+                if (!st.ok) ref0[0] = ref0[1] = ref0[2] = 0;
+                const bool lo1 = ref0[1] >= 0, hi1 = ref0[1] + 1 < n1, lo2 = ref0[2] >= 0, hi2 = ref0[2] + 1 < n2;
+                const int xb = ref0[0] < 0 ? 0 : (ref0[0] > n0 - 2 ? n0 - 2 : ref0[0]);
+                st.xsel = ref0[0] - xb;
+                const uint32_t cbase = ((uint32_t)ref0[2] * (uint32_t)n1 + (uint32_t)ref0[1]) * (uint32_t)n0 + (uint32_t)xb;
+                st.in = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s1 = r & 1, s2 = r >> 1;
+                    const bool in = st.ok && (s1 ? hi1 : lo1) && (s2 ? hi2 : lo2);
+                    st.in |= in ? (1u << r) : 0u;
+                    const uint32_t off = cbase + (s1 ? row1 : 0u) + (s2 ? row2 : 0u);
+                    typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+                    const Pair pr = *(const Pair*)(gb + (in ? off : 0u));
+                    st.gv[2 * r] = pr[0];
+                    st.gv[2 * r + 1] = pr[1];
+                }
+                st.edge = st.in != 0xfu || st.xsel != 0;
+            };
+            auto back = [&](int j, const Stage& st) {
+                T gi[8];
+                if (__ballot(st.edge) == 0ull) {  // (uniform)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) gi[s] = st.gv[s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const int r = s >> 1;
+                        const T gx = (s & 1) ? (st.xsel == 0 ? st.gv[2 * r + 1] : (st.xsel < 0 ? st.gv[2 * r] : T(0)))
+                                             : (st.xsel == 0 ? st.gv[2 * r] : (st.xsel > 0 ? st.gv[2 * r + 1] : T(0)));
+                        gi[s] = ((st.in >> r) & 1u) ? gx : T(0);
+                    }
+                }
+                T dpw_part = T(0), dcoord[3] = {T(0), T(0), T(0)}, dow_part = T(0);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const T dweight = voxel_weight<T, 3>(st.dlo, s, gi[s]);  // raster_pullback.jl:55
+                    dow_part += dweight * pwi[j];                            // :57
+                    dpw_part += dweight * ps.ow;                             // :58
+                    const T factor = gi[s] * ps.ow * pwi[j];                 // :60
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) dcoord[n] += factor * interp_weight<T, 3>(n, st.dlo, s);
+                }
+                T scaled[3];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) scaled[n] = st.ok ? dcoord[n] * xf.scale[n] : T(0);  // :67
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) vals[n + c * 3] = fma_t(scaled[n], pt[j][c], vals[n + c * 3]);  // :69
+                    vals[9 + n] += scaled[n];                                                                 // :68
+                }
+                vals[12] += st.ok ? dow_part : T(0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {  // rotation' * scaled (:70), summed over the poses in index order (:141)
+                    T v = ps.R[0 + c * 3] * scaled[0];
+                    v = v + ps.R[1 + c * 3] * scaled[1];
+                    v = v + ps.R[2 + c * 3] * scaled[2];
+                    gacc[j][c] += v;
+                }
+                gacc[j][3] += st.ok ? dpw_part : T(0);
+            };
+            Stage sa, sb;
+            front(0, sa);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {  // (gathers of point j + 1 in flight while point j is worked on)
+                Stage& cur = (j & 1) ? sb : sa;
+                Stage& nx = (j & 1) ? sa : sb;
+                if (j + 1 < K) front(j + 1, nx);
+                back(j, cur);
+            }
+            // the pose's 13 sums over this wave's K x 64 points -> the block's accumulators
+#pragma unroll
+            for (int k = 0; k < kNVal - 1; ++k) {
+                if constexpr (sizeof(T) == 4) {
+                    const float sm = wave_sum_lane63((float)vals[k]);
+                    if (lane == kWave - 1) atomicAdd(&acc[bl][k], (double)sm);
+                } else {
+                    const double sm = wave_sum<double>((double)vals[k]);
+                    if (lane == 0) atomicAdd(&acc[bl][k], sm);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int64_t p = base + threadIdx.x + (int64_t)j * kDT;
+            if (!live[j]) continue;
+            if (!accumulate) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) __builtin_nontemporal_store(gacc[j][c], &ds_dpoints[p * 3 + c]);
+                if (ds_dpw) __builtin_nontemporal_store(gacc[j][3], &ds_dpw[p]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ds_dpoints[p * 3 + c] += gacc[j][c];
+                if (ds_dpw) ds_dpw[p] += gacc[j][3];
+            }
+        }
+    }
+    // ds_dbackground: this block's slice of every pose's grid
+    for (int bl = 0; bl < nb; ++bl) {
+        const T* gb = g + (b0 + bl) * gd.G;
+        const int64_t c_lo = (int64_t)blockIdx.x * cells_per_block;
+        const int64_t c_hi = c_lo + cells_per_block < gd.G ? c_lo + cells_per_block : gd.G;
+        double bg_sum = 0.0;
+        for (int64_t i = c_lo + threadIdx.x; i < c_hi; i += kDT) bg_sum += (double)__builtin_nontemporal_load(gb + i);
+        bg_sum = wave_sum<double>(bg_sum);
+        if (lane == 0) atomicAdd(&acc[bl][kNVal - 1], bg_sum);
+    }
+    __syncthreads();
+    // partials[(pose, value)][block]
+    for (int i = threadIdx.x; i < nb * kNVal; i += kDT)
+        partials[(size_t)i * gridDim.x + blockIdx.x] = (&acc[0][0])[i];
+}
+
+// per-pose sums of a batch launch: block per (value, pose)
+template <typename T>
+__global__ __launch_bounds__(1024) void k_own_reduce_batch(const double* __restrict__ partials, int nblocks,
+                                                           int64_t b0, T* __restrict__ ds_drotation,
+                                                           T* __restrict__ ds_dtranslation,
+                                                           T* __restrict__ ds_dbackground,
+                                                           T* __restrict__ ds_dout_weight) {
+    __shared__ double wsum[16];
+    const int k = blockIdx.x, bl = blockIdx.y;
+    const int64_t b = b0 + bl;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nblocks; t += 1024) s += partials[((size_t)bl * kNVal + k) * nblocks + t];
+    s = wave_sum<double>(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (k < 9) ds_drotation[b * 9 + k] = (T)tot;
+        else if (k < 12) ds_dtranslation[b * 3 + (k - 9)] = (T)tot;
+        else if (k == 12) ds_dout_weight[b] = (T)tot;
+        else ds_dbackground[b] = (T)tot;
+    }
+}
+
 // per-pose sums from the per-block partials, in block order
 template <typename T>
 __global__ __launch_bounds__(1024) void k_own_reduce(const double* __restrict__ partials, int nblocks, int64_t b,
@@ -1274,8 +1476,8 @@ bool owner_supported(const int64_t* grid) {
 size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B) {
     OGeom tg;
     if (!make_ogeom(grid, &tg) || P >= ((int64_t)1 << 32)) return (size_t)-1;
-    // pullback: per-block partial sums only (at most 65536 blocks)
-    if (op == DPR_OP_PULLBACK) return oalign((size_t)65536 * kNVal * 8);
+    // pullback: per-block partial sums only (at most 8192 blocks, up to 64 poses per launch)
+    if (op == DPR_OP_PULLBACK) return oalign((size_t)8192 * kNVal * 8 * (size_t)(B < 1 ? 1 : (B < 64 ? B : 64)));
     return make_oplan(DPR_OP_RASTER, tg, P, B).total;
 }
 
@@ -1436,6 +1638,7 @@ static int own_cu_count() {
 }
 static int own_pullback_blocks(int64_t P, int64_t G) {
     int64_t nb = (int64_t)own_cu_count() * kDBlocksPerCU;
+    if (nb > 8192) nb = 8192;
     const int64_t by_points = (P + kDT - 1) / kDT, by_cells = (G + 4 * kDT - 1) / (4 * kDT);
     const int64_t want = by_points > by_cells ? by_points : by_cells;
     if (nb > want) nb = want;
@@ -1460,6 +1663,32 @@ int pullback_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
     // (the partial sums sit at the start of the workspace: a forward's boxes and plan, further up in
     // a KEEP / REUSE pair's shared buffer, are not this call's business -- it overwrites the header)
     double* partials = (double*)ws_;
+    if (B > 1 && sizeof(T) == 4) {
+        // fp32: pose loop inside the kernel, kDBatch poses per launch (further launches add to the point
+        // gradients): 1e7 points x 16 poses -> 256^3 2.87 -> 2.36 ms, x 4 poses 0.68 -> 0.56.  fp64 stays
+        // pose by pose: one point per thread at a time, the 13 f64 reductions per point and pose (78
+        // bpermutes) cost more than the traffic they save (50 M points x 8 poses -> 512^3: 12.8 vs 14.0 ms)
+        constexpr int K = own_batch_k<T>();
+        int64_t pb = ((P + nblocks - 1) / nblocks + (int64_t)kDT * K - 1) / ((int64_t)kDT * K) * ((int64_t)kDT * K);
+        if (pb < (int64_t)kDT * K) pb = (int64_t)kDT * K;
+        for (int64_t b0 = 0; b0 < B; b0 += kDBatch) {
+            const int nb = (int)(B - b0 < kDBatch ? B - b0 : kDBatch);
+            if (pw)
+                hipLaunchKernelGGL((k_own_pullback_batch<T, true>), dim3((unsigned)nblocks), dim3(kDT), 0, st, gd, P,
+                                   pb, cells_per_block, points, pw, g, rot, trans, ow, b0, nb, b0 > 0 ? 1 : 0, d_pts,
+                                   d_pw, partials);
+            else
+                hipLaunchKernelGGL((k_own_pullback_batch<T, false>), dim3((unsigned)nblocks), dim3(kDT), 0, st, gd, P,
+                                   pb, cells_per_block, points, pw, g, rot, trans, ow, b0, nb, b0 > 0 ? 1 : 0, d_pts,
+                                   d_pw, partials);
+            if (b0 == 0) stage_mark(st);
+            hipLaunchKernelGGL((k_own_reduce_batch<T>), dim3(kNVal, (unsigned)nb), dim3(1024), 0, st,
+                               (const double*)partials, nblocks, b0, d_rot, d_trans, d_bg, d_ow);
+            if (b0 == 0) stage_mark(st);
+        }
+        DPR_HIP(hipGetLastError());
+        return DPR_OK;
+    }
     for (int64_t b = 0; b < B; ++b) {
         // the point gradients accumulate over poses: one pose per launch (stream order = race-free
         // read-modify-write)
