@@ -379,6 +379,8 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
     # the pair of calls (include/dpr.h); the names are resolved here so that the no-share run and
     # the stage list use exactly the algorithms of the timed step.
     def shareable(a):
+        if a == "chunked" and n_out == 3:
+            return False  # (its pullback gathers directly and reads nothing a forward could leave)
         if (single_call and a in ("tiled", "chunked")) or (a == "chunked" and n_out == 2):
             return True
         # a batch on the tiled path: every pose keeps its own binning (B-fold records) where

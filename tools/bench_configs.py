@@ -37,7 +37,7 @@ def run(name, P, grid, B, dt, order, algo="auto"):
     f = t_ms(lambda: dpr_amd.raster_(out, tp, R, t, algo=algo, workspace=ws, **kw))
     b = t_ms(lambda: dpr_amd.raster_pullback_(g, tp, R, t, algo=algo, workspace=ws, **kw))
     if algo == "auto":
-        algo = dpr_amd.resolve_algo("raster", grid, P, B, 3) + "/" + dpr_amd.resolve_algo("pullback", grid, P, B, 3)
+        algo = dpr_amd.resolve_algo("raster", grid, P, B, 3, **kw) + "/" + dpr_amd.resolve_algo("pullback", grid, P, B, 3, **kw)
     pp = P * B
     print(f"{name:38s} {order:6s} algo={algo:15s} fwd {f:9.3f} ms ({pp / f / 1e6:8.2f} G point-poses/s)  bwd {b:9.3f} ms ({pp / b / 1e6:8.2f} G point-poses/s)  workspace {wsb / 2**20:7.0f} MiB", flush=True)
     del out, g, ws, tp
@@ -55,3 +55,8 @@ for order in ("random", "sorted"):
     run("C4 same, algo=tiled", 10_000_000, (512, 512), 64, torch.float32, order, "tiled")
     run("C5 50M -> 512^3 f64, B=8 (1 GPU of 8)", 50_000_000, (512,) * 3, 8, torch.float64, order)
     run("C5 50M -> 512^3 f64, B=1", 50_000_000, (512,) * 3, 1, torch.float64, order)
+    if order == "sorted":  # the 3-D DPR_ALGO_CHUNKED paths on their intended input
+        run("C3 same, algo=chunked", 10_000_000, (256,) * 3, 1, torch.float32, order, "chunked")
+        run("C5 B=8 same, algo=chunked", 50_000_000, (512,) * 3, 8, torch.float64, order, "chunked")
+        run("10M -> 256^3 f32, B=16", 10_000_000, (256,) * 3, 16, torch.float32, order)
+        run("10M -> 256^3 f32, B=16, algo=tiled", 10_000_000, (256,) * 3, 16, torch.float32, order, "tiled")

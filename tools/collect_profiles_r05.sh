@@ -1,0 +1,55 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): bench lines + rocprofv3 kernel stats + HBM traffic PMC passes of round 5.
+# Outputs under gpurun_out/final5/ ; tools/summarise_profiles_r05.py turns them into profiles/r05_*.
+# Every profiled program is `python ...` itself after `--` (no wrapper that would re-exec).
+set -o pipefail
+ROOT=$PWD
+O=$ROOT/gpurun_out/final5
+rm -rf $O && mkdir -p $O
+step() { echo "== $1"; }
+step bench_default
+timeout -k 10 600 python bench.py --steps 30 --warmup 5 2>/dev/null | tail -1 > $O/bench_default.json || exit 1
+step bench_c2
+timeout -k 10 300 python bench.py --config C2 --steps 30 --warmup 3 --cpu-budget 5 2>/dev/null | tail -1 > $O/bench_c2.json || exit 1
+step bench_c4
+timeout -k 10 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --cpu-budget 5 2>/dev/null | tail -1 > $O/bench_c4_64poses.json || exit 1
+step bench_c5
+timeout -k 10 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5_8poses.json || exit 1
+step bench_c3_coherent_auto
+timeout -k 10 300 python bench.py --order hilbert --coherent --steps 30 --warmup 5 --no-cpu-baseline --no-scaling-reference 2>/dev/null | tail -1 > $O/bench_c3_coherent_auto.json || exit 1
+step bench_c3_coherent_chunked
+timeout -k 10 300 python bench.py --order hilbert --coherent --algo chunked --steps 30 --warmup 5 --no-cpu-baseline --no-scaling-reference 2>/dev/null | tail -1 > $O/bench_c3_coherent_chunked.json || exit 1
+ARGS="--no-cpu-baseline --no-secondary --no-scaling-reference"
+cd /tmp && export TMPDIR=/tmp
+step stats_c3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $ROOT/bench.py --steps 30 --warmup 3 $ARGS > $O/stats.log 2>&1 || exit 1
+grep '^{"metric"' $O/stats.log | tail -1 > $O/bench_under_rocprof.json
+step stats_coherent_auto
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_coh_auto -- python $ROOT/bench.py --steps 30 --warmup 3 $ARGS --order hilbert --coherent > $O/stats_coh_auto.log 2>&1 || exit 1
+step stats_coherent_chunked
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_coh_chunked -- python $ROOT/bench.py --steps 30 --warmup 3 $ARGS --order hilbert --coherent --algo chunked > $O/stats_coh_chunked.log 2>&1 || exit 1
+step stats_c4
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -- python $ROOT/bench.py --config C4 --poses 64 --steps 5 --warmup 2 $ARGS > $O/stats_c4.log 2>&1 || exit 1
+step stats_c5
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $ROOT/bench.py --config C5 --poses 8 --steps 3 --warmup 1 $ARGS > $O/stats_c5.log 2>&1 || exit 1
+for mode in random coh_auto coh_chunked; do
+  case $mode in random) M="";; coh_auto) M="--order hilbert --coherent";; coh_chunked) M="--order hilbert --coherent --algo chunked";; esac
+  step fetch_$mode
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$mode -- python $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/fetch_$mode.log 2>&1 || exit 1
+  step write_$mode
+  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$mode -- python $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/write_$mode.log 2>&1 || exit 1
+done
+for mode in random coh_chunked; do
+  case $mode in random) M="";; coh_chunked) M="--order hilbert --coherent --algo chunked";; esac
+  step sq_$mode
+  timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $O/sq_$mode -- python3 $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/sq_$mode.log 2>&1 || exit 1
+  step sqi_$mode
+  timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD --output-format csv -d $O/sqi_$mode -- python3 $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/sqi_$mode.log 2>&1 || exit 1
+done
+cd $ROOT
+step owner_stats
+DPR_LIB_OVERRIDE=$ROOT/diffpointrasterisation.jl_amd/libdpr_stats.so timeout -k 10 200 python tools/own_probe.py > $O/owner_stats.json 2>/dev/null || true
+step other_configs
+timeout -k 10 600 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids > $O/other_configs.txt
+ls $O
+echo collect done
