@@ -1,1 +1,1 @@
-bash tools/collect_profiles_r05.sh > gpurun_out/collect5.log 2>&1; tail -5 gpurun_out/collect5.log
+bash tools/collect_profiles_r05.sh b > gpurun_out/collect5b.log 2>&1; rc=$?; tail -5 gpurun_out/collect5b.log; exit $rc

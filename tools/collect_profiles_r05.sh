@@ -5,8 +5,11 @@
 set -o pipefail
 ROOT=$PWD
 O=$ROOT/gpurun_out/final5
-rm -rf $O && mkdir -p $O
-step() { echo "== $1"; }
+PART=${1:-all}   # "a" = bench lines + kernel stats, "b" = counter passes + the rest (two gpurun calls)
+mkdir -p $O
+step() { echo "== $1 $(date +%T)"; }
+ARGS="--no-cpu-baseline --no-secondary --no-scaling-reference"
+if [ $PART != b ]; then
 step bench_default
 timeout -k 10 600 python bench.py --steps 30 --warmup 5 2>/dev/null | tail -1 > $O/bench_default.json || exit 1
 step bench_c2
@@ -19,7 +22,6 @@ step bench_c3_coherent_auto
 timeout -k 10 300 python bench.py --order hilbert --coherent --steps 30 --warmup 5 --no-cpu-baseline --no-scaling-reference 2>/dev/null | tail -1 > $O/bench_c3_coherent_auto.json || exit 1
 step bench_c3_coherent_chunked
 timeout -k 10 300 python bench.py --order hilbert --coherent --algo chunked --steps 30 --warmup 5 --no-cpu-baseline --no-scaling-reference 2>/dev/null | tail -1 > $O/bench_c3_coherent_chunked.json || exit 1
-ARGS="--no-cpu-baseline --no-secondary --no-scaling-reference"
 cd /tmp && export TMPDIR=/tmp
 step stats_c3
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $ROOT/bench.py --steps 30 --warmup 3 $ARGS > $O/stats.log 2>&1 || exit 1
@@ -32,6 +34,9 @@ step stats_c4
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -- python $ROOT/bench.py --config C4 --poses 64 --steps 5 --warmup 2 $ARGS > $O/stats_c4.log 2>&1 || exit 1
 step stats_c5
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $ROOT/bench.py --config C5 --poses 8 --steps 3 --warmup 1 $ARGS > $O/stats_c5.log 2>&1 || exit 1
+fi
+if [ $PART = a ]; then echo collect part a done; exit 0; fi
+cd /tmp && export TMPDIR=/tmp
 for mode in random coh_auto coh_chunked; do
   case $mode in random) M="";; coh_auto) M="--order hilbert --coherent";; coh_chunked) M="--order hilbert --coherent --algo chunked";; esac
   step fetch_$mode

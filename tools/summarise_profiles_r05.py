@@ -48,7 +48,7 @@ MUST_READ = {
     "dpr::k_own_splat": 12 * P,            # every point at least once (visited 1.6 times; repeats hit the caches)
     "dpr::k_own_pullback": 12 * P + 4 * G,  # points + every ds_dout cell (grid sum)
 }
-out = {"note": "Per-launch HBM traffic of the C3 forward / pullback kernels from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-scaling-reference [--order hilbert --coherent [--algo chunked]]`). Counter unit is KiB. Correction per MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads. Decided PER KERNEL from the bytes the kernel must read (`must_read_bytes`): a raw FETCH_SIZE below 0.75 x that floor is doubled (`fetch_doubled: true`), everything else is left as reported. WRITE_SIZE is exact.",
+out = {"note": "Per-launch HBM traffic of the C3 forward / pullback kernels from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-scaling-reference [--order hilbert --coherent [--algo chunked]]`). Counter unit is KiB. Correction per MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads. Decided PER KERNEL from the bytes the kernel must read (`must_read_bytes`): a raw FETCH_SIZE below 0.75 x that floor is doubled (`fetch_doubled: true`), everything else is left as reported. WRITE_SIZE is exact. `hbm_bytes_upper_bound` doubles every kernel's FETCH_SIZE (the value if all reads were of the half-reported kind): kernels that mix 16-byte and 4-byte loads (k_own_splat, k_tile_splat_runs: raw value just below the floor) lie between the two.",
        "kernels": {}, "forward": {}, "pullback": {}}
 fwd_k = ["dpr::k_count", "dpr::k_colscan", "dpr::k_tilescan", "dpr::k_scatter", "dpr::k_scatter_wc", "dpr::k_tile_splat",
          "dpr::k_halo_gather", "dpr::k_bin_local", "dpr::k_runscan", "dpr::k_place_desc", "dpr::k_tile_splat_runs",
@@ -80,6 +80,7 @@ for mode, key_f, key_b in (("random", "C3/tiled/random", "C3/tiled/random"),
             continue
         out[grp][key] = {"fetch_bytes_raw": round(tot[grp][0]), "fetch_bytes_corrected": round(tot[grp][1]),
                          "write_bytes": round(tot[grp][2]), "hbm_bytes_corrected": round(tot[grp][1] + tot[grp][2]),
+                         "hbm_bytes_upper_bound": round(2 * tot[grp][0] + tot[grp][2]),
                          "collected_with": mode}
 json.dump(out, open("profiles/r05_c3_hbm_traffic.json", "w"), indent=1)
 for grp in ("forward", "pullback"):
