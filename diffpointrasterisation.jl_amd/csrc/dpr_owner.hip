@@ -1083,7 +1083,8 @@ __global__ __launch_bounds__(kDT) void k_own_pullback(GridDesc<3> gd, int64_t P,
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) vals[n + j * 3] = fma_t(scaled[n], st.pt[j], vals[n + j * 3]);  // :69
+            for (int j = 0; j < 3; ++j)  // (a rejected point may be NaN / Inf: 0 * NaN must not reach the sums)
+                vals[n + j * 3] = fma_t(scaled[n], st.ok ? st.pt[j] : T(0), vals[n + j * 3]);  // :69
             vals[9 + n] += scaled[n];                                                                  // :68
         }
         vals[12] += st.ok ? dow_part : T(0);
@@ -1276,7 +1277,8 @@ __global__ __launch_bounds__(kDT) void k_own_pullback_batch(GridDesc<3> gd, int6
 #pragma unroll
                 for (int n = 0; n < 3; ++n) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) vals[n + c * 3] = fma_t(scaled[n], pt[j][c], vals[n + c * 3]);  // :69
+                    for (int c = 0; c < 3; ++c)  // (0 * NaN of a rejected point must not reach the sums)
+                        vals[n + c * 3] = fma_t(scaled[n], st.ok ? pt[j][c] : T(0), vals[n + c * 3]);  // :69
                     vals[9 + n] += scaled[n];                                                                 // :68
                 }
                 vals[12] += st.ok ? dow_part : T(0);

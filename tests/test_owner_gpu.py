@@ -117,6 +117,21 @@ def test_non_finite_points_and_weights(oracle, dev, bad):
     refpb = oracle.raster_pullback(d.ds_dout, pts, d.rotations, d.translations, d.weights, w, dtype=npdt)
     assert_close(pb.points, refpb.points, 1e-4, "ds_dpoints")
     assert float(pb.points[5].abs().sum()) == 0.0
+    # (the per-pose sums multiply by the point itself: 0 * NaN of a rejected point must not reach them --
+    # found by tools/fuzz_owner.py in round 5)
+    assert_close(pb.rotation, refpb.rotation, 1e-3, "ds_drotation")
+    assert_close(pb.translation, refpb.translation, 1e-3, "ds_dtranslation")
+    assert_close(pb.out_weight, refpb.out_weight, 1e-3, "ds_dout_weight")
+    for npdt2, B in ((np.float32, 3), (np.float64, 2)):  # the batched kernels (pose loop inside / per pose)
+        db = D.make(n_points=20_000, n_in=3, n_out=3, batch=B, grid_n=32, seed=12, dtype=npdt2)
+        pb_pts = np.ascontiguousarray(db.points[hilbert_like_order(db.points)])
+        pb_pts[[7, 2000, 19_999]] = bad
+        got = dpr_amd.raster_pullback_(grid_to_dev(db.ds_dout, dev), T(pb_pts, dev), T(db.rotations, dev),
+                                       T(db.translations, dev), None, T(db.weights, dev), None, algo="chunked",
+                                       coherent_points=True)
+        want = oracle.raster_pullback(db.ds_dout, pb_pts, db.rotations, db.translations, db.weights, None, dtype=npdt2)
+        for name in ("points", "rotation", "translation", "out_weight", "background"):
+            assert_close(getattr(got, name), getattr(want, name), tol(npdt2, "pose"), f"batched {name}")
     w2 = w.copy()
     w2[777] = bad
     ref2 = oracle.raster(d.grid, pts, d.rotations, d.translations, None, d.weights, w2, dtype=npdt)
