@@ -139,7 +139,14 @@ extern "C" {
  * "Rounding level" = the differences any two summation orders of the same terms show in the
  * accumulation type; no output depends on the order beyond that.  The contributions themselves
  * (cell choice, weights) are computed with the reference's operation order in T and do not depend
- * on any order. */
+ * on any order.
+ *
+ * ABSOLUTE ERROR BOUND OF THE FIXED-POINT SUMS (a deviation from the reference's fp32 float atomics,
+ * which keep the relative precision of every cell): a contribution is rounded to a multiple of
+ * 2^-sexp, with sexp chosen per work item so that n * maxw * 2^sexp <= 2^62 (n = records of the item,
+ * maxw = |out_weight| * max |point_weight| OF THE WHOLE CALL).  A contribution therefore keeps at
+ * least 38 bits below maxw (items hold < 2^24 records; typically 49): cells whose points all weigh
+ * less than ~2^-38 * maxw receive 0.  NaN / Inf weights switch the item to IEEE f64 atomics. */
 
 /* flags (the *_ex entry points).  DPR_ALGO_TILED: any B -- with B > 1 every pose keeps its own
  * binning (the per-pose part of the workspace is laid out B times; pose groups are off);

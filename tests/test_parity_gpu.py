@@ -1386,3 +1386,35 @@ def test_1024_cube_fp32_forward_auto_is_tiled_and_matches_the_oracle(oracle, dev
     out = dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), None,
                          T(d.weights, dev), algo="tiled")
     _assert_close_on_device(out, grid_to_dev(ref, dev), 5e-5, "out (1024^3)")
+
+
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+def test_chunk_owner_pullback_with_large_nearly_equal_and_infinite_sensitivities(oracle, dev, npdt, tdt):
+    """Round 4's advisor: `k_co_gather` forms the bilinear gradient from DIFFERENCES of the four neighbours
+    (g10 - g00, ...) and adds the 4096 terms of a (chunk, pose) as an f32 tree.  (a) `ds_dout` = 1e4 + noise:
+    the differences cancel five digits -- the point gradients still meet the tolerance against the oracle's
+    product form (they are compared on the scale of the sensitivities, as everywhere).  (b) an Inf cell: the
+    difference form gives NaN (Inf - Inf) where the reference's sum of products gives +-Inf -- pinned here as
+    'non-finite exactly where the oracle is non-finite, equal everywhere else'."""
+    d = D.make(n_points=20_000, n_in=3, n_out=2, batch=5, grid_n=64, seed=77, dtype=npdt)
+    rng = np.random.default_rng(5)
+    g = np.asfortranarray((1.0e4 + rng.normal(size=d.ds_dout.shape)).astype(npdt))
+    args = (T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), None, T(d.weights, dev), None)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), *args, algo="chunked")
+    ref = oracle.raster_pullback(g, d.points, d.rotations, d.translations, d.weights, None, dtype=npdt)
+    scale = 1.0e4  # |ds_dout|: the sums below are O(scale * gradient of the weights)
+    for name in ("points", "rotation", "translation", "out_weight", "background"):
+        a, e = getattr(pb, name).cpu().numpy(), np.asarray(getattr(ref, name))
+        err = np.abs(a - e).max()
+        bound = tol(npdt, "pose") * max(np.abs(e).max(), scale * (1 if name == "points" else len(d.points) ** 0.5))
+        assert err <= bound, f"{name}: {err} > {bound}"
+    g2 = np.asfortranarray(rng.normal(size=d.ds_dout.shape).astype(npdt))
+    g2[20, 31, 2] = np.inf
+    pb2 = dpr_amd.raster_pullback_(grid_to_dev(g2, dev), *args, algo="chunked")
+    ref2 = oracle.raster_pullback(g2, d.points, d.rotations, d.translations, d.weights, None, dtype=npdt)
+    for name in ("points", "rotation", "translation", "out_weight", "background"):
+        a, e = getattr(pb2, name).cpu().numpy(), np.asarray(getattr(ref2, name))
+        fin = np.isfinite(e)
+        assert np.array_equal(np.isfinite(a), fin), f"{name}: non-finite entries differ from the oracle's"
+        if fin.any():
+            assert_close(a[fin], e[fin], tol(npdt, "pose"), name + " (finite entries)")
