@@ -498,7 +498,9 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         }
         // parts: every n-th candidate each
         uint32_t ev = e < 4.0e9f ? (uint32_t)e : 4000000000u;
-        if (begin == 0xffffffffu) ev = P < 4000000000ll ? (uint32_t)P : 4000000000u;
+        // (a tile whose candidates outgrow its slot still has the estimate of the masks; only a tile that could
+        // not scan its level-2 hits knows nothing)
+        if (scan_all) ev = P < 4000000000ll ? (uint32_t)P : 4000000000u;
         uint32_t np = 1;
         if (ev > pa.cap) {
             np = (ev + pa.cap - 1) / pa.cap;
@@ -509,6 +511,10 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         if (np > 1) {
             first_slab = atomicAdd(&ctl0[1], np);
             uint32_t sidx = 0;
+            // (the slabs [first_slab, first_slab + np) are this tile's whatever happens: when they straddle the
+            // end of the buffer the tile takes the ones that exist)
+            if (first_slab + 2 <= (uint32_t)pa.max_slabs && first_slab + np > (uint32_t)pa.max_slabs)
+                np = (uint32_t)pa.max_slabs - first_slab;
             if (first_slab + np > (uint32_t)pa.max_slabs ||
                 (sidx = atomicAdd(&ctl[2], 1u)) >= (uint32_t)pa.max_split) {
                 np = 1;  // no slab left: one long item (slower, still right)
@@ -1416,7 +1422,7 @@ static const OwnKnobs& oknobs() {
         OwnKnobs q;
         q.cap_div = env_int("DPR_OWN_CAP_DIV", 512, 1, 1 << 20);     // a part: ~1.6 P / 512 visits
         q.cap_min = env_int("DPR_OWN_CAP_MIN", 8192, 64, 1 << 24);
-        q.max_slabs = env_int("DPR_OWN_MAX_SLABS", 1024, 0, 1 << 16);
+        q.max_slabs = env_int("DPR_OWN_MAX_SLABS", 0, 0, 1 << 16);   // 0: 1024 for one or two poses, 2048 for batches
         q.fixed = env_int("DPR_FIXED_POINT", 1, 0, 1);
         return q;
     }();
@@ -1429,9 +1435,12 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     pl.nL1 = (P + kL1 - 1) / kL1;
     pl.nL2 = (pl.nL1 + kL2 - 1) / kL2;
     pl.Bw = B < 1 ? 1 : (B < kOwnBw ? B : kOwnBw);
-    const int64_t cap = (P + P / 2) / oknobs().cap_div;
+    // a part holds ~1/512 of the visits of the whole pose group: the number of parts -- and of the slabs they
+    // leave their tiles in -- stays bounded whatever the batch (with a per-pose cap a clustered cloud ran out of
+    // slabs at 4 poses, its heaviest tiles stayed whole: 10.5 ms instead of 1.5)
+    const int64_t cap = (P + P / 2) * pl.Bw / oknobs().cap_div;
     pl.cap = (uint32_t)(cap < oknobs().cap_min ? oknobs().cap_min : (cap > 0x3fffffff ? 0x3fffffff : cap));
-    pl.max_slabs = oknobs().max_slabs;
+    pl.max_slabs = oknobs().max_slabs ? oknobs().max_slabs : (pl.Bw <= 2 ? 1024 : 2048);
     pl.max_split = pl.max_slabs / 2 + 1;
     pl.max_items = tg.NT + pl.max_slabs;
     // candidate chunks per tile: 64 times the average of a cloud that fills the grid, 256 .. 8192;
