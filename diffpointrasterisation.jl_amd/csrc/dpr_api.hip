@@ -132,8 +132,17 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
                                 int64_t B, unsigned flags) {
     if (op != DPR_OP_RASTER || n_out != 3 || (flags & 3u) || !(flags & DPR_FLAG_COHERENT_POINTS))
         return false;
-    if (B < 4 || P < 30000 || P >= ((int64_t)1 << 32)) return false;
-    if (!owner_supported(grid) || !chunked_supported(n_out, grid)) return false;
+    if (P >= ((int64_t)1 << 32) || !owner_supported(grid)) return false;
+    // DENSE cloud, two poses or more, a grid of >= 1024 owner tiles (256^3: 1216): the owner-computes forward
+    // (dpr_owner.hip) reads the points in place for every pose where the tiled path writes and re-reads a record
+    // per (point, pose).  Measured on Hilbert-sorted clouds, 2-16 poses, fp32 and fp64
+    // (profiles/r05_owner_batch_sweep*.txt): at 0.6-1.8 points per voxel 1.3-1.7x ahead on a Gaussian cloud,
+    // 1.7-2.2x on a uniform one, 1.0-1.08x ... 0.73x on a clustered one (0.1 sigma; the host cannot tell) -- the
+    // smaller worst case.  Below ~0.4 points per voxel (3e7 -> 512^3: 0.93-0.98 Gaussian, 0.6 clustered) and on
+    // grids with fewer tiles than CUs (128^3: 160 tiles) the tiled path stays.
+    if (B >= 2 && owner_tiles(grid) >= 1024 && P * 5 >= G * 2 && P <= 2 * G) return true;
+    if (B < 4 || P < 30000) return false;
+    if (!chunked_supported(n_out, grid)) return false;
     // (fewer than 16 poses: only the very sparse cloud -- on a clustered one the lists lose 2x at
     // one point per 17-21 voxels and 4 poses, where they win 1.3x on a Gaussian or uniform cloud)
     return P * (B >= 16 ? 10 : 25) <= G;

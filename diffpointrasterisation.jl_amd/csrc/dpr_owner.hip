@@ -1484,6 +1484,11 @@ bool owner_supported(const int64_t* grid) {
     return make_ogeom(grid, &tg);
 }
 
+int64_t owner_tiles(const int64_t* grid) {
+    OGeom tg;
+    return make_ogeom(grid, &tg) ? tg.NT : 0;
+}
+
 size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B) {
     OGeom tg;
     if (!make_ogeom(grid, &tg) || P >= ((int64_t)1 << 32)) return (size_t)-1;

@@ -55,6 +55,7 @@ int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
 
 // DPR_ALGO_CHUNKED on 3-D grids: owner-computes tiles over a box hierarchy, direct pullback (dpr_owner.hip)
 bool owner_supported(const int64_t* grid);
+int64_t owner_tiles(const int64_t* grid);  // 32 x 32 x 14-cell tiles of the owner-computes forward
 size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B);
 
 template <typename T>

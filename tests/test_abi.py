@@ -155,7 +155,14 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     # 3-D chunk lists: forward over several poses of a coherent cloud that is sparse on the grid
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3) == "tiled"
-    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "tiled"
+    # dense coherent cloud, two poses or more, >= 1024 owner tiles, 0.4-2 points per voxel: owner-computes forward
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 2, 3, coherent_points=True) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 2, 3, coherent_points=True, sharing=True) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 3_000_000, 16, 3, coherent_points=True) == "tiled"    # 0.18 per voxel
+    assert dpr_amd.resolve_algo("raster", (128,) * 3, 10_000_000, 16, 3, coherent_points=True) == "tiled"   # 160 tiles
+    assert dpr_amd.resolve_algo("raster", (512,) * 3, 50_000_000, 8, 3, coherent_points=True) == "tiled"    # C5: 0.37
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3) == "tiled"                         # no flag
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 500_000, 16, 3, coherent_points=True) == "atomic"
     # (batches of a coherent cloud, 1e6 points and more, fewer than 32 poses: the direct 3-D pullback, pose by pose)
