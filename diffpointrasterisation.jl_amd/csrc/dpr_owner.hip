@@ -179,6 +179,31 @@ __device__ __forceinline__ bool own_ref(const T (&pt)[3], const Pose<T, 3, 3>& p
     return ok;
 }
 
+// The same for a tile kernel: PADDED tile coordinates l = ref0 - x0 + 1 of the lower neighbour and the deltas,
+// without the range tests of own_ref -- a point whose l is within 0 .. T on every axis has all eight
+// neighbours in the padded tile, and a neighbour outside the GRID then lies in a pad cell or in an owned cell
+// beyond the grid's edge, neither of which is ever flushed (the individual drop of src/raster.jl:62; a point
+// with no neighbour in the grid at all cannot reach an owned cell inside it).  Returns false for NaN / Inf
+// coordinates (a float -> int conversion of those is 0 / saturated and must not be trusted).
+template <typename T>
+__device__ __forceinline__ bool own_ref_local(const T (&pt)[3], const Pose<T, 3, 3>& ps, const OwnXform<T>& xf,
+                                              const int (&x0)[3], uint32_t (&l)[3], T (&dlo)[3]) {
+    T csum = T(0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        T proj = ps.R[d] * pt[0];
+        proj = proj + ps.R[d + 3] * pt[1];
+        proj = proj + ps.R[d + 6] * pt[2];
+        const T coord = (proj - xf.origin[d]) * xf.scale[d];
+        const T c = coord - T(0.5);
+        const T r = ceil_t<T>(c);
+        l[d] = (uint32_t)(int)r - (uint32_t)x0[d];  // = ref0 - x0 + 1 (wraps far out of range for saturated r)
+        dlo[d] = coord - (r - T(0.5));
+        csum += c;
+    }
+    return (csum - csum) == T(0);  // finite
+}
+
 // 16 bytes at a time where the caller's buffer allows it (`vec`: wave-uniform)
 template <typename T, int N> __device__ __forceinline__ void load_run(const T* __restrict__ src, bool vec, T (&v)[N]) {
     constexpr int PER = 16 / sizeof(T);
@@ -804,12 +829,11 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
         constexpr bool FIX = decltype(fix_tag)::value;
         auto visit = [&](uint32_t sc, int quarter, bool have) {
             own_points<T, HAS_PW>(sc, quarter, have, P, points, pw, vec_ok != 0, [&](int, bool live, const T (&pt)[3], T pwi) {
-                int ref0[3];
+                uint32_t l[3];
                 T dlo[3];
-                const bool ok = own_ref<T>(pt, ps, xf, ref0, dlo) && live;
+                const bool ok = own_ref_local<T>(pt, ps, xf, x0, l, dlo) && live;
                 // padded tile coordinates of the lower neighbour: 0 .. T
-                const uint32_t l0 = (uint32_t)(ref0[0] - x0[0] + 1), l1 = (uint32_t)(ref0[1] - x0[1] + 1),
-                               l2 = (uint32_t)(ref0[2] - x0[2] + 1);
+                const uint32_t l0 = l[0], l1 = l[1], l2 = l[2];
                 const bool touches = ok && l0 <= (uint32_t)kTX && l1 <= (uint32_t)kTY && l2 <= (uint32_t)kTZ;
 #if defined(DPR_OWN_STATS) && DPR_OWN_STATS >= 2  /* (per-point counters slow the kernel down 2x) */
                 st_vis += live ? 1u : 0u;
