@@ -163,7 +163,11 @@ static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P
     if (op != DPR_OP_PULLBACK || n_out != 3 || !(flags & DPR_FLAG_COHERENT_POINTS) || grid[0] < 2 ||
         P >= ((int64_t)1 << 32) || !owner_supported(grid))
         return false;
-    return (B == 1 && P >= 30000) || (B >= 2 && B < 32 && P >= 1000000);
+    // (32 poses and more, measured with the in-kernel pose loop -- tools/batch_probe.py, Gaussian cloud, 128^3 and
+    // 256^3: from 3e6 points on the direct kernel is 1.4-2.3x ahead of both alternatives in fp32 (1e7 x 32 -> 256^3:
+    // 4.7 vs 8.8 tiled / 9.8 atomic) and level to 1.1x ahead in fp64; at 1e6 points the ATOMIC kernel keeps a
+    // 1.05-1.3x lead on 256^3)
+    return (B == 1 && P >= 30000) || (B >= 2 && P >= 1000000 && (B < 32 || P >= 3000000));
 }
 
 // (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both

@@ -170,6 +170,7 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 4, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 700_000, 4, 3, coherent_points=True) == "tiled"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 64, 3, coherent_points=True) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 64, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (512, 512), 20_000, 64, 3) == "atomic"
     # many poses onto a 2-D grid: chunk-owned LDS tiles with the pose loop inside
     assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3) == "chunked"

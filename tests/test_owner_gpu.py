@@ -97,6 +97,9 @@ def test_more_poses_than_one_plan_group_and_sparse_regime(oracle, dev, npdt, tdt
     is sparse on its grid runs the chunk lists (P * 10 <= G, B >= 4)."""
     run_case(oracle, dev, npdt, tdt, (48, 40, 36), 30_000, 37, seed=9)   # dense: owner-computes tiles
     run_case(oracle, dev, npdt, tdt, (64, 64, 64), 20_000, 5, seed=10)   # sparse: chunk lists
+    # 70 poses: the fp32 pullback's in-kernel pose loop takes 64 per launch, the second launch ADDS its point
+    # gradients to the first one's; five plan groups of the forward
+    run_case(oracle, dev, npdt, tdt, (33, 40, 30), 8_000, 70, seed=11)
 
 
 @pytest.mark.parametrize("bad", [np.nan, np.inf])

@@ -1,39 +1,38 @@
-"""Timing of the batched direct 3-D pullback (DPR_ALGO_CHUNKED, coherent cloud) on a few shapes."""
-import os, sys, time, torch
+"""Pullback over a batch of poses of a Hilbert-sorted cloud on a 3-D grid (DPR_FLAG_COHERENT_POINTS): the direct
+kernels of DPR_ALGO_CHUNKED (fp32: pose loop inside; fp64: a launch per pose) against the tiled pipeline and the
+direct kernel of DPR_ALGO_ATOMIC.  Usage: batch_probe.py [--f64]"""
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dpr_amd as dpr
-torch.manual_seed(0)
 dev = "cuda"
+dt = torch.float64 if "--f64" in sys.argv else torch.float32
 
-def run(P, n, B, dt, algo="chunked"):
-    pts = (0.4 * torch.randn(P, 3, device=dev, dtype=dt)).clamp(-1.2, 1.2)
-    pts, _ = dpr.sort_points(pts)
-    R = torch.linalg.qr(torch.randn(B, 3, 3, device=dev, dtype=dt))[0]
-    t = 0.05 * torch.randn(B, 3, device=dev, dtype=dt)
-    bg = torch.zeros(B, device=dev, dtype=dt); ow = torch.ones(B, device=dev, dtype=dt)
-    g = torch.randn(B, n, n, n, device=dev, dtype=dt).permute(3, 2, 1, 0)  # grid layout: axis 1 fastest, batch last
+def run(pts, n, B, algo):
+    P = pts.shape[0]
+    g0 = torch.Generator(device=dev); g0.manual_seed(B)
+    R = torch.linalg.qr(torch.randn(B, 3, 3, device=dev, dtype=dt, generator=g0))[0]
+    t = 0.05 * torch.randn(B, 3, device=dev, dtype=dt, generator=g0)
+    g = torch.randn(B, n, n, n, device=dev, dtype=dt, generator=g0).permute(3, 2, 1, 0)  # grid layout, batch last
     kw = dict(algo=algo, coherent_points=True)
     ws = torch.empty(max(16, dpr.workspace_bytes("pullback", (n, n, n), P, B, 3, dt, algo, coherent_points=True)),
                      dtype=torch.uint8, device=dev)
-    f = lambda: dpr.raster_pullback_(g, pts, R, t, bg, ow, workspace=ws, **kw)
-    out = f(); torch.cuda.synchronize()
-    for _ in range(3): f()
-    torch.cuda.synchronize()
+    f = lambda: dpr.raster_pullback_(g, pts, R, t, None, None, workspace=ws, **kw)
+    f(); f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    N = 5
     e0.record()
-    N = 10
     for _ in range(N): f()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / N, out
+    return e0.elapsed_time(e1) / N
 
-for (P, n, B, dt) in [(10_000_000, 256, 4, torch.float32), (10_000_000, 256, 16, torch.float32),
-                      (1_000_000, 128, 16, torch.float32), (10_000_000, 256, 4, torch.float64),
-                      (50_000_000, 512, 8, torch.float64)]:
-    ms, out = run(P, n, B, dt)
-    print(f"P={P:>9d} n={n} B={B:>2d} {str(dt)[6:]:8s} chunked pullback {ms:8.3f} ms", flush=True)
-    if len(sys.argv) > 1 and P <= 10_000_000:
-        ms2, out2 = run(P, n, B, dt, "tiled")
-        err = max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(out, out2))
-        print(f"    tiled {ms2:8.3f} ms   max rel diff {err:.2e}", flush=True)
-    del out
-    torch.cuda.empty_cache()
+print(f"# {'P':>9s} {'grid':>5s} {'B':>3s} {'chunked':>9s} {'tiled':>9s} {'atomic':>9s}  AUTO   ({str(dt)[6:]})", flush=True)
+for P in (1_000_000, 3_000_000, 10_000_000):
+    g0 = torch.Generator(device=dev); g0.manual_seed(0)
+    pts = dpr.sort_points((0.4 * torch.randn(P, 3, device=dev, generator=g0)).to(dt))[0]
+    for n in (128, 256):
+        for B in (4, 16, 32, 64):
+            if n ** 3 * B * (8 if dt == torch.float64 else 4) > 12e9:
+                continue
+            ts = [run(pts, n, B, a) for a in ("chunked", "tiled", "atomic")]
+            auto = dpr.resolve_algo("pullback", (n, n, n), P, B, 3, coherent_points=True)
+            print(f"  {P:9d} {n:5d} {B:3d} {ts[0]:9.3f} {ts[1]:9.3f} {ts[2]:9.3f}  {auto}", flush=True)
