@@ -167,7 +167,11 @@ static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P
     // 256^3: from 3e6 points on the direct kernel is 1.4-2.3x ahead of both alternatives in fp32 (1e7 x 32 -> 256^3:
     // 4.7 vs 8.8 tiled / 9.8 atomic) and level to 1.1x ahead in fp64; at 1e6 points the ATOMIC kernel keeps a
     // 1.05-1.3x lead on 256^3)
-    return (B == 1 && P >= 30000) || (B >= 2 && P >= 1000000 && (B < 32 || P >= 3000000));
+    // On small grids (<= 1024 tiles of the tiled path, e.g. 128^3) the alternative at 32+ poses is the tiled
+    // pipeline, not the ATOMIC kernel: the direct kernel is 1.6x ahead of it in fp32 from 1e6 points on, 1.08-1.16x
+    // behind the best in fp64.
+    return (B == 1 && P >= 30000) ||
+           (B >= 2 && P >= 1000000 && (B < 32 || P >= 3000000 || tiled_tiles(n_out, grid) <= 1024));
 }
 
 // (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both
