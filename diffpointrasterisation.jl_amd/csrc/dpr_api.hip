@@ -2,6 +2,7 @@
 // Host checks mirror the reference's @argcheck's (src/raster.jl:14-23,
 // ext/DiffPointRasterisationCUDAExt.jl:246-262) but report through status codes.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdarg>
@@ -126,7 +127,8 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
 // which forward the 3-D algorithm runs: chunk lists (small tiles) for a sparse cloud over several
 // poses, owner-computes large tiles otherwise
 static bool chunked3d_lists(const int64_t* grid, int64_t G, int64_t P, int64_t B) {
-    return B >= 4 && P * 10 <= G && chunked_supported(3, grid);
+    static const bool off = getenv("DPR_CHUNKED3D_NO_LISTS") != nullptr;  // (experiments: owner tiles everywhere)
+    return !off && B >= 4 && P * 10 <= G && chunked_supported(3, grid);
 }
 static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t G, int64_t P,
                                 int64_t B, unsigned flags) {

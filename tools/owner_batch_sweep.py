@@ -10,6 +10,7 @@ from tests import data as D
 ap = argparse.ArgumentParser()
 ap.add_argument("--f64", action="store_true")
 ap.add_argument("--quick", action="store_true")
+ap.add_argument("--sparse", action="store_true", help="only the rows where explicit `chunked` means the chunk lists")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 tdt = torch.float64 if a.f64 else torch.float32
@@ -40,6 +41,8 @@ def time_fwd(algo, grid, pts, R, t, B):
 
 print(f"# {'cloud':8s} {'P':>9s} {'grid':>5s} {'B':>3s} {'pts/voxel':>9s} {'owner ms':>9s} {'tiled ms':>9s} {'tiled/owner':>11s}   ({'fp64' if a.f64 else 'fp32'})", flush=True)
 Ps = [1_000_000, 3_000_000, 10_000_000, 30_000_000] if not a.quick else [3_000_000]
+if a.sparse:
+    Ps = [300_000, 1_000_000, 3_000_000, 10_000_000]
 for dist in ("gauss", "uniform", "tight"):
     for P in Ps:
         pts = dpr_amd.sort_points(cloud(dist, P))[0]
@@ -47,6 +50,8 @@ for dist in ("gauss", "uniform", "tight"):
             grid = (n, n, n)
             for B in (2, 4, 8, 16):
                 if n ** 3 * B * (8 if a.f64 else 4) > 20e9 or (a.f64 and P > 10_000_000):
+                    continue
+                if a.sparse and not (B >= 4 and P * 10 <= n ** 3):
                     continue
                 rng = np.random.default_rng(B)
                 R = torch.as_tensor(D.random_rotations(rng, B, 3), device=dev).to(tdt)
