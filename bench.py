@@ -727,6 +727,56 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
                                   "achieved": round(gbs(a_bwd, st_bm["total"]), 2),
                                   "frac": round(gbs(a_bwd, st_bm["total"]) / HBM_PEAK_GBS, 4)}
         coh["roofline"] = roof_c
+        if cfg == "C3" and do_bwd and args.algo == "auto":
+            # the same sorted cloud over a BATCH of 8 poses: where DPR_ALGO_AUTO takes the record-free 3-D paths
+            # (owner-computes forward, direct pullback with the pose loop inside) -- next to the tiled pair it
+            # took before round 5
+            Bb = 8
+            gen = torch.Generator(device=device)
+            gen.manual_seed(7)
+            Rb = torch.linalg.qr(torch.randn(Bb, 3, 3, device=device, dtype=tdt, generator=gen))[0]
+            tb = 0.05 * torch.randn(Bb, 3, device=device, dtype=tdt, generator=gen)
+            outb = dpr_amd.empty_grid(grid, Bb, tdt, device)
+            gb = dpr_amd.empty_grid(grid, Bb, tdt, device)
+            gb.normal_(generator=gen)
+
+            def batch_ms(algo_f, algo_b):
+                wsb = torch.empty(max(16, *(dpr_amd.workspace_bytes(op, grid, P, Bb, n_in, tdt, a, coherent_points=True)
+                                            for op, a in (("raster", algo_f), ("pullback", algo_b)))),
+                                  dtype=torch.uint8, device=device)
+
+                def stepb():
+                    dpr_amd.raster_(outb, points, Rb, tb, algo=algo_f, workspace=wsb, **coherent_kw)
+                    dpr_amd.raster_pullback_(gb, points, Rb, tb, ds_dpoints=fused[: P * n_in].view(P, n_in),
+                                             ds_dpoint_weight=fused[P * n_in:], algo=algo_b, workspace=wsb,
+                                             **coherent_kw)
+                for _ in range(2):
+                    stepb()
+                nb_steps = max(5, args.steps // 3)
+                elb = []
+                for _rep in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(nb_steps):
+                        stepb()
+                    torch.cuda.synchronize()
+                    elb.append((time.perf_counter() - t0) / nb_steps)
+                del wsb
+                return float(np.median(elb))
+
+            algo_fb, algo_bb = (dpr_amd.resolve_algo(op, grid, P, Bb, n_in, coherent_points=True)
+                                for op in ("raster", "pullback"))
+            el_auto = batch_ms(algo_fb, algo_bb)
+            el_tiled = batch_ms("tiled", "tiled")
+            coh["batch_of_8_poses"] = {
+                "what": "the same sorted cloud, 8 poses per call (raster! + raster_pullback! through the plain "
+                        "entry points, DPR_ALGO_AUTO + DPR_FLAG_COHERENT_POINTS); median of 3 loops",
+                "algo": {"raster": algo_fb, "pullback": algo_bb},
+                "ms_per_step": round(el_auto * 1e3, 4),
+                "value": round(P * Bb / el_auto / 1e6, 3), "unit": "M point-poses/s",
+                "tiled_pair_ms_per_step": round(el_tiled * 1e3, 4),
+                "tiled_pair_is": "the same step with algo = tiled for both calls (AUTO's choice before round 5)"}
+            del outb, gb
         line["coherent_input"] = coh
         points = points_random
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not lean:
