@@ -14,6 +14,7 @@
 //
 // Gradients computed on the sorted cloud go back with ds_dpoints[perm[i]] = sorted_grad[i].
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstring>
 
@@ -146,8 +147,18 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
         hipLaunchKernelGGL((k_hilbert_keys<T, 2, true>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
     else
         hipLaunchKernelGGL((k_hilbert_keys<T, 2, false>), grid, dim3(256), 0, st, P, points, keys_in, idx_in);
+    // In-call sorts of 3-D clouds order by the top 5 bits per axis of the 24-bit key only (32^3 cells; a stable
+    // sort: points of one cell keep their order): the chunk-owner kernels need compact 4096-point chunks, not
+    // sorted neighbours -- C4's share measured 6.20 / 6.22 / 6.12 / 6.31 / 10.4 ms per step at 8 / 6 / 5 / 4 / 3 bits
+    // -- and 15 key bits are two radix passes instead of three (DPR_SORT_BITS: experiments).
+    static const int cbits = [] {
+        const char* v = getenv("DPR_SORT_BITS");
+        const int x = v ? atoi(v) : 5;
+        return x < 2 ? 2 : (x > 8 ? 8 : x);
+    }();
+    const unsigned begin_bit = (!fine && n_in == 3) ? (unsigned)(3 * (8 - cbits)) : 0u;
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm,
-                                             (size_t)P, 0, (fine && n_in == 3) ? 30 : 24, st);
+                                             (size_t)P, begin_bit, (fine && n_in == 3) ? 30 : 24, st);
     if (e != hipSuccess)
         return fail(DPR_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
     const dim3 ggrid((unsigned)((P + 256 * kGatherPer - 1) / (256 * kGatherPer)));
