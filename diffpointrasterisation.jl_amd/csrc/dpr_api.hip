@@ -53,9 +53,13 @@ static double chunk_spread(int n_in, int64_t G, int64_t P) {
     return (double)G * (n_in == 3 ? std::cbrt(frac * frac) : frac);
 }
 static double clamp01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
-// Hilbert keys + rocPRIM radix sort + gather of the points (mid-size clouds pay the sort's fixed
-// passes: 1e6 points 0.17 ms, 1e7 points 0.62 ms)
-static double sort_cost(double pm) { return 0.07 + 0.05 * pm + 0.05 * (pm < 1.0 ? pm : 1.0); }
+// The in-call sort of an unsorted cloud: since round 5 a counting sort into 4096 Hilbert-numbered cells
+// (dpr_coarse.h: count, two small scans, one write-combining scatter; 1e7 points 0.2 ms, 1e6 points 0.05 ms --
+// rounds 2-4: Hilbert keys + radix passes + a random gather, 0.62 / 0.17 ms)
+// (coefficients: the measured sort plus what the coarser chunks cost the kernels, chosen against
+// profiles/r05_auto_regret.txt with tools/regret_eval.py -- 0.03 + 0.017 pm, the sort alone, sends 1e5-1e6 points x
+// 4-16 poses on 512^2-1024^2 to the chunk-owner forward, 1.4-1.8x behind the tiled one)
+static double sort_cost(double pm) { return 0.05 + 0.025 * pm; }
 static PairCost chunkown_cost(int n_in, int64_t G, int64_t P, int64_t B, bool coherent) {
     const double pm = (double)P * 1e-6, f = chunk_spread(n_in, G, P), gm = (double)G / 1048576.0;
     PairCost c;
@@ -165,6 +169,7 @@ static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P
     if (op != DPR_OP_PULLBACK || n_out != 3 || !(flags & DPR_FLAG_COHERENT_POINTS) || grid[0] < 2 ||
         P >= ((int64_t)1 << 32) || !owner_supported(grid))
         return false;
+    const int64_t G = grid[0] * grid[1] * grid[2];
     // (32 poses and more, measured with the in-kernel pose loop -- tools/batch_probe.py, Gaussian cloud, 128^3 and
     // 256^3: from 3e6 points on the direct kernel is 1.4-2.3x ahead of both alternatives in fp32 (1e7 x 32 -> 256^3:
     // 4.7 vs 8.8 tiled / 9.8 atomic) and level to 1.1x ahead in fp64; at 1e6 points the ATOMIC kernel keeps a
@@ -172,8 +177,12 @@ static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P
     // On small grids (<= 1024 tiles of the tiled path, e.g. 128^3) the alternative at 32+ poses is the tiled
     // pipeline, not the ATOMIC kernel: the direct kernel is 1.6x ahead of it in fp32 from 1e6 points on, 1.08-1.16x
     // behind the best in fp64.
-    return (B == 1 && P >= 30000) ||
-           (B >= 2 && P >= 1000000 && (B < 32 || P >= 3000000 || tiled_tiles(n_out, grid) <= 1024));
+    // Few poses: per pose the direct kernel costs ~13 ns per 1000 points + 2.1 ns per 1000 cells (its grid-sum
+    // slices), the ATOMIC kernel 50 + 0.8 (profiles/r05_auto_regret.txt, coherent section: 1e5 x 16 -> 128^3
+    // 0.12 vs 0.23 ms, 1e5 x 16 -> 256^3 0.58 vs 0.35): direct from P > G / 28 on.
+    if (B == 1) return P >= 10000;
+    if (B < 32) return P >= 10000 && P * 28 >= G;
+    return P >= 3000000 || (P >= 1000000 && tiled_tiles(n_out, grid) <= 1024);
 }
 
 // (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both

@@ -999,9 +999,25 @@ static COPlan co_plan(size_t elem, int op, unsigned flags, int n_in, int64_t P, 
     pl.off_part = o;
     if (op == DPR_OP_PULLBACK) o += co_align((size_t)(2 * n_in + 3) * (size_t)(B > 0 ? B : 1) * pl.nblk * 8);
     pl.off_sort = o;
-    if (sort) o += co_align(sort_workspace_bytes(P));
+    if (sort) {
+        const size_t a = sort_workspace_bytes(P), c = coarse_sort_scratch_bytes(elem, P);
+        o += co_align(a > c ? a : c);
+    }
     pl.total = o > 0 ? o : 256;
     return pl;
+}
+
+// The in-call sort of a cloud not known to be coherent.  What the kernels need is compact 4096-point chunks, not
+// sorted neighbours (profiles/r05_experiments.md): a counting sort into 4096 Hilbert-numbered cells of the model
+// frame (dpr_coarse.h: count, two small scans, one write-combining scatter) instead of keys + radix passes + a
+// random gather.  DPR_CO_RADIX_SORT=1: the radix sort (experiments).
+template <typename T>
+static int co_sort(hipStream_t st, int n_in, int64_t P, const T* points, const T* pw, T* spts, T* spw,
+                   uint32_t* perm, char* scratch) {
+    static const bool radix = getenv("DPR_CO_RADIX_SORT") != nullptr;
+    if (!radix) return coarse_sort_with_perm<T>(st, n_in, P, points, pw, spts, spw, perm, scratch);
+    return sort_points_impl<T>((void*)st, n_in, P, points, spts, perm, pw, spw, scratch, sort_workspace_bytes(P),
+                               nullptr, false);
 }
 
 size_t chunkown_workspace_bytes(size_t elem, int op, unsigned flags, int n_in, int64_t P,
@@ -1045,8 +1061,7 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
     if (sort && P > 0) {
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
-        if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts, (uint32_t*)(ws + pl.off_perm),
-                                         pw, spw, ws + pl.off_sort, sort_workspace_bytes(P), nullptr, false))
+        if (int rc = co_sort<T>(st, NI, P, points, pw, spts, spw, (uint32_t*)(ws + pl.off_perm), ws + pl.off_sort))
             return rc;
         pts = spts;
         pws = spw;
@@ -1138,9 +1153,8 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
         if (!reuse)
-            if (int rc = sort_points_impl<T>((void*)st, NI, P, points, spts,
-                                             (uint32_t*)(ws + pl.off_perm), pw, spw,
-                                             ws + pl.off_sort, sort_workspace_bytes(P), nullptr, false))
+            if (int rc = co_sort<T>(st, NI, P, points, pw, spts, spw, (uint32_t*)(ws + pl.off_perm),
+                                    ws + pl.off_sort))
                 return rc;
         pts = spts;
         pws = spw;

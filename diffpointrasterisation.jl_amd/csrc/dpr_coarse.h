@@ -101,17 +101,21 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t* __restrict__
 
 // Write-combining scatter by cell (the structure of k_scatter_wc): S points per round.
 //   LDS: cursor[4096] | lhist[4096] | spt[S * NI] | spw[S] | dest[S]
-template <typename T, int NI, bool HAS_PW, int S>
+// PERM: also write perm[position in the sorted copy] = original index (what the chunk-owner kernels scatter
+// their gradients through), coalesced with the points.
+template <typename T, int NI, bool HAS_PW, int S, bool PERM = false>
 __global__ __launch_bounds__(kCellThreads) void k_cell_scatter(
     int64_t P, int64_t chunk, const T* __restrict__ points, const T* __restrict__ pw,
     const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ cell_start,
-    T* __restrict__ points_sorted, T* __restrict__ pw_sorted, uint32_t* __restrict__ inv_perm) {
+    T* __restrict__ points_sorted, T* __restrict__ pw_sorted, uint32_t* __restrict__ inv_perm,
+    uint32_t* __restrict__ perm = nullptr) {
     constexpr int PPT = S / kCellThreads;
     constexpr int BPT = kCells / kCellThreads;
     __shared__ uint32_t cursor[kCells], lhist[kCells];
     __shared__ T spt[S * NI];
     __shared__ T spw[HAS_PW ? S : 1];
     __shared__ uint32_t dest[S];
+    __shared__ uint32_t sorig[PERM ? S : 1];
     uint32_t* const wsum = dest;  // per-wave sums of the scan: dead before phase c writes dest[]
     const unsigned slice = xcd_slice(blockIdx.x, gridDim.x);
     const uint32_t* row = prefix + (size_t)slice * kCells;
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_scatter(
                 for (int j = 0; j < NI; ++j) spt[sidx * NI + j] = pt[k][j];
                 if (HAS_PW) spw[sidx] = w[k];
                 dest[sidx] = d;
+                if (PERM) sorig[sidx] = (uint32_t)p;
                 __builtin_nontemporal_store(d, &inv_perm[p]);
             }
         }
@@ -192,6 +197,8 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_scatter(
         }
         if (HAS_PW)
             for (uint32_t i = threadIdx.x; i < n_valid; i += kCellThreads) pw_sorted[dest[i]] = spw[i];
+        if (PERM)
+            for (uint32_t i = threadIdx.x; i < n_valid; i += kCellThreads) perm[dest[i]] = sorig[i];
         // e. advance the cursors, clear the histogram
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {
@@ -221,7 +228,8 @@ static size_t coarse_workspace_bytes(size_t elem, int64_t P) {
 
 template <typename T, int NI>
 static int coarse_sort_points(hipStream_t st, int64_t P, const T* points, const T* pw,
-                              T* points_sorted, T* pw_sorted, uint32_t* inv_perm, char* ws) {
+                              T* points_sorted, T* pw_sorted, uint32_t* inv_perm, char* ws,
+                              uint32_t* perm = nullptr) {
     if (P <= 0) return DPR_OK;
     int nblk;
     int64_t chunk;
@@ -235,6 +243,17 @@ static int coarse_sort_points(hipStream_t st, int64_t P, const T* points, const 
                        totals);
     hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)totals, cell_start);
     constexpr int S = sizeof(T) == 4 ? 4096 : 2048;
+    if (perm) {
+        if (pw)
+            hipLaunchKernelGGL((k_cell_scatter<T, NI, true, S, true>), dim3(nblk), dim3(kCellThreads), 0, st, P,
+                               chunk, points, pw, (const uint32_t*)counts, (const uint32_t*)cell_start,
+                               points_sorted, pw_sorted, inv_perm, perm);
+        else
+            hipLaunchKernelGGL((k_cell_scatter<T, NI, false, S, true>), dim3(nblk), dim3(kCellThreads), 0, st, P,
+                               chunk, points, pw, (const uint32_t*)counts, (const uint32_t*)cell_start,
+                               points_sorted, pw_sorted, inv_perm, perm);
+        return DPR_OK;
+    }
     if (pw)
         hipLaunchKernelGGL((k_cell_scatter<T, NI, true, S>), dim3(nblk), dim3(kCellThreads), 0, st, P,
                            chunk, points, pw, (const uint32_t*)counts, (const uint32_t*)cell_start,

@@ -54,6 +54,10 @@ int raster_chunked(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                    const T* ow, const T* pw, void* ws, size_t ws_bytes);
 
 // DPR_ALGO_CHUNKED on 3-D grids: owner-computes tiles over a box hierarchy, direct pullback (dpr_owner.hip)
+size_t coarse_sort_scratch_bytes(size_t elem, int64_t P);
+template <typename T>
+int coarse_sort_with_perm(hipStream_t st, int n_in, int64_t P, const T* points, const T* pw, T* points_sorted,
+                          T* pw_sorted, uint32_t* perm, char* scratch);
 bool owner_supported(const int64_t* grid);
 int64_t owner_tiles(const int64_t* grid);  // 32 x 32 x 14-cell tiles of the owner-computes forward
 size_t owner_workspace_bytes(int op, const int64_t* grid, int64_t P, int64_t B);

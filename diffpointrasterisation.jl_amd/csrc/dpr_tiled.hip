@@ -4088,4 +4088,23 @@ DPR_INST(float, 3, 2)
 DPR_INST(double, 2, 2)
 DPR_INST(double, 3, 3)
 DPR_INST(double, 3, 2)
+// Coarse cell sort for the chunk-owner kernels (dpr_chunkown.hip): the sorted copy, the sorted weights and the
+// permutation sorted position -> original index.  `scratch`: coarse_sort_scratch_bytes(sizeof(T), P) bytes
+// (slice histograms | inverse permutation, which this caller does not use).
+size_t coarse_sort_scratch_bytes(size_t elem, int64_t P) {
+    return (coarse_workspace_bytes(elem, P) + 255) / 256 * 256 + (size_t)(P < 1 ? 1 : P) * 4;
+}
+template <typename T>
+int coarse_sort_with_perm(hipStream_t st, int n_in, int64_t P, const T* points, const T* pw, T* points_sorted,
+                          T* pw_sorted, uint32_t* perm, char* scratch) {
+    uint32_t* inv = (uint32_t*)(scratch + (coarse_workspace_bytes(sizeof(T), P) + 255) / 256 * 256);
+    if (n_in == 3) return coarse_sort_points<T, 3>(st, P, points, pw, points_sorted, pw_sorted, inv, scratch, perm);
+    if (n_in == 2) return coarse_sort_points<T, 2>(st, P, points, pw, points_sorted, pw_sorted, inv, scratch, perm);
+    return fail(DPR_ERR_UNSUPPORTED_DIMS, "coarse cell sort: n_in = %d", n_in);
+}
+template int coarse_sort_with_perm<float>(hipStream_t, int, int64_t, const float*, const float*, float*, float*,
+                                          uint32_t*, char*);
+template int coarse_sort_with_perm<double>(hipStream_t, int, int64_t, const double*, const double*, double*,
+                                           double*, uint32_t*, char*);
+
 }  // namespace dpr

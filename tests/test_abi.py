@@ -168,10 +168,13 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     # (batches of a coherent cloud, 1e6 points and more, fewer than 32 poses: the direct 3-D pullback, pose by pose)
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 4, 3, coherent_points=True) == "chunked"
-    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 700_000, 4, 3, coherent_points=True) == "tiled"
+    # (fewer than 32 poses: direct from P > G / 28 on -- 6e5 points on 256^3)
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 700_000, 4, 3, coherent_points=True) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 500_000, 4, 3, coherent_points=True) != "chunked"
+    assert dpr_amd.resolve_algo("pullback", (128,) * 3, 100_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 64, 3, coherent_points=True) == "atomic"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 64, 3, coherent_points=True) == "chunked"
-    assert dpr_amd.resolve_algo("pullback", (512, 512), 20_000, 64, 3) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (512, 512), 5_000, 64, 3) == "atomic"
     # many poses onto a 2-D grid: chunk-owned LDS tiles with the pose loop inside
     assert dpr_amd.resolve_algo("pullback", (512, 512), 10_000_000, 64, 3) == "chunked"
     assert dpr_amd.resolve_algo("raster", (512, 512), 10_000_000, 64, 3) == "chunked"
@@ -195,7 +198,8 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 1, 3, coherent_points=True, sharing=True) == "tiled"
     assert not dpr_amd.sharing_effective((256,) * 3, 10_000_000, 1, 3, coherent_points=True)
     assert dpr_amd.sharing_effective((256,) * 3, 10_000_000, 1, 3)
-    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000, 1, 3, coherent_points=True) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 5_000, 1, 3, coherent_points=True) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000, 1, 3, coherent_points=True) == "chunked"
     # more than 32768 tiles: the tiled path works in slabs -- the forward from 1e6 points on, the
     # pullback stays with the direct kernel; a tile layer beyond 16384 tiles -> direct kernels
     assert dpr_amd.resolve_algo("raster", (4096, 4096, 64), 10_000_000, 1, 3) == "tiled"
