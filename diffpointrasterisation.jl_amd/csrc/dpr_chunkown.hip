@@ -25,8 +25,9 @@
 // neighbours project onto the same pixels, and same-address LDS atomics serialise (26 -> 190
 // cycles per wave instruction, profiles/r02_microbench_lds_conflicts.txt).
 //
-// Input that is not known to be coherent (no DPR_FLAG_COHERENT_POINTS) is Hilbert-sorted into the
-// workspace first (rocPRIM radix sort, 0.55 ms for 10 M points: amortised over the poses of the
+// Input that is not known to be coherent (no DPR_FLAG_COHERENT_POINTS) is cell-sorted into the
+// workspace first (a counting sort into 4096 Hilbert-numbered cells of the model frame, 0.2 ms for
+// 10 M points -- compact chunks are what counts, not sorted neighbours: amortised over the poses of the
 // call) and the point gradients are scattered back through the permutation.  Whatever the order,
 // the result is correct: a (chunk, pose) whose footprint does not fit the LDS tile, and any
 // neighbour outside the footprint bound, goes to / comes from global memory directly.
