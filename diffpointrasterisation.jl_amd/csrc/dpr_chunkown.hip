@@ -1011,11 +1011,18 @@ static COPlan co_plan(size_t elem, int op, unsigned flags, int n_in, int64_t P, 
 // The in-call sort of a cloud not known to be coherent.  What the kernels need is compact 4096-point chunks, not
 // sorted neighbours (profiles/r05_experiments.md): a counting sort into 4096 Hilbert-numbered cells of the model
 // frame (dpr_coarse.h: count, two small scans, one write-combining scatter) instead of keys + radix passes + a
-// random gather.  DPR_CO_RADIX_SORT=1: the radix sort (experiments).
+// random gather.
+// The cells are 1/16 of the frame wide, a chunk of the cell sort spans a whole cell: its footprints are larger
+// than those of a Hilbert-sorted chunk, which costs the kernels ~2-3 us per pose at 10 M points (C4's share, 64 poses:
+// k_co_gather 3.06 -> 3.15 ms, k_co_splat + wide 2.55 -> 2.67) against 0.21 ms saved once per call (0.43 -> 0.22).
+// Steps of C4's share with the cell sort / the radix sort: 8 poses 1.34 / 1.58 ms, 32 poses 3.33 / 3.49, 64 poses
+// 6.09 / 6.13; the 512-pose job 41.6 / 40.4.  The cell sort up to 96 poses, the radix sort (15 key bits, as compact
+// as the full key) beyond.
 template <typename T>
-static int co_sort(hipStream_t st, int n_in, int64_t P, const T* points, const T* pw, T* spts, T* spw,
+static int co_sort(hipStream_t st, int n_in, int64_t P, int64_t B, const T* points, const T* pw, T* spts, T* spw,
                    uint32_t* perm, char* scratch) {
-    static const bool radix = getenv("DPR_CO_RADIX_SORT") != nullptr;
+    static const int mode = getenv("DPR_CO_SORT") ? atoi(getenv("DPR_CO_SORT")) : 0;  // 1: cells, 2: radix (A/B runs)
+    const bool radix = mode == 2 || (mode == 0 && B > 96);
     if (!radix) return coarse_sort_with_perm<T>(st, n_in, P, points, pw, spts, spw, perm, scratch);
     return sort_points_impl<T>((void*)st, n_in, P, points, spts, perm, pw, spw, scratch, sort_workspace_bytes(P),
                                nullptr, false);
@@ -1062,7 +1069,7 @@ int raster_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64_t
     if (sort && P > 0) {
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
-        if (int rc = co_sort<T>(st, NI, P, points, pw, spts, spw, (uint32_t*)(ws + pl.off_perm), ws + pl.off_sort))
+        if (int rc = co_sort<T>(st, NI, P, B, points, pw, spts, spw, (uint32_t*)(ws + pl.off_perm), ws + pl.off_sort))
             return rc;
         pts = spts;
         pws = spw;
@@ -1154,7 +1161,7 @@ int pullback_chunkown(hipStream_t st, unsigned flags, const int64_t* grid, int64
         T* spts = (T*)(ws + pl.off_pts);
         T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
         if (!reuse)
-            if (int rc = co_sort<T>(st, NI, P, points, pw, spts, spw, (uint32_t*)(ws + pl.off_perm),
+            if (int rc = co_sort<T>(st, NI, P, B, points, pw, spts, spw, (uint32_t*)(ws + pl.off_perm),
                                     ws + pl.off_sort))
                 return rc;
         pts = spts;
