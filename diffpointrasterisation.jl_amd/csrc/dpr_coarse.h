@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_scatter(
                 if (HAS_PW) spw[sidx] = w[k];
                 dest[sidx] = d;
                 if (PERM) sorig[sidx] = (uint32_t)p;
-                __builtin_nontemporal_store(d, &inv_perm[p]);
+                if (!PERM) __builtin_nontemporal_store(d, &inv_perm[p]);  // (the PERM caller has no use for it)
             }
         }
         lds_barrier();
