@@ -89,8 +89,11 @@ extern "C" {
                               small projected footprint, and loops over the poses -- forward:
                               LDS accumulation + row-shaped global atomic flush, pullback:
                               LDS-staged ds_dout, gradients in registers across poses, no
-                              atomics.  The points are Hilbert-sorted into the workspace first
-                              unless DPR_FLAG_COHERENT_POINTS says they already are.
+                              atomics.  Unless DPR_FLAG_COHERENT_POINTS says the cloud is coherent
+                              it is sorted into the workspace first (a counting sort into 4096
+                              Hilbert-numbered cells for up to 96 poses, a radix sort on 15-bit
+                              Hilbert keys beyond: compact 4096-point chunks are what the kernels
+                              need, not sorted neighbours).
                               3-D grids: three kernel families behind one name.  FORWARD:
                               voxel tiles of 32 x 32 x 14 cells that own their cells outright
                               (no halo exchange, no global atomics, exact 64-bit fixed-point sums
@@ -101,11 +104,18 @@ extern "C" {
                               over >= 4 poses runs small 32 x 16 x 8 tiles fed by per-tile lists
                               of 64-point chunks instead.  PULLBACK: a thread per point in cloud
                               order gathers its eight ds_dout cells straight from memory (no
-                              workspace beyond 7 MB of partial sums); batches pose by pose.
-                              What AUTO picks with DPR_FLAG_COHERENT_POINTS: the forward for
-                              >= 4 poses of a sparse cloud (P >= 30000, P * 10 <= G from 16 poses
-                              on, P * 25 <= G for 4..15 poses), the pullback for one pose from
-                              30000 points on and for 2..31 poses from 1e6 points on.
+                              workspace beyond the partial sums: 0.9 MB per pose, 64 poses at
+                              most); fp32 batches run the pose loop inside the kernel, fp64
+                              batches one launch per pose.
+                              What AUTO picks with DPR_FLAG_COHERENT_POINTS: the owner-tile
+                              forward for >= 2 poses of a DENSE cloud (0.4 <= P / G <= 2) on a
+                              grid of >= 1024 such tiles (256^3: 1216); the chunk-list forward
+                              for >= 4 poses of a sparse cloud (P >= 30000, P * 10 <= G from 16
+                              poses on, P * 25 <= G for 4..15 poses); the pullback for one pose
+                              from 1e4 points on, for 2..31 poses from P >= G / 28, for any
+                              number of poses from 3e6 points (1e6 on grids of <= 1024 tiles of
+                              DPR_ALGO_TILED).  KEEP / REUSE flags are dropped where the pullback
+                              is this one (it reads nothing a forward could leave).
                               Correct for any point order; fast only for coherent input. */
 
 /* SUMMATION ORDER.  The reference promises none for its float atomics (src/raster.jl:64) and sums
