@@ -154,6 +154,13 @@ static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t 
     return P * (B >= 16 ? 10 : 25) <= G;
 }
 
+static bool pullback3d_sorts(unsigned flags, const int64_t* grid, int64_t P, int64_t B);  // (below)
+static bool raster3d_sorts(unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B);
+template <typename T>
+static int raster_owner_sorted(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                               T* out, const T* points, const T* rot, const T* trans, const T* bg, const T* ow,
+                               const T* pw, void* ws_, size_t ws_bytes);
+
 // DPR_ALGO_CHUNKED pullback on 3-D grids: a thread per point in cloud order gathering straight from
 // ds_dout (dpr_owner.hip).  On a cloud the caller vouches is coherent a wave's gathers share cache
 // lines, nothing is binned, staged or un-permuted: 10 M points -> 256^3 0.136 ms (Gaussian; 0.11
@@ -267,6 +274,21 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     if (op == DPR_OP_PULLBACK && coherent && n_out == 3 && tiled_tiles(n_out, grid) > 1024 &&
         (B >= 32 || (B >= 8 && P <= 1500000)))
         return DPR_ALGO_ATOMIC;
+    // pullback over 16+ poses of a large 3-D cloud in ANY order: sort inside the call, direct kernels on the
+    // sorted copy (pullback3d_sorts above): 1e7 x 16 -> 256^3 3.0 vs 4.4 ms tiled, x 64 10.3 vs 17.3; 3e6 x 16
+    // 1.55 vs 1.77
+    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent && B >= 16 && P >= 3000000 &&
+        pullback3d_sorts(*flags, grid, P, B) && owner_supported(grid))
+        return DPR_ALGO_CHUNKED;
+    // forward over 32+ poses of a large DENSE 3-D cloud in any order: sort inside the call, owner tiles on the
+    // sorted copy -- where the owner tiles win on coherent input (chunked3d_preferred's dense rule).  The tiled
+    // path bins such batches in pose groups and is hard to beat in fp32: 1e7 points -> 256^3, as-generated
+    // order, 16 / 32 / 64 poses: 3.05 / 5.40 / 10.2 ms against 2.97 / 5.93 / 11.8 (fp64: 4.1 / 7.6 / 14.5 against
+    // 5.2 / 10.5 / 20.9) -- profiles/r05_unsorted_batches.txt
+    if (op == DPR_OP_RASTER && n_out == 3 && !coherent && !(*flags & 3u) && B >= 32 && P >= 3000000 &&
+        raster3d_sorts(*flags, grid, G, P, B) && owner_supported(grid) && owner_tiles(grid) >= 1024 &&
+        P * 5 >= G * 2 && P <= 2 * G)
+        return DPR_ALGO_CHUNKED;
     return tiled_preferred(op, n_out, grid, P, B, G) ? DPR_ALGO_TILED : DPR_ALGO_ATOMIC;
 }
 
@@ -352,6 +374,9 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
             else if (chunked3d_lists(grid, G, P, B))                                           \
                 return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot,   \
                                                  trans, bg, ow, pw, ws, ws_bytes);             \
+            else if (P > 0 && raster3d_sorts(flags, grid, G, P, B))                           \
+                return raster_owner_sorted<T>(st, flags, grid, G, P, B, out, points, rot,      \
+                                              trans, bg, ow, pw, ws, ws_bytes);                \
             else                                                                               \
                 return raster_owner<T>(st, flags, grid, G, P, B, out, points, rot, trans, bg,  \
                                        ow, pw, ws, ws_bytes);                                  \
@@ -423,6 +448,121 @@ static int pullback_atomic(hipStream_t st, const int64_t* grid, int64_t G, int64
     return DPR_OK;
 }
 
+// 3-D DPR_ALGO_CHUNKED pullback of a cloud that is NOT flagged coherent, over a batch large enough to pay for
+// a sort: the cloud is Hilbert-sorted into the workspace (dpr_sort_points' kernels, 30-bit keys), the direct
+// kernels run on the sorted copy (dpr_owner.hip: a wave's gathers share cache lines; fp32: pose loop inside)
+// and the point gradients go back to the caller's order through the inverse permutation.  1e7 points x 16
+// poses -> 256^3 in as-generated order: 3.0 ms against 4.4 for the tiled pipeline and 8.2 for the ATOMIC kernel.
+static bool pullback3d_sorts(unsigned flags, const int64_t* grid, int64_t P, int64_t B) {
+    return !(flags & DPR_FLAG_COHERENT_POINTS) && B >= 8 && P >= 200000 && P < ((int64_t)1 << 32) && grid[0] >= 2;
+}
+struct Sorted3dPlan {
+    size_t off_pts, off_pw, off_inv, off_perm, off_g, off_gw, off_sort, off_own, own_bytes, total;
+};
+static size_t s3_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static Sorted3dPlan sorted3d_plan(size_t elem, const int64_t* grid, int64_t P, int64_t B) {
+    Sorted3dPlan pl;
+    size_t o = 0;
+    pl.off_pts = o;  o += s3_align((size_t)P * 3 * elem);
+    pl.off_pw = o;   o += s3_align((size_t)P * elem);
+    pl.off_inv = o;  o += s3_align((size_t)P * 4);
+    pl.off_perm = o; o += s3_align((size_t)P * 4);
+    pl.off_g = o;    o += s3_align((size_t)P * 3 * elem);
+    pl.off_gw = o;   o += s3_align((size_t)P * elem);
+    pl.off_sort = o; o += s3_align(sort_workspace_bytes(P));
+    pl.off_own = o;
+    pl.own_bytes = owner_workspace_bytes(DPR_OP_PULLBACK, grid, P, B);
+    o += s3_align(pl.own_bytes == (size_t)-1 ? 0 : pl.own_bytes);
+    pl.total = o;
+    return pl;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_unsort3(int64_t P, const uint32_t* __restrict__ inv,
+                                                 const T* __restrict__ gs, const T* __restrict__ gws,
+                                                 T* __restrict__ d_pts, T* __restrict__ d_pw) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const size_t q = inv[p];
+    if (q >= (size_t)P) return;  // (never for a permutation this library wrote)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) __builtin_nontemporal_store(gs[q * 3 + j], &d_pts[p * 3 + j]);
+    if (d_pw) __builtin_nontemporal_store(gws[q], &d_pw[p]);
+}
+// The forward likewise (owner-computes tiles on the sorted copy; nothing to bring back): only where the owner
+// tiles are the kernel -- not the chunk lists of a sparse cloud, whose 64-point chunks want the same order but are
+// not worth a sort.
+static bool raster3d_sorts(unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B) {
+    return !(flags & DPR_FLAG_COHERENT_POINTS) && B >= 8 && P >= 200000 && P < ((int64_t)1 << 32) &&
+           !chunked3d_lists(grid, G, P, B);
+}
+struct SortedFwdPlan {
+    size_t off_pts, off_pw, off_perm, off_sort, off_own, own_bytes, total;
+};
+static SortedFwdPlan sorted_fwd_plan(size_t elem, const int64_t* grid, int64_t P, int64_t B) {
+    SortedFwdPlan pl;
+    size_t o = 0;
+    pl.off_pts = o;  o += s3_align((size_t)P * 3 * elem);
+    pl.off_pw = o;   o += s3_align((size_t)P * elem);
+    pl.off_perm = o; o += s3_align((size_t)P * 4);
+    pl.off_sort = o; o += s3_align(sort_workspace_bytes(P));
+    pl.off_own = o;
+    pl.own_bytes = owner_workspace_bytes(DPR_OP_RASTER, grid, P, B);
+    o += s3_align(pl.own_bytes == (size_t)-1 ? 0 : pl.own_bytes);
+    pl.total = o;
+    return pl;
+}
+template <typename T>
+static int raster_owner_sorted(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B,
+                               T* out, const T* points, const T* rot, const T* trans, const T* bg, const T* ow,
+                               const T* pw, void* ws_, size_t ws_bytes) {
+    const SortedFwdPlan pl = sorted_fwd_plan(sizeof(T), grid, P, B);
+    if (pl.own_bytes == (size_t)-1)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs too many tiles or P >= 2^32");
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED forward (sorting inside the call) needs %zu workspace bytes, got %zu",
+                    pl.total, ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    T* spts = (T*)(ws + pl.off_pts);
+    T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
+    if (int rc = sort_points_impl<T>((void*)st, 3, P, points, spts, (uint32_t*)(ws + pl.off_perm), pw, spw,
+                                     ws + pl.off_sort, sort_workspace_bytes(P), nullptr, true))
+        return rc;
+    stage_mark(st);
+    return raster_owner<T>(st, (flags | DPR_FLAG_COHERENT_POINTS) & ~3u, grid, G, P, B, out, spts, rot, trans, bg, ow,
+                           spw, ws + pl.off_own, pl.own_bytes);
+}
+
+template <typename T>
+static int pullback_owner_sorted(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G, int64_t P,
+                                 int64_t B, const T* g, const T* points, const T* rot, const T* trans,
+                                 const T* ow, const T* pw, T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow,
+                                 T* d_pw, void* ws_, size_t ws_bytes) {
+    const Sorted3dPlan pl = sorted3d_plan(sizeof(T), grid, P, B);
+    if (pl.own_bytes == (size_t)-1)
+        return fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs too many tiles or P >= 2^32");
+    if (!ws_ || ws_bytes < pl.total)
+        return fail(DPR_ERR_WORKSPACE, "DPR_ALGO_CHUNKED pullback (sorting inside the call) needs %zu workspace bytes, got %zu",
+                    pl.total, ws_ ? ws_bytes : (size_t)0);
+    char* ws = (char*)ws_;
+    T* spts = (T*)(ws + pl.off_pts);
+    T* spw = pw ? (T*)(ws + pl.off_pw) : (T*)nullptr;
+    if (int rc = sort_points_impl<T>((void*)st, 3, P, points, spts, (uint32_t*)(ws + pl.off_perm), pw, spw,
+                                     ws + pl.off_sort, sort_workspace_bytes(P), (uint32_t*)(ws + pl.off_inv), true))
+        return rc;
+    stage_mark(st);
+    T* gs = (T*)(ws + pl.off_g);
+    T* gws = d_pw ? (T*)(ws + pl.off_gw) : (T*)nullptr;
+    if (int rc = pullback_owner<T>(st, flags | DPR_FLAG_COHERENT_POINTS, grid, G, P, B, g, spts, rot, trans, ow, spw,
+                                   gs, d_rot, d_trans, d_bg, d_ow, gws, ws + pl.off_own, pl.own_bytes))
+        return rc;
+    hipLaunchKernelGGL((k_unsort3<T>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, P,
+                       (const uint32_t*)(ws + pl.off_inv), (const T*)gs, (const T*)gws, d_pts, d_pw);
+    stage_mark(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DPR_ERR_HIP, "k_unsort3: %s", hipGetErrorString(e));
+    return DPR_OK;
+}
+
 template <typename T>
 static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n_out, const int64_t* grid,
                          int64_t P, int64_t B, const T* g, const T* points, const T* rot,
@@ -478,6 +618,10 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
                     return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans,  \
                                                       ow, pw, d_pts, d_rot, d_trans, d_bg, d_ow, \
                                                       d_pw, rs);                                 \
+                if (P > 0 && pullback3d_sorts(flags, grid, P, B))                               \
+                    return pullback_owner_sorted<T>(st, flags, grid, G, P, B, g, points, rot,    \
+                                                    trans, ow, pw, d_pts, d_rot, d_trans, d_bg,  \
+                                                    d_ow, d_pw, ws, ws_bytes);                   \
                 return pullback_owner<T>(st, flags, grid, G, P, B, g, points, rot, trans, ow,    \
                                          pw, d_pts, d_rot, d_trans, d_bg, d_ow, d_pw, ws,        \
                                          ws_bytes);                                              \
@@ -533,6 +677,10 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
         }
         size_t n = owner_workspace_bytes(op, grid, P, B);
         if (op == DPR_OP_RASTER && chunked3d_lists(grid, G, P, B)) n = chunked_workspace_bytes(n_out, grid, P, B);
+        if (op == DPR_OP_PULLBACK && n != (size_t)-1 && P > 0 && pullback3d_sorts(flags, grid, P, B))
+            n = sorted3d_plan(sizeof(T), grid, P, B).total;
+        if (op == DPR_OP_RASTER && n != (size_t)-1 && P > 0 && raster3d_sorts(flags, grid, G, P, B))
+            n = sorted_fwd_plan(sizeof(T), grid, P, B).total;
         if (n == (size_t)-1)
             fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs too many tiles or P >= 2^32");
         return n;

@@ -957,11 +957,6 @@ struct COPlan {
     size_t off_hdr, off_pts, off_pw, off_perm, off_grad, off_gradw, off_part, off_sort, total;
 };
 
-size_t sort_workspace_bytes(int64_t P);
-template <typename T>
-int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted,
-                     uint32_t* perm, const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes,
-                     uint32_t* inv_perm, bool fine);
 
 // One layout for both operations (like DPR_ALGO_TILED): a workspace sized for `raster` also
 // serves the pullback of the same problem.

@@ -72,4 +72,10 @@ int pullback_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t 
                    const T* g, const T* points, const T* rot, const T* trans, const T* ow, const T* pw,
                    T* d_pts, T* d_rot, T* d_trans, T* d_bg, T* d_ow, T* d_pw, void* ws, size_t ws_bytes);
 
+// dpr_sort.hip: Hilbert sort of a cloud (keys, radix sort, gather); `fine`: 30-bit keys for 3-D clouds
+size_t sort_workspace_bytes(int64_t P);
+template <typename T>
+int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* points_sorted, uint32_t* perm,
+                     const T* pw, T* pw_sorted, void* ws_, size_t ws_bytes, uint32_t* inv_perm, bool fine);
+
 }  // namespace dpr

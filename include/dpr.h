@@ -116,7 +116,11 @@ extern "C" {
                               number of poses from 3e6 points (1e6 on grids of <= 1024 tiles of
                               DPR_ALGO_TILED).  KEEP / REUSE flags are dropped where the pullback
                               is this one (it reads nothing a forward could leave).
-                              Correct for any point order; fast only for coherent input. */
+                              Without the flag, from 8 poses and 2e5 points on, the 3-D calls
+                              Hilbert-sort the cloud into the workspace themselves (the workspace
+                              query says how much more that takes) and AUTO picks them for >= 16
+                              (pullback) / >= 32 (forward, dense clouds) poses of >= 3e6 points.
+                              Correct for any point order. */
 
 /* SUMMATION ORDER.  The reference promises none for its float atomics (src/raster.jl:64) and sums
  * serially per pose on the CPU (src/raster_pullback.jl:39-72).  Here, per algorithm and output:

@@ -162,7 +162,13 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 3_000_000, 16, 3, coherent_points=True) == "tiled"    # 0.18 per voxel
     assert dpr_amd.resolve_algo("raster", (128,) * 3, 10_000_000, 16, 3, coherent_points=True) == "tiled"   # 160 tiles
     assert dpr_amd.resolve_algo("raster", (512,) * 3, 50_000_000, 8, 3, coherent_points=True) == "tiled"    # C5: 0.37
-    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3) == "tiled"                         # no flag
+    # no flag: 16+ poses of a dense cloud of 3e6+ points are sorted inside the call (owner tiles / direct pullback)
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 32, 3) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 16, 3) == "chunked"
+    # (a KEEP / REUSE pair of such a batch on a grid with pose groups shares nothing: the flags are dropped first)
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 32, 3, sharing=True) == "chunked"
+    assert not dpr_amd.sharing_effective((256,) * 3, 10_000_000, 32, 3)
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 500_000, 16, 3, coherent_points=True) == "atomic"
     # (batches of a coherent cloud, 1e6 points and more, fewer than 32 poses: the direct 3-D pullback, pose by pose)

@@ -217,3 +217,66 @@ def test_auto_takes_the_owner_forward_for_dense_coherent_batches(oracle, dev):
     assert_close(pb.rotation, full.rotation, 1e-3, "ds_drotation")
     assert_close(pb.translation, full.translation, 1e-3, "ds_dtranslation")
     assert_close(pb.background, full.background, 1e-3, "ds_dbackground")
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+@pytest.mark.parametrize("with_pw,want_pw", [(True, True), (False, False)])
+def test_unsorted_batch_is_sorted_inside_the_pullback(oracle, dev, npdt, tdt, with_pw, want_pw):
+    """DPR_ALGO_CHUNKED pullback on a 3-D grid WITHOUT the coherence flag, >= 8 poses and >= 2e5 points: the cloud
+    is Hilbert-sorted into the workspace, the direct kernels run on the sorted copy and the point gradients come
+    back in the caller's order (non-finite points included)."""
+    P, B, grid = 210_000, 9, (40, 33, 29)
+    d = D.make(n_points=P, n_in=3, n_out=3, batch=B, grid_n=40, seed=23, dtype=npdt)
+    rng = np.random.default_rng(3)
+    pts = d.points.copy()
+    pts[[11, 100_000, P - 1]] = np.nan
+    g = np.asfortranarray(rng.normal(size=grid + (B,)).astype(npdt))
+    pw = rng.uniform(0.5, 1.5, size=P).astype(npdt) if with_pw else None
+    need = dpr_amd.workspace_bytes("pullback", grid, P, B, 3, tdt, "chunked")
+    assert need > 2 * P * 3 * np.dtype(npdt).itemsize  # (sorted copy + sorted gradients: the sorting variant)
+    assert dpr_amd.workspace_bytes("pullback", grid, P, B, 3, tdt, "chunked", coherent_points=True) < need // 2
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    pb = dpr_amd.raster_pullback_(grid_to_dev(g, dev), T(pts, dev), T(d.rotations, dev), T(d.translations, dev), None,
+                                  T(d.weights, dev), T(pw, dev), algo="chunked", workspace=ws, point_weight_grad=want_pw)
+    ref = oracle.raster_pullback(g, pts, d.rotations, d.translations, d.weights, pw, dtype=npdt)
+    assert_close(pb.points, ref.points, tol(npdt, "points"), "ds_dpoints")
+    assert float(pb.points[11].abs().sum()) == 0.0
+    if want_pw:
+        assert_close(pb.point_weight, ref.point_weight, tol(npdt, "points"), "ds_dpoint_weight")
+    else:
+        assert pb.point_weight is None
+    for name in ("rotation", "translation", "out_weight", "background"):
+        assert_close(getattr(pb, name), getattr(ref, name), tol(npdt, "pose"), name)
+    # AUTO takes this path for 16+ poses of 3e6+ points in any order
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 16, 3) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 8, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3) != "chunked"
+
+
+@pytest.mark.parametrize("npdt,tdt", [(np.float32, torch.float32), (np.float64, torch.float64)])
+def test_unsorted_batch_is_sorted_inside_the_forward(oracle, dev, npdt, tdt):
+    """DPR_ALGO_CHUNKED forward on a 3-D grid WITHOUT the coherence flag, >= 8 poses of >= 2e5 points that are not
+    sparse on the grid: sorted into the workspace, owner tiles on the sorted copy; the caller's arrays are not
+    touched and `out` does not depend on the order (fp32: bit for bit)."""
+    P, B, grid = 230_000, 8, (48, 40, 36)
+    d = D.make(n_points=P, n_in=3, n_out=3, batch=B, grid_n=48, seed=29, dtype=npdt)
+    rng = np.random.default_rng(4)
+    pts = d.points.copy()
+    pts[[3, 99_999]] = np.inf
+    pw = rng.uniform(0.5, 1.5, size=P).astype(npdt)
+    need = dpr_amd.workspace_bytes("raster", grid, P, B, 3, tdt, "chunked")
+    assert need > dpr_amd.workspace_bytes("raster", grid, P, B, 3, tdt, "chunked", coherent_points=True) + P * 3 * np.dtype(npdt).itemsize
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = dpr_amd.empty_grid(grid, B, tdt, dev)
+    tp, tw = T(pts, dev), T(pw, dev)
+    before = tp.clone()
+    dpr_amd.raster_(out, tp, T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev), tw,
+                    algo="chunked", workspace=ws)
+    assert torch.equal(torch.nan_to_num(tp), torch.nan_to_num(before))
+    ref = oracle.raster(grid, pts, d.rotations, d.translations, d.backgrounds, d.weights, pw, dtype=npdt, threaded=True)
+    assert_close(out, ref, tol(npdt, "out"), "out")
+    if npdt == np.float32:
+        sp, _, sw = dpr_amd.sort_points(tp, tw)
+        out2 = dpr_amd.raster((grid), sp, T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
+                              T(d.weights, dev), sw, algo="chunked", coherent_points=True)
+        assert torch.equal(out, out2)
