@@ -277,7 +277,8 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     // pullback over 16+ poses of a large 3-D cloud in ANY order: sort inside the call, direct kernels on the
     // sorted copy (pullback3d_sorts above): 1e7 x 16 -> 256^3 3.0 vs 4.4 ms tiled, x 64 10.3 vs 17.3; 3e6 x 16
     // 1.55 vs 1.77
-    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent && B >= 16 && P >= 3000000 &&
+    // (1e6 points: from 64 poses on -- 1.18 vs 1.60 ms on 128^3, 3.7 vs 4.6 on 256^3; fp64 on 128^3 1.08x behind)
+    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent && ((B >= 16 && P >= 3000000) || (B >= 64 && P >= 1000000)) &&
         pullback3d_sorts(*flags, grid, P, B) && owner_supported(grid))
         return DPR_ALGO_CHUNKED;
     // forward over 32+ poses of a large DENSE 3-D cloud in any order: sort inside the call, owner tiles on the
