@@ -281,6 +281,12 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent && ((B >= 16 && P >= 3000000) || (B >= 64 && P >= 1000000)) &&
         pullback3d_sorts(*flags, grid, P, B) && owner_supported(grid))
         return DPR_ALGO_CHUNKED;
+    // forward over 16+ poses of a cloud in any order that is SPARSE on a 3-D grid: sort inside the call, chunk lists
+    // on the sorted copy (profiles/r05_unsorted_batches.txt: 3e5-1e6 points -> 256^3 / 384^3, 16-64 poses: 1.1-2.5x
+    // ahead of the tiled and ATOMIC kernels on clouds that fill the grid; the clustered cloud at 1e6 -> 256^3 0.82-0.88x)
+    if (op == DPR_OP_RASTER && n_out == 3 && !coherent && !(*flags & 3u) && B >= 16 && P >= 200000 &&
+        raster3d_sorts(*flags, grid, G, P, B) && chunked3d_lists(grid, G, P, B) && owner_supported(grid))
+        return DPR_ALGO_CHUNKED;
     // forward over 32+ poses of a large DENSE 3-D cloud in any order: sort inside the call, owner tiles on the
     // sorted copy -- where the owner tiles win on coherent input (chunked3d_preferred's dense rule).  The tiled
     // path bins such batches in pose groups and is hard to beat in fp32: 1e7 points -> 256^3, as-generated
@@ -372,12 +378,12 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
             if constexpr (NO == 2)                                                             \
                 return raster_chunkown<T, NI>(st, flags, grid, G, P, B, out, points, rot, trans, \
                                               bg, ow, pw, ws, ws_bytes);                       \
-            else if (chunked3d_lists(grid, G, P, B))                                           \
-                return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot,   \
-                                                 trans, bg, ow, pw, ws, ws_bytes);             \
             else if (P > 0 && raster3d_sorts(flags, grid, G, P, B))                           \
                 return raster_owner_sorted<T>(st, flags, grid, G, P, B, out, points, rot,      \
                                               trans, bg, ow, pw, ws, ws_bytes);                \
+            else if (chunked3d_lists(grid, G, P, B))                                           \
+                return raster_chunked<T, NI, NO>(st, flags, grid, G, P, B, out, points, rot,   \
+                                                 trans, bg, ow, pw, ws, ws_bytes);             \
             else                                                                               \
                 return raster_owner<T>(st, flags, grid, G, P, B, out, points, rot, trans, bg,  \
                                        ow, pw, ws, ws_bytes);                                  \
@@ -489,12 +495,12 @@ __global__ __launch_bounds__(256) void k_unsort3(int64_t P, const uint32_t* __re
     for (int j = 0; j < 3; ++j) __builtin_nontemporal_store(gs[q * 3 + j], &d_pts[p * 3 + j]);
     if (d_pw) __builtin_nontemporal_store(gws[q], &d_pw[p]);
 }
-// The forward likewise (owner-computes tiles on the sorted copy; nothing to bring back): only where the owner
-// tiles are the kernel -- not the chunk lists of a sparse cloud, whose 64-point chunks want the same order but are
-// not worth a sort.
+// The forward likewise (owner-computes tiles, or the chunk lists of a sparse cloud, on the sorted copy; nothing to
+// bring back).
 static bool raster3d_sorts(unsigned flags, const int64_t* grid, int64_t G, int64_t P, int64_t B) {
-    return !(flags & DPR_FLAG_COHERENT_POINTS) && B >= 8 && P >= 200000 && P < ((int64_t)1 << 32) &&
-           !chunked3d_lists(grid, G, P, B);
+    (void)grid;
+    (void)G;
+    return !(flags & DPR_FLAG_COHERENT_POINTS) && B >= 8 && P >= 200000 && P < ((int64_t)1 << 32);
 }
 struct SortedFwdPlan {
     size_t off_pts, off_pw, off_perm, off_sort, off_own, own_bytes, total;
@@ -507,7 +513,9 @@ static SortedFwdPlan sorted_fwd_plan(size_t elem, const int64_t* grid, int64_t P
     pl.off_perm = o; o += s3_align((size_t)P * 4);
     pl.off_sort = o; o += s3_align(sort_workspace_bytes(P));
     pl.off_own = o;
-    pl.own_bytes = owner_workspace_bytes(DPR_OP_RASTER, grid, P, B);
+    int64_t G = grid[0] * grid[1] * grid[2];
+    pl.own_bytes = chunked3d_lists(grid, G, P, B) ? chunked_workspace_bytes(3, grid, P, B)
+                                                  : owner_workspace_bytes(DPR_OP_RASTER, grid, P, B);
     o += s3_align(pl.own_bytes == (size_t)-1 ? 0 : pl.own_bytes);
     pl.total = o;
     return pl;
@@ -529,8 +537,11 @@ static int raster_owner_sorted(hipStream_t st, unsigned flags, const int64_t* gr
                                      ws + pl.off_sort, sort_workspace_bytes(P), nullptr, true))
         return rc;
     stage_mark(st);
-    return raster_owner<T>(st, (flags | DPR_FLAG_COHERENT_POINTS) & ~3u, grid, G, P, B, out, spts, rot, trans, bg, ow,
-                           spw, ws + pl.off_own, pl.own_bytes);
+    const unsigned f = (flags | DPR_FLAG_COHERENT_POINTS) & ~3u;
+    if (chunked3d_lists(grid, G, P, B))
+        return raster_chunked<T, 3, 3>(st, f, grid, G, P, B, out, spts, rot, trans, bg, ow, spw, ws + pl.off_own,
+                                       pl.own_bytes);
+    return raster_owner<T>(st, f, grid, G, P, B, out, spts, rot, trans, bg, ow, spw, ws + pl.off_own, pl.own_bytes);
 }
 
 template <typename T>
@@ -681,7 +692,7 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
         if (op == DPR_OP_PULLBACK && n != (size_t)-1 && P > 0 && pullback3d_sorts(flags, grid, P, B))
             n = sorted3d_plan(sizeof(T), grid, P, B).total;
         if (op == DPR_OP_RASTER && n != (size_t)-1 && P > 0 && raster3d_sorts(flags, grid, G, P, B))
-            n = sorted_fwd_plan(sizeof(T), grid, P, B).total;
+            n = sorted_fwd_plan(sizeof(T), grid, P, B).total;  // (owner tiles or chunk lists behind the sort)
         if (n == (size_t)-1)
             fail(DPR_ERR_UNSUPPORTED_ALGO, "DPR_ALGO_CHUNKED: grid needs too many tiles or P >= 2^32");
         return n;

@@ -154,7 +154,9 @@ def test_auto_algorithm_and_workspace_queries_need_no_device():
     assert dpr_amd.resolve_algo("raster", (128, 128, 128), 50_000, 1, 3) == "atomic"
     # 3-D chunk lists: forward over several poses of a coherent cloud that is sparse on the grid
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3, coherent_points=True) == "chunked"
-    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3) == "tiled"
+    # (without the flag: sorted inside the call from 16 poses and 2e5 points on)
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 8, 3) == "tiled"
     # dense coherent cloud, two poses or more, >= 1024 owner tiles, 0.4-2 points per voxel: owner-computes forward
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 16, 3, coherent_points=True) == "chunked"
     assert dpr_amd.resolve_algo("raster", (256,) * 3, 10_000_000, 2, 3, coherent_points=True) == "chunked"

@@ -866,7 +866,11 @@ def test_c5_full_batch_64_poses_against_the_oracle(oracle, dev):
     import bench
 
     P, n, B = 5_000_000, 512, 64
-    assert dpr_amd.resolve_algo("raster", (n, n, n), P, B, 3) == "tiled"
+    # (5 M points are SPARSE on 512^3 -- one per 27 voxels: since round 5 AUTO sorts such a batch inside the call
+    # and runs the chunk lists; the config's own 50 M points stay on the tiled path)
+    assert dpr_amd.resolve_algo("raster", (n, n, n), P, B, 3) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (n, n, n), 50_000_000, B, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (n, n, n), P, B, 3) == "chunked"
     np_pts = bench.synth_points("C5")[:P]
     np_R, np_t = bench.synth_poses("C5", B, seed=1)
     pts, R, t = T(np_pts, dev), T(np_R, dev), T(np_t, dev)

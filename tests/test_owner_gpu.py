@@ -280,3 +280,14 @@ def test_unsorted_batch_is_sorted_inside_the_forward(oracle, dev, npdt, tdt):
         out2 = dpr_amd.raster((grid), sp, T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev),
                               T(d.weights, dev), sw, algo="chunked", coherent_points=True)
         assert torch.equal(out, out2)
+    # the same cloud SPARSE on a larger grid (P * 10 <= G): the chunk lists behind the same sort
+    grid2 = (160, 160, 96)
+    need2 = dpr_amd.workspace_bytes("raster", grid2, P, B, 3, tdt, "chunked")
+    assert need2 > dpr_amd.workspace_bytes("raster", grid2, P, B, 3, tdt, "chunked", coherent_points=True) + P * 3 * np.dtype(npdt).itemsize
+    out3 = dpr_amd.empty_grid(grid2, B, tdt, dev)
+    dpr_amd.raster_(out3, tp, T(d.rotations, dev), T(d.translations, dev), T(d.backgrounds, dev), T(d.weights, dev), tw,
+                    algo="chunked", workspace=torch.empty(need2, dtype=torch.uint8, device=dev))
+    ref3 = oracle.raster(grid2, pts, d.rotations, d.translations, d.backgrounds, d.weights, pw, dtype=npdt, threaded=True)
+    assert_close(out3, ref3, tol(npdt, "out"), "out (sparse)")
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 16, 3) == "chunked"
+    assert dpr_amd.resolve_algo("raster", (256,) * 3, 1_000_000, 8, 3) == "tiled"

@@ -29,12 +29,17 @@ def run(pts, n, B, algo):
     return e0.elapsed_time(e1) / N
 
 print(f"# {'forward' if FWD else 'pullback'}: {'P':>9s} {'grid':>5s} {'B':>3s} {'chunked':>9s} {'tiled':>9s} {'atomic':>9s}  AUTO   ({str(dt)[6:]}, as-generated order)", flush=True)
-for P in (1_000_000, 3_000_000, 10_000_000):
+SPARSE = "--sparse" in sys.argv  # (forward: clouds sparse on the grid -- the chunk lists behind the sort)
+for P in ((300_000, 1_000_000) if SPARSE else (1_000_000, 3_000_000, 10_000_000)):
     g0 = torch.Generator(device=dev); g0.manual_seed(0)
     pts = (0.4 * torch.randn(P, 3, device=dev, generator=g0)).to(dt)
-    for n in (128, 256):
+    if "--uniform" in sys.argv:
+        pts = (1.1 * torch.rand(P, 3, device=dev, generator=g0) - 0.55).to(dt)
+    if "--tight" in sys.argv:
+        pts = (0.1 * torch.randn(P, 3, device=dev, generator=g0)).to(dt)
+    for n in ((256, 384) if SPARSE else (128, 256)):
         for B in (8, 16, 32, 64):
             if n ** 3 * B * (8 if dt == torch.float64 else 4) > 12e9:
                 continue
-            ts = [run(pts, n, B, a) for a in (("chunked", "tiled") if FWD else ("chunked", "tiled", "atomic"))] + [float("nan")]
+            ts = [run(pts, n, B, a) for a in ("chunked", "tiled", "atomic")]
             print(f"  {P:9d} {n:5d} {B:3d} {ts[0]:9.3f} {ts[1]:9.3f} {ts[2]:9.3f}  {dpr.resolve_algo('raster' if FWD else 'pullback', (n, n, n), P, B, 3)}", flush=True)
