@@ -278,7 +278,9 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     // sorted copy (pullback3d_sorts above): 1e7 x 16 -> 256^3 3.0 vs 4.4 ms tiled, x 64 10.3 vs 17.3; 3e6 x 16
     // 1.55 vs 1.77
     // (1e6 points: from 64 poses on -- 1.18 vs 1.60 ms on 128^3, 3.7 vs 4.6 on 256^3; fp64 on 128^3 1.08x behind)
-    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent && ((B >= 16 && P >= 3000000) || (B >= 64 && P >= 1000000)) &&
+    // (1e7 points: from 8 poses on -- 2.3 vs 2.7 ms on 256^3, level on 128^3; fp64 3.6 vs 4.5 / 3.1 vs 3.4)
+    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent &&
+        ((B >= 16 && P >= 3000000) || (B >= 64 && P >= 1000000) || (B >= 8 && P >= 10000000)) &&
         pullback3d_sorts(*flags, grid, P, B) && owner_supported(grid))
         return DPR_ALGO_CHUNKED;
     // forward over 16+ poses of a cloud in any order that is SPARSE on a 3-D grid: sort inside the call, chunk lists

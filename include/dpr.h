@@ -118,8 +118,10 @@ extern "C" {
                               is this one (it reads nothing a forward could leave).
                               Without the flag, from 8 poses and 2e5 points on, the 3-D calls
                               Hilbert-sort the cloud into the workspace themselves (the workspace
-                              query says how much more that takes) and AUTO picks them for >= 16
-                              (pullback) / >= 32 (forward, dense clouds) poses of >= 3e6 points.
+                              query says how much more that takes) and AUTO picks them for large
+                              batches: the pullback from 16 poses of 3e6 points on (8 of 1e7, 64 of
+                              1e6), the forward from 32 poses of a dense cloud of 3e6 points and
+                              from 16 poses of a sparse one (P * 10 <= G) of 2e5 points.
                               Correct for any point order. */
 
 /* SUMMATION ORDER.  The reference promises none for its float atomics (src/raster.jl:64) and sums

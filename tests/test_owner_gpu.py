@@ -249,7 +249,8 @@ def test_unsorted_batch_is_sorted_inside_the_pullback(oracle, dev, npdt, tdt, wi
         assert_close(getattr(pb, name), getattr(ref, name), tol(npdt, "pose"), name)
     # AUTO takes this path for 16+ poses of 3e6+ points in any order
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 16, 3) == "chunked"
-    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 8, 3) == "tiled"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 10_000_000, 8, 3) == "chunked"
+    assert dpr_amd.resolve_algo("pullback", (256,) * 3, 5_000_000, 8, 3) == "tiled"
     assert dpr_amd.resolve_algo("pullback", (256,) * 3, 1_000_000, 16, 3) != "chunked"
 
 
