@@ -17,6 +17,7 @@ STAGES = {
     ("pullback", "chunked"): ["direct_gather", "pose_reduce"],
     # ... of a cloud not flagged coherent over >= 8 poses (sorted inside the call): pass algo="chunked_sorting"
     ("pullback", "chunked_sorting"): ["sort", "direct_gather", "pose_reduce", "unsort"],
+    ("raster", "chunked_sorting"): ["sort", "boxes", "plan", "own_splat", "combine"],
     ("pullback", "tiled"): ["count", "scan", "scatter", "tile_gather", "unpermute", "pose_reduce"],
     # DPR_ALGO_TILED with coherent_points=True (local binning): pass algo="tiled_local"
     ("raster", "tiled_local"): ["clear", "bin_local", "runscan", "tile_splat", "halo"],
