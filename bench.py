@@ -776,6 +776,51 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
                 "value": round(P * Bb / el_auto / 1e6, 3), "unit": "M point-poses/s",
                 "tiled_pair_ms_per_step": round(el_tiled * 1e3, 4),
                 "tiled_pair_is": "the same step with algo = tiled for both calls (AUTO's choice before round 5)"}
+            # ... and 16 poses of the cloud in its AS-GENERATED order (no flag): from 16 poses on AUTO sorts a
+            # 3-D cloud inside the pullback call and runs the same direct kernels on the copy
+            del outb, gb
+            Bb = 16
+            Rb = torch.linalg.qr(torch.randn(Bb, 3, 3, device=device, dtype=tdt, generator=gen))[0]
+            tb = 0.05 * torch.randn(Bb, 3, device=device, dtype=tdt, generator=gen)
+            outb = dpr_amd.empty_grid(grid, Bb, tdt, device)
+            gb = dpr_amd.empty_grid(grid, Bb, tdt, device)
+            gb.normal_(generator=gen)
+            points, coherent_kw = points_random, {}
+            algo_fr, algo_br = (dpr_amd.resolve_algo(op, grid, P, Bb, n_in) for op in ("raster", "pullback"))
+
+            def batch_ms_random(algo_f, algo_b):
+                wsb = torch.empty(max(16, *(dpr_amd.workspace_bytes(op, grid, P, Bb, n_in, tdt, a)
+                                            for op, a in (("raster", algo_f), ("pullback", algo_b)))),
+                                  dtype=torch.uint8, device=device)
+
+                def stepb():
+                    dpr_amd.raster_(outb, points, Rb, tb, algo=algo_f, workspace=wsb)
+                    dpr_amd.raster_pullback_(gb, points, Rb, tb, ds_dpoints=fused[: P * n_in].view(P, n_in),
+                                             ds_dpoint_weight=fused[P * n_in:], algo=algo_b, workspace=wsb)
+                for _ in range(2):
+                    stepb()
+                nb_steps = max(5, args.steps // 6)
+                elb = []
+                for _rep in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(nb_steps):
+                        stepb()
+                    torch.cuda.synchronize()
+                    elb.append((time.perf_counter() - t0) / nb_steps)
+                del wsb
+                return float(np.median(elb))
+
+            el_auto_r = batch_ms_random(algo_fr, algo_br)
+            el_tiled_r = batch_ms_random("tiled", "tiled")
+            line["batch_of_16_poses_any_order"] = {
+                "what": "the C3 cloud in as-generated order (no flags), 16 poses per call, raster! + raster_pullback! "
+                        "through the plain entry points with DPR_ALGO_AUTO; median of 3 loops",
+                "algo": {"raster": algo_fr, "pullback": algo_br},
+                "ms_per_step": round(el_auto_r * 1e3, 4),
+                "value": round(P * Bb / el_auto_r / 1e6, 3), "unit": "M point-poses/s",
+                "tiled_pair_ms_per_step": round(el_tiled_r * 1e3, 4),
+                "tiled_pair_is": "the same step with algo = tiled for both calls (AUTO's choice before round 5)"}
             del outb, gb
         line["coherent_input"] = coh
         points = points_random
