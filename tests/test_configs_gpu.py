@@ -780,6 +780,9 @@ def test_bench_pose_exchange_step_over_a_one_rank_rccl_group():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["steps"] == 3
     ex = line["config"]["exchange"]
     assert "all-reduce(sum)" in ex and "(nccl)" in ex and "overlapped" in ex, ex
+    # what the driver's SCALE record checks an N-rank run with: the ranks RCCL saw, and its version
+    assert line["config"]["ranks_seen"] == 1
+    assert str(line["config"]["rccl_version"])[0].isdigit(), line["config"]["rccl_version"]
     # and serialised (no double buffer): the all-reduce completes inside each step
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C4",
                          "--poses", "6", "--force-exchange", "--no-overlap-exchange", "--steps", "2",
