@@ -21,6 +21,7 @@ ERR_HIP = -4
 ERR_UNSUPPORTED_ALGO = -5
 OP_RASTER = 0
 OP_PULLBACK = 1
+OP_RESIDUAL_PULLBACK = 2
 ALGO_AUTO = 0
 ALGO_ATOMIC = 1
 ALGO_TILED = 2

@@ -131,7 +131,7 @@ static bool chunkown_preferred(int op, int n_in, int n_out, const int64_t* grid,
 // which forward the 3-D algorithm runs: chunk lists (small tiles) for a sparse cloud over several
 // poses, owner-computes large tiles otherwise
 static bool chunked3d_lists(const int64_t* grid, int64_t G, int64_t P, int64_t B) {
-    static const bool off = getenv("DPR_CHUNKED3D_NO_LISTS") != nullptr;  // (experiments: owner tiles everywhere)
+    static const bool off = env_knob("DPR_CHUNKED3D_NO_LISTS", 0, 0, 1) != 0;  // (experiments: owner tiles everywhere)
     return !off && B >= 4 && P * 10 <= G && chunked_supported(3, grid);
 }
 static bool chunked3d_preferred(int op, int n_out, const int64_t* grid, int64_t G, int64_t P,
@@ -237,8 +237,14 @@ template <int NO> static GridDesc<NO> make_grid(const int64_t* grid, int64_t G) 
 // arguments both calls share -- and when the pair's algorithm cannot share (atomic; tiled with
 // B > 1), AUTO drops the two flags instead of failing: each call then works on its own.
 // An explicit algorithm keeps the strict behaviour (error).
+//
+// op == DPR_OP_RESIDUAL_PULLBACK: a pullback that forms its sensitivity from (out, target).  The 3-D
+// DPR_ALGO_CHUNKED pullback (direct gathers) has no such variant, so AUTO never picks it for this op -- the
+// rules that would are skipped and a KEEP / REUSE pair keeps its flags (the tiled pair shares as usual).
 static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* grid, int64_t P,
                         int64_t B, int64_t G, unsigned* flags) {
+    const bool residual = op == DPR_OP_RESIDUAL_PULLBACK;
+    if (residual) op = DPR_OP_PULLBACK;
     if (!dims_have_all_algos(n_in, n_out)) {
         // direct kernels only: AUTO drops the sharing flags (nothing to keep), an explicit other
         // algorithm is refused by the dispatch below
@@ -249,7 +255,8 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     const bool coherent = (*flags & DPR_FLAG_COHERENT_POINTS) != 0;
     // a coherent cloud on a 3-D grid, one pose: the pullback gathers directly and reads nothing a
     // forward could keep -- the pair has nothing to share, each call picks its own best path
-    if ((*flags & 3u) && direct3d_preferred(DPR_OP_PULLBACK, n_out, grid, P, B, *flags)) *flags &= ~3u;
+    // (a residual pullback cannot take that path: its pair stays a tiled pair)
+    if ((*flags & 3u) && !residual && direct3d_preferred(DPR_OP_PULLBACK, n_out, grid, P, B, *flags)) *flags &= ~3u;
     if (*flags & 3u) {
         if (chunkown_preferred(-1, n_in, n_out, grid, G, P, B, coherent)) return DPR_ALGO_CHUNKED;
         // tiled: one pose, or a batch on a grid too large for pose groups (every pose keeps its
@@ -265,7 +272,7 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     // forward over several poses of a coherent cloud on a large 3-D grid: owner-computes tiles
     if (chunked3d_preferred(op, n_out, grid, G, P, B, *flags)) return DPR_ALGO_CHUNKED;
     // pullback of one pose of a coherent cloud on a 3-D grid: direct gathers in cloud order
-    if (direct3d_preferred(op, n_out, grid, P, B, *flags)) return DPR_ALGO_CHUNKED;
+    if (!residual && direct3d_preferred(op, n_out, grid, P, B, *flags)) return DPR_ALGO_CHUNKED;
     // pullback over many (>= 32) poses of a coherent cloud on a grid without pose groups: the direct
     // kernel (point in registers across the poses, cache-friendly gathers on sorted input) is
     // never more than ~6 % behind the tiled pipeline there and up to 1.9x ahead (clustered cloud,
@@ -279,7 +286,7 @@ static int resolve_algo(int algo, int op, int n_in, int n_out, const int64_t* gr
     // 1.55 vs 1.77
     // (1e6 points: from 64 poses on -- 1.18 vs 1.60 ms on 128^3, 3.7 vs 4.6 on 256^3; fp64 on 128^3 1.08x behind)
     // (1e7 points: from 8 poses on -- 2.3 vs 2.7 ms on 256^3, level on 128^3; fp64 3.6 vs 4.5 / 3.1 vs 3.4)
-    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent &&
+    if (op == DPR_OP_PULLBACK && n_out == 3 && !coherent && !residual &&
         ((B >= 16 && P >= 3000000) || (B >= 64 && P >= 1000000) || (B >= 8 && P >= 10000000)) &&
         pullback3d_sorts(*flags, grid, P, B) && owner_supported(grid))
         return DPR_ALGO_CHUNKED;
@@ -608,7 +615,8 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     if (int rc = check_alignment<T>(ws, {g, points, rot, trans, ow, pw, d_pts, d_rot, d_trans, d_bg,
                                          d_ow, d_pw, rs.target, rs.loss}))
         return rc;
-    algo = resolve_algo(algo, DPR_OP_PULLBACK, n_in, n_out, grid, P, B, G, &flags);
+    algo = resolve_algo(algo, rs.target ? DPR_OP_RESIDUAL_PULLBACK : DPR_OP_PULLBACK, n_in, n_out, grid, P, B, G,
+                        &flags);
     stage_mark(st);
 #define DPR_CASE(NI, NO)                                                                         \
     if (n_in == NI && n_out == NO) {                                                             \
@@ -665,11 +673,18 @@ static size_t workspace_impl(int op, int algo, unsigned flags, int n_in, int n_o
                              const int64_t* grid, int64_t P, int64_t B) {
     int64_t G = 0;
     if (check_common(n_in, n_out, grid, P, B, &G)) return (size_t)-1;
-    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK) {
+    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK && op != DPR_OP_RESIDUAL_PULLBACK) {
         fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
         return (size_t)-1;
     }
     algo = resolve_algo(algo, op, n_in, n_out, grid, P, B, G, &flags);
+    if (op == DPR_OP_RESIDUAL_PULLBACK) {
+        if (algo == DPR_ALGO_CHUNKED && n_out == 3) {
+            fail(DPR_ERR_UNSUPPORTED_ALGO, "the residual pullback has no 3-D DPR_ALGO_CHUNKED variant");
+            return (size_t)-1;
+        }
+        op = DPR_OP_PULLBACK;  // (same buffers as the plain pullback of the algorithm chosen for it)
+    }
     if (algo == DPR_ALGO_ATOMIC) return 0;
     if (!dims_have_all_algos(n_in, n_out)) {
         fail(DPR_ERR_UNSUPPORTED_ALGO, "(n_in, n_out) = (%d, %d) runs on DPR_ALGO_ATOMIC only", n_in,
@@ -715,7 +730,7 @@ int dpr_resolve_algo_ex(int op, unsigned flags, int n_in, int n_out, const int64
                         int64_t P, int64_t B) {
     int64_t G = 0;
     if (int rc = dpr::check_common(n_in, n_out, grid, P, B, &G)) return rc;
-    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK)
+    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK && op != DPR_OP_RESIDUAL_PULLBACK)
         return dpr::fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
     return dpr::resolve_algo(DPR_ALGO_AUTO, op, n_in, n_out, grid, P, B, G, &flags);
 }
@@ -724,7 +739,7 @@ int dpr_resolve_flags_ex(int op, unsigned flags, int n_in, int n_out, const int6
                          int64_t P, int64_t B) {
     int64_t G = 0;
     if (int rc = dpr::check_common(n_in, n_out, grid, P, B, &G)) return rc;
-    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK)
+    if (op != DPR_OP_RASTER && op != DPR_OP_PULLBACK && op != DPR_OP_RESIDUAL_PULLBACK)
         return dpr::fail(DPR_ERR_INVALID_ARG, "unknown op %d", op);
     (void)dpr::resolve_algo(DPR_ALGO_AUTO, op, n_in, n_out, grid, P, B, G, &flags);
     return (int)(flags & 0xffffu);

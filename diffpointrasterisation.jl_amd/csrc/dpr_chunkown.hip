@@ -169,28 +169,25 @@ __device__ __forceinline__ bool co_load_chunk(const T* __restrict__ points,
     return any;
 }
 
-// max |point_weight| over the chunk (1 without point weights), identical in every thread; NaN
-// and Inf come out non-finite.  `smax`: one float per wave; ends with a barrier.
+// (an upper bound within 2^-7 of) max |point_weight| over the chunk (1 without point weights), identical
+// in every thread; NaN and Inf come out non-finite -- and so does a chunk whose non-zero weights span
+// more than 2^10 (wrange_*, fix_guard_range in dpr_device.h: its fp32 sums then run on f64 atomics
+// instead of fixed point).  `smax`: one word per wave; ends with a barrier.
 template <typename T, bool HAS_PW>
 __device__ __forceinline__ float co_max_abs_weight(const T (&w)[kCOPPT], const bool (&live)[kCOPPT],
                                                    float* smax) {
     if (!HAS_PW) return 1.f;
-    uint32_t m = 0;  // bit patterns of non-negative floats: unsigned order, NaN above Inf
+    uint32_t key = 0;
 #pragma unroll
-    for (int k = 0; k < kCOPPT; ++k) {
-        const uint32_t bits = __float_as_uint(fabsf((float)w[k]));
-        m = (live[k] && bits > m) ? bits : m;
-    }
-    m = wave_max<uint32_t>(m);
-    if ((threadIdx.x & (kWave - 1)) == 0) smax[threadIdx.x / kWave] = __uint_as_float(m);
+    for (int k = 0; k < kCOPPT; ++k) key = live[k] ? wrange_merge(key, wrange_key((float)w[k])) : key;
+    key = wrange_wave(key);
+    uint32_t* const sk = (uint32_t*)smax;
+    if ((threadIdx.x & (kWave - 1)) == 0) sk[threadIdx.x / kWave] = key;
     __syncthreads();
     uint32_t r = 0;
 #pragma unroll
-    for (int q = 0; q < kCOWaves; ++q) {
-        const uint32_t bits = __float_as_uint(smax[q]);
-        r = bits > r ? bits : r;
-    }
-    return __uint_as_float(r);
+    for (int q = 0; q < kCOWaves; ++q) r = wrange_merge(r, sk[q]);
+    return wrange_guarded_max(r >> 16, r & 0xffffu);
 }
 
 // Pixel rectangle [lo, hi] (inclusive, clipped to the grid) that bounds every in-grid neighbour
@@ -299,10 +296,7 @@ __device__ __forceinline__ bool sort_header_ok(const SortHeader* hdr, const Sort
 
 // DPR_FIXED_POINT=0 (experiment knob, read once): f64 LDS accumulators for fp32 data too
 static int co_fixed_point() {
-    static const int v = [] {
-        const char* e = getenv("DPR_FIXED_POINT");
-        return (e && atoi(e) == 0) ? 0 : 1;
-    }();
+    static const int v = env_knob("DPR_FIXED_POINT", 1, 0, 1);
     return v;
 }
 
@@ -1016,7 +1010,7 @@ static COPlan co_plan(size_t elem, int op, unsigned flags, int n_in, int64_t P, 
 template <typename T>
 static int co_sort(hipStream_t st, int n_in, int64_t P, int64_t B, const T* points, const T* pw, T* spts, T* spw,
                    uint32_t* perm, char* scratch) {
-    static const int mode = getenv("DPR_CO_SORT") ? atoi(getenv("DPR_CO_SORT")) : 0;  // 1: cells, 2: radix (A/B runs)
+    static const int mode = env_knob("DPR_CO_SORT", 0, 0, 2);  // 1: cells, 2: radix (A/B runs)
     const bool radix = mode == 2 || (mode == 0 && B > 96);
     if (!radix) return coarse_sort_with_perm<T>(st, n_in, P, points, pw, spts, spw, perm, scratch);
     return sort_points_impl<T>((void*)st, n_in, P, points, spts, perm, pw, spw, scratch, sort_workspace_bytes(P),

@@ -185,6 +185,47 @@ struct FixScale {
     double inv;  // 2^-sexp
 };
 constexpr double kFixMagic = 6755399441055744.0;  // 1.5 * 2^52
+// The scale comes from the LARGEST weight of the scope it is chosen for (the call on the tiled path, the
+// candidate chunks of a tile on the owner path, the 4096-point chunk on the 2-D chunk-owner path).  Where the
+// non-zero |point_weight| of that scope span more than 2^10 the scope uses f64 atomics instead: otherwise
+// cells that only small-weight points reach would lose relative precision against the reference's float
+// atomics (/root/reference/src/raster.jl:62-64), down to exactly 0 below 2^-38 of the largest weight.
+// With the guard every contribution keeps at least 28 bits (typically 39) below the SMALLEST weight.
+constexpr float kFixMaxWeightRange = 1024.f;
+// maxw, or +Inf (= no fixed point) when maxw > minw * range or either is NaN; minw = +Inf: no non-zero weight
+__device__ __forceinline__ float fix_guard_range(float maxw, float minw) {
+    return (maxw <= minw * kFixMaxWeightRange) ? maxw : __builtin_inff();
+}
+// Running (max, min non-zero) of |point_weight| in ONE register: a = upper 16 bits of |w| (sign 0, 8
+// exponent, 7 mantissa bits; NaN / Inf sort on top) -- high half: max a; low half: max of (0x10000 - a)
+// over a >= 1, i.e. the minimum turned into a maximum (0 = nothing but zeros seen).  Both halves merge
+// with one v_pk_max_u16.  The bounds that come back out are conservative by construction: wrange_max
+// >= every |w| (within 2^-7), wrange_min <= every non-zero |w| -- which is all the scale (an upper
+// bound of the contributions) and the range guard need.  (Two full-precision words cost the binning
+// kernels two live registers and pushed three of them into scratch.)
+typedef unsigned short dpr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wrange_key(float w) {
+    const uint32_t a = __float_as_uint(fabsf(w)) >> 16;
+    return (a << 16) | (((a - 1u) ^ 0xffffu) & 0xffffu);
+}
+__device__ __forceinline__ uint32_t wrange_merge(uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(dpr_u16x2, x),
+                                                                  __builtin_bit_cast(dpr_u16x2, y)));
+}
+__device__ __forceinline__ uint32_t wrange_wave(uint32_t key) {  // all 64 lanes must call
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) key = wrange_merge(key, (uint32_t)__shfl_xor((int)key, o, kWave));
+    return key;
+}
+// from the two halves (as published / reduced separately: hi = key >> 16, lo = key & 0xffff)
+__device__ __forceinline__ float wrange_max(uint32_t hi) { return __uint_as_float((hi + 1u) << 16); }
+__device__ __forceinline__ float wrange_min(uint32_t lo) {
+    return lo ? __uint_as_float((0x10000u - lo) << 16) : __builtin_inff();
+}
+// largest |point_weight| to scale by, or +Inf (f64 atomics) when the range guard trips
+__device__ __forceinline__ float wrange_guarded_max(uint32_t hi, uint32_t lo) {
+    return fix_guard_range(wrange_max(hi), wrange_min(lo));
+}
 constexpr int kFixNone = 1 << 30;  // "no fixed point" exponent
 // exponent sexp of the scale 2^sexp, or kFixNone
 __device__ __forceinline__ int fix_exponent(float maxw, uint32_t n, int enabled) {

@@ -151,11 +151,7 @@ int sort_points_impl(void* stream, int n_in, int64_t P, const T* points, T* poin
     // sort: points of one cell keep their order): the chunk-owner kernels need compact 4096-point chunks, not
     // sorted neighbours -- C4's share measured 6.20 / 6.22 / 6.12 / 6.31 / 10.4 ms per step at 8 / 6 / 5 / 4 / 3 bits
     // -- and 15 key bits are two radix passes instead of three (DPR_SORT_BITS: experiments).
-    static const int cbits = [] {
-        const char* v = getenv("DPR_SORT_BITS");
-        const int x = v ? atoi(v) : 5;
-        return x < 2 ? 2 : (x > 8 ? 8 : x);
-    }();
+    static const int cbits = env_knob("DPR_SORT_BITS", 5, 2, 8);
     const unsigned begin_bit = (!fine && n_in == 3) ? (unsigned)(3 * (8 - cbits)) : 0u;
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, perm,
                                              (size_t)P, begin_bit, (fine && n_in == 3) ? 30 : 24, st);

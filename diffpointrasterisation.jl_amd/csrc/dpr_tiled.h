@@ -3,12 +3,28 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dpr_device.h"
 
 namespace dpr {
 
 int fail(int code, const char* fmt, ...);
+
+// A/B switches of the experiments (profiles/r0N_experiments.md) are environment variables ONLY in builds
+// with -DDPR_EXPERIMENTS (`make EXPERIMENTS=1`); the shipped library compiles them out and runs the
+// defaults below, so no environment variable changes its algorithm choice or its numerics.  The one
+// exception, documented in include/dpr.h, is DPR_MAX_TILES (slab size of the tiled path; results unchanged).
+inline int env_knob(const char* name, int dflt, int lo, int hi) {
+#ifdef DPR_EXPERIMENTS
+    const char* v = getenv(name);
+    const int x = v ? atoi(v) : dflt;
+    return x < lo ? lo : (x > hi ? hi : x);
+#else
+    (void)name; (void)lo; (void)hi;
+    return dflt;
+#endif
+}
 
 // records hipEvent k (if stage timing is armed, see dpr_stage_timing_begin) on `st`
 void stage_mark(hipStream_t st);

@@ -27,7 +27,8 @@
 // wave-instruction (profiles/r01_microbench_lds_atomics.txt).  It also makes fp32 results
 // practically independent of the accumulation order.
 //
-// Experiment knobs (environment, compiled-in defaults are the measured best):
+// Experiment knobs (environment variables in -DDPR_EXPERIMENTS builds only -- `make EXPERIMENTS=1`; the
+// compiled-in defaults are the measured best and all the shipped library knows):
 //   DPR_SCATTER_WC=0     plain scatter instead of the write-combining one
 //   DPR_SPLAT_BLOCKED=0|1  lane-adjacent (strided) / blocked record assignment in k_tile_splat
 //                        (default: chosen on the device from the order of the cloud)
@@ -36,6 +37,7 @@
 //   DPR_FIXED_POINT=0    f64 LDS accumulators instead of 64-bit fixed point in the fp32 forward
 //   DPR_FUSE_TILESCAN=0  k_tilescan / k_runscan as launches of their own
 //   DPR_BIN_DIRECT_STORE=0  fp64 batches stage their records in LDS like everything else
+// Always read (test hook, documented in include/dpr.h; it moves slab boundaries, never results):
 //   DPR_MAX_TILES=n      tiles per launch sequence (default 32768): lets a test walk slabs on small grids
 #include <hip/hip_runtime.h>
 
@@ -324,15 +326,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// max |point_weight| of the records a binning kernel has seen, as the bit pattern of a
-// non-negative float (unsigned order = float order; NaN sorts above Inf): wave max, one global
-// atomicMax per wave.  All 64 lanes must call.
-__device__ __forceinline__ void publish_max_abs(uint32_t* __restrict__ dst, uint32_t bits) {
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        const uint32_t v = __shfl_xor(bits, o, kWave);
-        bits = v > bits ? v : bits;
-    }
+// max |point_weight| and min NON-ZERO |point_weight| of the records a binning kernel has seen (wrange_*,
+// dpr_device.h: one packed register per thread): wave reduction, then at most two global atomicMax per
+// wave -- dst[0] = high half (max), dst[1] = low half (the complemented min; 0 = no non-zero weight
+// seen), so that ONE zero-initialisation serves both words.  The tile kernels take the scale of their
+// fixed-point sums from the maximum and fall back to f64 atomics when the two are more than 2^10 apart
+// (fix_guard_range).  All 64 lanes must call.
+__device__ __forceinline__ void publish_one_max(uint32_t* __restrict__ dst, uint32_t bits) {
     // The running maximum is READ first (device scope, past the non-coherent caches) and the atomic
     // only issued when this wave raises it: thousands of waves doing an atomicMax on ONE address
     // serialise in a single L2 channel -- 39 000 of them took ~0.39 ms at the end of k_bin_local
@@ -342,8 +342,19 @@ __device__ __forceinline__ void publish_max_abs(uint32_t* __restrict__ dst, uint
         bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(dst, bits);
 }
-template <typename T> __device__ __forceinline__ uint32_t abs_bits(T w) {
-    return __float_as_uint(fabsf((float)w));  // (fp64 data does not use the fixed-point path)
+__device__ __forceinline__ void publish_max_abs(uint32_t* __restrict__ dst, uint32_t key) {
+    key = wrange_wave(key);
+    publish_one_max(dst, key >> 16);
+    publish_one_max(dst + 1, key & 0xffffu);
+}
+// |out_weight| * (upper bound of) max |point_weight| for fix_scale, or +Inf (= f64 atomics) when the
+// weights of the call span more than kFixMaxWeightRange; w[0] / w[1] as published above
+__device__ __forceinline__ float guarded_max_weight(float ow_abs, const uint32_t* __restrict__ w, bool has_pw) {
+    if (!has_pw) return ow_abs;
+    return ow_abs * wrange_guarded_max(w[0], w[1]);
+}
+template <typename T> __device__ __forceinline__ uint32_t abs_key(T w) {
+    return wrange_key((float)w);  // (fp64 data does not use the fixed-point path)
 }
 
 // ------------------------------------------------------------------ K1: count
@@ -799,7 +810,7 @@ __global__ __launch_bounds__(1024) void k_colscan(uint32_t* __restrict__ counts,
                                                   uint32_t* __restrict__ totals,
                                                   uint32_t* __restrict__ zero_word = nullptr) {
     // (max |point_weight| bits: published by the scatter that follows with atomicMax)
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x < 2) zero_word[threadIdx.x] = 0u;  // (max, ~min)
     // A thread owns `rows` consecutive rows of one column.  Its loads are issued kRowBatch at a
     // time (one row per iteration was a chain of 2 x rows dependent round trips: 9.2 us for the
     // 512 x 2048 table of C3, 16 rows per thread); when the rows fit one batch -- up to 512 count
@@ -880,7 +891,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
     // latter to the spare slot P when the point has no in-range voxel) so that the wait for
     // the prefetched point is a counted vmcnt that never covers the scattered store.
     if (lo >= hi) return;
-    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of k_tile_splat's fixed point)
+    uint32_t wkey = 0;  // max / min |point_weight| of the binned points (wrange_*: k_tile_splat's fixed point)
     int64_t p = lo + threadIdx.x;
     T nxt[NI], nxt_w = T(1);
     {
@@ -912,7 +923,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
         valid = tl >= 0;  // (a point of another slab is no point of this launch)
         uint32_t pos = (uint32_t)P;  // spare slot
         if (valid) pos = atomicAdd(&cursor[tl], 1u);
-        if (HAS_PW && valid) max_w = abs_bits(w) > max_w ? abs_bits(w) : max_w;
+        if (HAS_PW && valid) wkey = wrange_merge(wkey, abs_key(w));
         Rec4<T> r;
 #pragma unroll
         for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[(j < NI) ? j : 0] : T(0);
@@ -927,7 +938,7 @@ __global__ __launch_bounds__(kBinThreads) void k_scatter(
             if (ds_dpw) ds_dpw[pc] = T(0);
         }
     }
-    if (HAS_PW) publish_max_abs(maxpw, max_w);
+    if (HAS_PW) publish_max_abs(maxpw, wkey);
 }
 
 // ------------------------------------------------------------------ K3': write-combining scatter
@@ -959,7 +970,7 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
     }
     static_assert(!(W3 && HAS_PW), "compact records carry no point weight");
     constexpr int PPT = S / kWcThreads;  // points per thread per sub-chunk
-    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of k_tile_splat's fixed point)
+    uint32_t wkey = 0;  // max / min |point_weight| of the binned points (wrange_*: k_tile_splat's fixed point)
     // Pose group (nb > 1): the S points of a sub-chunk stay in registers while the poses of the
     // group are binned one after the other, each into its own NT bins -- the runs that are
     // written out stay as long as in the single-pose case, the points are read once per group.
@@ -1031,53 +1042,57 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
 #define DPR_WC_PREFETCH 1
 #endif
     constexpr bool kPrefetch = DPR_WC_PREFETCH && (!GROUP || DPR_GROUP_PREFETCH);
-    T nxt_pt[kPrefetch ? PPT : 1][NI], nxt_w[kPrefetch ? PPT : 1];
-    if constexpr (kPrefetch) {
+    // Everything per point is addressed as (sub-chunk base: uniform, 64-bit, in scalar registers) +
+    // (index inside the sub-chunk: 32-bit): with 64-bit per-point indices the pose-group variants kept
+    // a dozen hoisted addresses alive across the pose loop and spilled 10-24 VGPRs.
+    auto load_sub = [&](int64_t sbase, T (&dp)[PPT][NI], T (&dw)[PPT]) {
+        // points of the sub-chunk at `sbase` (clamped to the slice: past its end the last point again)
+        const int64_t left = hi - sbase;  // (may be <= 0 for the prefetch past the last round)
+        const uint32_t n = left >= S ? (uint32_t)S : (left > 0 ? (uint32_t)left : 0u);
+        const T* const pb = points + (n ? sbase : hi - 1) * NI;
+        const T* const wb = HAS_PW ? pw + (n ? sbase : hi - 1) : nullptr;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int64_t p = lo + threadIdx.x + (int64_t)k * kWcThreads;
-            const int64_t pl = p < hi ? p : hi - 1;
-            load_point<T, NI>(points, pl, nxt_pt[k]);
-            nxt_w[k] = HAS_PW ? pw[pl] : T(1);
+            const uint32_t lp = threadIdx.x + (uint32_t)k * kWcThreads;
+            const uint32_t ll = n ? (lp < n ? lp : n - 1) : 0u;
+            load_point<T, NI>(pb, (int64_t)ll, dp[k]);
+            dw[k] = HAS_PW ? wb[ll] : T(1);
         }
-    }
+    };
+    T nxt_pt[kPrefetch ? PPT : 1][NI], nxt_w[kPrefetch ? PPT : 1];
+    if constexpr (kPrefetch) load_sub(lo, nxt_pt, nxt_w);
     for (int64_t base = lo; base < hi; base += S) {
+        const uint32_t nloc = (uint32_t)((hi - base < S) ? hi - base : S);  // points of this sub-chunk
         T pt[PPT][NI], w[PPT];
+        if constexpr (kPrefetch) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            if constexpr (kPrefetch) {
+            for (int k = 0; k < PPT; ++k) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) pt[k][j] = nxt_pt[k][j];
                 w[k] = nxt_w[k];
-                const int64_t p = base + S + threadIdx.x + (int64_t)k * kWcThreads;
-                const int64_t pl = p < hi ? p : hi - 1;
-                load_point<T, NI>(points, pl, nxt_pt[k]);
-                nxt_w[k] = HAS_PW ? pw[pl] : T(1);
-            } else {
-                const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
-                const int64_t pl = p < hi ? p : hi - 1;
-                load_point<T, NI>(points, pl, pt[k]);
-                w[k] = HAS_PW ? pw[pl] : T(1);
             }
+            load_sub(base + S, nxt_pt, nxt_w);
+        } else {
+            load_sub(base, pt, w);
         }
         for (int jp = 0; jp < (GROUP ? nb : 1); ++jp) {
             const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
             uint32_t* cur = cursor + jp * NT;
-            uint32_t* slot_j = slot_of ? slot_of + (size_t)jp * P : nullptr;
+            uint32_t* const slot_b = slot_of ? slot_of + (size_t)jp * P + base : (uint32_t*)nullptr;
             // a. classify, rank inside (sub-chunk, tile)
             int tile[PPT];
             uint32_t lrank[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
+                const uint32_t lp = threadIdx.x + (uint32_t)k * kWcThreads;
                 int ref0[NO];
                 T dlo[NO];
-                bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && p < hi;
+                bool valid = ref_and_deltas<T, NI, NO>(pt[k], ps, gd, ref0, dlo) && lp < nloc;
                 tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
                 valid = tile[k] >= 0;
                 lrank[k] = 0;
                 if (valid) lrank[k] = atomicAdd(&lhist[tile[k]], 1u);
-                if (HAS_PW && valid) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
+                if (HAS_PW && valid) wkey = wrange_merge(wkey, abs_key(w[k]));
             }
             lds_barrier();
             // b. exclusive scan of lhist (in place)
@@ -1112,23 +1127,24 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
             // c. place into LDS in tile order; remember the global destination
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
-                const int64_t p = base + threadIdx.x + (int64_t)k * kWcThreads;
+                const uint32_t lp = threadIdx.x + (uint32_t)k * kWcThreads;
                 if (tile[k] >= 0) {
                     const uint32_t sidx = lhist[tile[k]] + lrank[k];
                     const uint32_t d = cur[tile[k]] + lrank[k];
                     RecT<T, W3> r;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) r.v[j] = (j < NI) ? pt[k][(j < NI) ? j : 0] : T(0);
-                    if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)p, T(0));
+                    if constexpr (!W3) r.v[3] = HAS_PW ? w[k] : idx_to_slot((uint32_t)base + lp, T(0));
                     recs[sidx] = r;
                     dest[sidx] = d;
-                    if (slot_j) __builtin_nontemporal_store(d, &slot_j[p]);
-                } else if (p < hi) {
-                    if (slot_j) __builtin_nontemporal_store(Pe, &slot_j[p]);  // spare slot
+                    if (slot_b) __builtin_nontemporal_store(d, &slot_b[lp]);
+                } else if (lp < nloc) {
+                    if (slot_b) __builtin_nontemporal_store(Pe, &slot_b[lp]);  // spare slot
                     if (zero_dropped) {
+                        T* const dp_b = ds_dpoints + base * NI;
 #pragma unroll
-                        for (int j = 0; j < NI; ++j) ds_dpoints[p * NI + j] = T(0);
-                        if (ds_dpw) ds_dpw[p] = T(0);
+                        for (int j = 0; j < NI; ++j) dp_b[lp * NI + j] = T(0);
+                        if (ds_dpw) (ds_dpw + base)[lp] = T(0);
                     }
                 }
             }
@@ -1148,7 +1164,7 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
             lds_barrier();
         }
     }
-    if (HAS_PW) publish_max_abs(maxpw, max_w);
+    if (HAS_PW) publish_max_abs(maxpw, wkey);
 }
 
 // ------------------------------------------------------------------ local binning: K1
@@ -1169,7 +1185,7 @@ __global__ __launch_bounds__(kWcThreads) void k_scatter_wc(
 struct LocalBinArgs {
     char* ws;            // pose copy 0 of the per-pose workspace
     size_t pose_stride;  // distance between the copies
-    size_t off_rec, off_slot, off_desc, off_bdesc, off_ltot;  // ltot: ndesc[NT] | npts[NT] | - | max|pw|
+    size_t off_rec, off_slot, off_desc, off_bdesc, off_ltot;  // ltot: ndesc[NT] | npts[NT] | max|pw| | ~min|pw|
 };
 constexpr int kTouchCap = 1024;
 // (fp32: 74 KB of LDS, two workgroups per CU when the kernel stays within 64 VGPRs; fp64 grids
@@ -1219,9 +1235,19 @@ __global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_l
             w[k] = T(1);
         }
     }
+    if constexpr (HAS_PW) {
+        // max / ~min |point_weight| for the fixed-point splat, over every LOADED point, valid under a
+        // given pose or not: published once for all poses of the local batch (a point outside the grid
+        // under pose 0 may be inside under pose j > 0) -- and at once, so that nothing of it lives
+        // across the pose loop
+        uint32_t wkey = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (threadIdx.x + (uint32_t)k * TH < nloc) wkey = wrange_merge(wkey, abs_key(w[k]));
+        publish_max_abs((uint32_t*)(la.ws + la.off_ltot) + 2 * NT, wkey);
+    }
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    uint32_t max_w = 0;  // max |point_weight| of the binned points (scale of the fixed-point splat)
 #pragma unroll 1
     for (int jp = 0; jp < nb; ++jp) {
         const Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, nullptr, b0 + jp);
@@ -1250,10 +1276,6 @@ __global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_l
             tile[k] = valid ? primary_tile<NO>(ref0, tg) : -1;
             valid = tile[k] >= 0;
             lrank[k] = 0;
-            // (every LOADED point, valid under this pose or not: the maximum is published once for
-            // all poses of the local batch, and a point outside the grid under pose 0 may be inside
-            // under pose j > 0)
-            if (HAS_PW && jp == 0 && lp < nloc) max_w = abs_bits(w[k]) > max_w ? abs_bits(w[k]) : max_w;
             unsigned long long todo = __ballot(valid);
             int rounds = 0;
             while (todo && rounds < 8) {
@@ -1404,7 +1426,6 @@ __global__ __launch_bounds__(TH, ((sizeof(T) == 4 && ONE) ? 8 : 4)) void k_bin_l
         if (threadIdx.x == 0) s_ntouch = 0;
         lds_barrier();
     }
-    if (HAS_PW) publish_max_abs((uint32_t*)(la.ws + la.off_ltot) + 2 * NT + 1, max_w);
 }
 
 // local binning: K2 -- tile totals -> descriptor offsets, work list (a work item is a range of
@@ -1711,7 +1732,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     // busy chip).  Only a pose group's later images need a second pose fetch.
     const uint32_t n_it = *n_items;
     const uint32_t order_flag = n_items[1];  // the tile scan's verdict on the cloud's order
-    const uint32_t maxpw_bits = HAS_PW ? *maxpw : 0x3f800000u;  // max |point_weight| (1.0f without)
+    const float maxw_call = sizeof(T) == 4 ? guarded_max_weight(1.f, maxpw, HAS_PW) : __builtin_inff();
     const WorkItem item = items[blockIdx.x];
     Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
@@ -1756,8 +1777,7 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
     }
     lds_barrier();  // LDS phases only: prefetched records stay in flight
     // fp32 data: exact 64-bit fixed-point sums (see FixScale); fp64 data and non-finite weights: f64
-    const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * __uint_as_float(maxpw_bits)
-                                                 : __builtin_inff(),
+    const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * maxw_call : __builtin_inff(),
                                   item.end - item.begin, fixed);
     auto record_loop = [&](auto fix_tag) {
         constexpr bool FIX = decltype(fix_tag)::value;
@@ -1851,7 +1871,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
     // busy chip).  Only a pose group's later images need a second pose fetch.
     const uint32_t n_it = *n_items;
     const WorkItem item = items[blockIdx.x];
-    const uint32_t maxpw_bits = HAS_PW ? *maxpw : 0x3f800000u;  // max |point_weight| (1.0f without)
+    const float maxw_call = sizeof(T) == 4 ? guarded_max_weight(1.f, maxpw, HAS_PW) : __builtin_inff();
     Pose<T, NI, NO> ps = load_pose<T, NI, NO>(rot, trans, ow, b0);
     for (int i = threadIdx.x; i < NVH; i += kSplatThreads) acc[i] = 0.0;
     if (blockIdx.x >= n_it) return;  // the grid is sized for the worst case
@@ -1869,9 +1889,7 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
     // a run holds at most one sub-chunk (<= 4096 records).
     uint32_t n_bound = (item.end - item.begin) < (1u << 19) ? (item.end - item.begin) * 4096u : max_rec;
     n_bound = n_bound < max_rec ? n_bound : max_rec;
-    const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * __uint_as_float(maxpw_bits)
-                                                 : __builtin_inff(),
-                                  n_bound, fixed);
+    const FixScale fs = fix_scale(sizeof(T) == 4 ? fabsf((float)ps.ow) * maxw_call : __builtin_inff(), n_bound, fixed);
     {
         // LOCAL BINNING: the item is a range of run descriptors; the records of a run are
         // contiguous.  Each thread takes a contiguous share of the item's records (as in the
@@ -3110,19 +3128,16 @@ __global__ __launch_bounds__(256) void k_unsort(int64_t P, const uint32_t* __res
 // ------------------------------------------------------------------ host side
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Experiment knobs: environment overrides of the compiled-in defaults, read ONCE per process
-// (function-local static: thread-safe, no getenv on the call path) and clamped to valid ranges.
+// Experiment knobs: in builds with -DDPR_EXPERIMENTS environment overrides of the compiled-in defaults, read
+// ONCE per process (function-local static: thread-safe, no getenv on the call path) and clamped to valid
+// ranges; in the shipped library the defaults (env_knob, dpr_tiled.h).
 struct Knobs {
     int cap3d_div, cap2d_div, cap_min, pose_group, scatter_wc, bwd_unpermute, compact_records,
         splat_blocked, fixed_point, fuse_tilescan, bin_direct_store;
 };
 static const Knobs& knobs() {
     static const Knobs k = [] {
-        auto env_int = [](const char* name, int dflt, int lo, int hi) {
-            const char* v = getenv(name);
-            int x = v ? atoi(v) : dflt;
-            return x < lo ? lo : (x > hi ? hi : x);
-        };
+        auto env_int = [](const char* name, int dflt, int lo, int hi) { return env_knob(name, dflt, lo, hi); };
         Knobs q;
         q.cap3d_div = env_int("DPR_CAP3D_DIV", 256, 1, 1 << 20);
         q.cap2d_div = env_int("DPR_CAP2D_DIV", 2048, 0, 1 << 20);  // 0: use the 3-D rule
@@ -3184,7 +3199,7 @@ struct Plan {
     int sub;               // points per sub-chunk
     int64_t nsub;          // sub-chunks = blocks of k_bin_local
     int64_t max_desc;      // descriptor slots: `sub` per sub-chunk
-    size_t off_ltot, off_dstart, off_dcursor, off_bdesc, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | - | max|pw|
+    size_t off_ltot, off_dstart, off_dcursor, off_bdesc, off_desc, off_sdesc;  // ltot: ndesc[NT] | npts[NT] | max|pw| | ~min|pw|
 };
 
 // Pose groups: with few tiles per pose (2-D projections, small 3-D grids) the bins become
@@ -3288,7 +3303,7 @@ static Plan make_plan(size_t elem, int n_out, int NT1, int64_t P1, int64_t B, in
     pl.max_items = NT + pl.max_slabs;
     pl.off_items = o;
     o += align_up((size_t)pl.max_items * sizeof(WorkItem));
-    pl.off_nitems = o;  // [0] = items, [1] = record assignment of k_tile_splat
+    pl.off_nitems = o;  // [0] = items, [1] = record assignment of k_tile_splat, [2] / [3] = max / ~min |point_weight| bits
     o += align_up(4);
     pl.off_nzbins = o;  // bins touched per count block (k_count -> k_tilescan)
     o += align_up((size_t)kMaxBinBlocks * 4);
@@ -3697,11 +3712,13 @@ static int bin_points_local(hipStream_t st, const GridDesc<NO>& gd, const TileGe
     } while (0)
     // fp64 batches: two 512-thread workgroups per CU without LDS staging (see k_bin_local)
     const bool direct_store = sizeof(T) == 8 && nb > 1 && knobs().bin_direct_store;
+    // (the 512-thread variant exists for fp64 only: the branch is not even instantiated for fp32 data)
 #define DPR_LAUNCH_LOCAL(HAS_PW, W3)                                        \
     do {                                                                    \
         if (nb == 1) DPR_LAUNCH_LOCAL2(HAS_PW, W3, true, 1024, true);       \
-        else if (direct_store) DPR_LAUNCH_LOCAL2(HAS_PW, W3, false, 512, false); \
-        else DPR_LAUNCH_LOCAL2(HAS_PW, W3, false, 1024, true);              \
+        else if (direct_store) {                                            \
+            if constexpr (sizeof(T) == 8) DPR_LAUNCH_LOCAL2(HAS_PW, W3, false, 512, false); \
+        } else DPR_LAUNCH_LOCAL2(HAS_PW, W3, false, 1024, true);            \
     } while (0)
     if (pw) DPR_LAUNCH_LOCAL(true, false);
     else if (!want_idx && knobs().compact_records) DPR_LAUNCH_LOCAL(false, true);
@@ -3828,7 +3845,7 @@ int raster_tiled(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
                        (const uint32_t*)(wsb + pl.off_nitems),                                  \
                        (const uint32_t*)(wsb + pl.off_tslab), rot, trans, ow, bg, b, out, halo, \
                        ovf, (pl.sort_inside || knobs().splat_blocked == 0) ? 0 : 1,                 \
-                       (const uint32_t*)(ws0 + pl.off_ltot) + 2 * tg.NT + 1,                    \
+                       (const uint32_t*)(ws0 + pl.off_ltot) + 2 * tg.NT,                        \
                        knobs().fixed_point)
 #define DPR_LAUNCH_SPLAT(HAS_PW, W3)                                                             \
     hipLaunchKernelGGL((k_tile_splat<T, NI, NO, HAS_PW, W3>), dim3(pl.max_items),               \

@@ -142,7 +142,8 @@ def workspace_bytes(op: str, grid_size, n_points: int, batch: int, n_in: int, dt
     import numpy as np
 
     grid_arr = np.asarray(grid_size, dtype=np.int64)
-    opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
+    opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK,
+           "residual_pullback": _lib.OP_RESIDUAL_PULLBACK}[op]
     need = getattr(_lib.lib(), f"dpr_workspace_bytes_ex_{_SUFFIX[dtype]}")(
         opc, _lib.ALGOS[algo], _lib.flag_max_pose_group(max_pose_group)
         | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0)
@@ -161,7 +162,8 @@ def resolve_algo(op: str, grid_size, n_points: int, batch: int, n_in: int, *,
     import numpy as np
 
     grid_arr = np.asarray(grid_size, dtype=np.int64)
-    opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK}[op]
+    opc = {"raster": _lib.OP_RASTER, "pullback": _lib.OP_PULLBACK,
+           "residual_pullback": _lib.OP_RESIDUAL_PULLBACK}[op]
     flags = (_lib.FLAG_KEEP_BINNING if sharing else 0) | (_lib.FLAG_COHERENT_POINTS if coherent_points else 0)
     rc = _lib.lib().dpr_resolve_algo_ex(opc, flags, n_in, len(grid_size),
                                         grid_arr.ctypes.data_as(ctypes.c_void_p), n_points, batch)
@@ -378,7 +380,7 @@ def raster_residual_pullback_(out, target, points, rotation, translation, backgr
                               loss=None, ds_dpoints=None, ds_drotation=None,
                               ds_dtranslation=None, ds_dbackground=None, ds_dout_weight=None,
                               ds_dpoint_weight=None, algo: str = "auto", workspace=None,
-                              reuse_binning: bool = False):
+                              reuse_binning: bool = False, coherent_points: bool = False):
     """Pullback of a squared-error loss without materialising its sensitivity
     (dpr_raster_residual_pullback_*).  Equivalent to
 
@@ -392,7 +394,7 @@ def raster_residual_pullback_(out, target, points, rotation, translation, backgr
     return _pullback(out, (target, float(scale), loss), points, rotation, translation, background,
                      out_weight, point_weight, ds_dpoints, ds_drotation, ds_dtranslation,
                      ds_dbackground, ds_dout_weight, ds_dpoint_weight, algo, workspace,
-                     reuse_binning)
+                     reuse_binning, coherent_points=coherent_points)
 
 
 def _pullback(ds_dout, residual, points, rotation, translation, background, out_weight,
@@ -468,8 +470,8 @@ def _pullback(ds_dout, residual, points, rotation, translation, background, out_
         flags |= _lib.FLAG_COHERENT_POINTS if coherent_points else 0
         flags |= _lib.FLAG_REUSE_BINNING if reuse_binning else 0
         flags |= 0 if point_weight_grad else _lib.FLAG_NO_POINT_WEIGHT_GRAD
-        ws, ws_bytes = _workspace(_lib.OP_PULLBACK, algo_c, suf, n_in, n_out, grid_arr, P, B, dev,
-                                  workspace, flags)
+        ws, ws_bytes = _workspace(_lib.OP_PULLBACK if residual is None else _lib.OP_RESIDUAL_PULLBACK,
+                                  algo_c, suf, n_in, n_out, grid_arr, P, B, dev, workspace, flags)
         if reuse_binning and workspace is None:
             raise ValueError("reuse_binning needs the workspace of the preceding raster_ call")
         head = (_stream_ptr(dev), algo_c, flags, n_in, n_out,

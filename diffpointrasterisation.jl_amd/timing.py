@@ -12,8 +12,12 @@ STAGES = {
     ("raster", "atomic"): ["fill", "splat"],
     ("pullback", "atomic"): ["zero+grid_sum", "gather"],
     ("raster", "tiled"): ["count", "scan", "scatter", "tile_splat", "halo"],
-    # DPR_ALGO_CHUNKED on 3-D grids (owner-computes tiles over a box hierarchy)
+    # DPR_ALGO_CHUNKED on 3-D grids (owner-computes tiles over a box hierarchy; one group of marks per
+    # pass of <= 16 poses, folded below)
     ("raster", "chunked"): ["boxes", "plan", "own_splat", "combine"],
+    # ... its sparse regime (B >= 4 poses, P <= G / 10: chunk lists over small tiles): pass algo="chunked_lists"
+    ("raster", "chunked_lists"): ["boxes", "lists", "chunk_splat", "divert"],
+    ("raster", "chunked_lists_sorting"): ["sort", "boxes", "lists", "chunk_splat", "divert"],
     ("pullback", "chunked"): ["direct_gather", "pose_reduce"],
     # ... of a cloud not flagged coherent over >= 8 poses (sorted inside the call): pass algo="chunked_sorting"
     ("pullback", "chunked_sorting"): ["sort", "direct_gather", "pose_reduce", "unsort"],
@@ -44,9 +48,13 @@ def _hiprt():
 
 def stage_times(call: Callable[[], None], op: str, algo: str, reps: int = 10,
                 max_events: int = 64, prepare: Callable[[], None] = None) -> Dict[str, float]:
-    """Run `call` (ONE dpr raster/pullback invocation with B == 1) `reps` times with stage
-    timing armed; returns {stage: mean ms} plus "total".  `prepare` (untimed) runs before
-    every armed call, e.g. the forward pass whose binning a reuse-pullback consumes."""
+    """Run `call` (ONE dpr raster/pullback invocation) `reps` times with stage timing armed; returns
+    {stage: mean ms} plus "total".  `prepare` (untimed) runs before every armed call, e.g. the forward
+    pass whose binning a reuse-pullback consumes.  A call that walks its stages several times (the
+    tiled path once per pose or pose group, the 3-D owner forward once per 16 poses, the direct
+    pullback once per launch of <= 64 poses -- fp64: per pose) records one group of marks per walk:
+    the groups are folded, each stage reporting the sum over the walks; one-off stages at the ends
+    ("sort", "unsort") stay single.  More marks than `max_events` is an error (raise it)."""
     hip = _hiprt()
     L = _lib.lib()
     names = STAGES[(op, algo)]
@@ -65,11 +73,20 @@ def stage_times(call: Callable[[], None], op: str, algo: str, reps: int = 10,
                 call()
             finally:
                 n = L.dpr_stage_timing_end()
-            assert n == len(names) + 1, f"expected {len(names) + 1} stage marks, got {n}"
+            if n >= max_events:
+                raise ValueError(f"more stage marks than max_events = {max_events}: raise it")
+            # marks = 1 (call start) + [one-off leading stages] + walks x (repeating stages)
+            lead = 1 if names[0] == "sort" else 0
+            tail = 1 if names[-1] == "unsort" else 0
+            rep = len(names) - lead - tail
+            intervals = n - 1 - lead - tail
+            assert intervals >= rep and intervals % rep == 0, \
+                f"expected 1 + {lead} + k * {rep} + {tail} stage marks for {names}, got {n}"
             assert hip.hipEventSynchronize(events[n - 1]) == 0
-            for k in range(len(names)):
+            for i in range(n - 1):
+                k = i if i < lead else (len(names) - 1 if i >= n - 1 - tail else lead + (i - lead) % rep)
                 ms = ctypes.c_float()
-                assert hip.hipEventElapsedTime(ctypes.byref(ms), events[k], events[k + 1]) == 0
+                assert hip.hipEventElapsedTime(ctypes.byref(ms), events[i], events[i + 1]) == 0
                 acc[k] += ms.value
     finally:
         for i in range(max_events):

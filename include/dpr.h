@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define DPR_VERSION 104 /* 0.1.4: + DPR_FLAG_NO_POINT_WEIGHT_GRAD; 3-D DPR_ALGO_CHUNKED = owner-computes tiles over a box hierarchy */
+#define DPR_VERSION 105 /* 0.1.5: + DPR_OP_RESIDUAL_PULLBACK; fp32 fixed-point sums fall back to f64 on wide weight ranges */
 
 /* status codes */
 #define DPR_OK 0
@@ -64,9 +64,13 @@ extern "C" {
 #define DPR_ERR_HIP (-4)              /* a HIP runtime call failed */
 #define DPR_ERR_UNSUPPORTED_ALGO (-5) /* algorithm not available for this shape */
 
-/* operations, for dpr_workspace_bytes_* */
+/* operations, for dpr_workspace_bytes_* and dpr_resolve_* */
 #define DPR_OP_RASTER 0
 #define DPR_OP_PULLBACK 1
+/* the pullback entered through dpr_raster_residual_pullback_*: with DPR_ALGO_AUTO it never resolves to the
+ * 3-D DPR_ALGO_CHUNKED pullback (which has no residual variant), so its workspace can differ from
+ * DPR_OP_PULLBACK's for the same shape -- query with this op before a residual call */
+#define DPR_OP_RESIDUAL_PULLBACK 2
 
 /* algorithms (the *_ex entry points; the plain ones use DPR_ALGO_AUTO) */
 #define DPR_ALGO_AUTO 0
@@ -145,11 +149,11 @@ extern "C" {
  *                        (fp32), then float atomics into the     order: bit-reproducible for a given    fixed tree in T (fp32 data; fp64: f64 across
  *                        image across chunks: run to run,        point order (2-D); 3-D: one thread     threads), the partials per (chunk, pose) in f64
  *                        rounding level.  3-D owner tiles:       per point, poses added in index        in a fixed order.  3-D: per-thread sums in T over
- *                        fp32 EXACT (64-bit fixed point, split   order through memory: bit-             a fixed slice of the cloud, f64 across threads
- *                        tiles summed as integers) -- the same   reproducible                           and blocks in a fixed order: bit-reproducible
- *                        bits for any point order; fp64: f64                                            for a given point order
- *                        LDS atomics, rounding level.  3-D
- *                        chunk lists (sparse clouds): f64 LDS
+ *                        fp32 EXACT (64-bit fixed point, split   order through memory: bit-             a slice of the cloud (its size follows the CU
+ *                        tiles summed as integers) -- the same   reproducible                           count of the device), then f64: one pose per launch
+ *                        bits for any point order; fp64: f64                                            in a fixed order; the fp32 batch kernel (pose loop
+ *                        LDS atomics, rounding level.  3-D                                              inside) adds its waves' sums with f64 LDS atomics in
+ *                        chunk lists (sparse clouds): f64 LDS                                           arrival order: rounding level of f64
  *                        atomics + diverted global atomics
  *
  * "Rounding level" = the differences any two summation orders of the same terms show in the
@@ -157,12 +161,25 @@ extern "C" {
  * (cell choice, weights) are computed with the reference's operation order in T and do not depend
  * on any order.
  *
- * ABSOLUTE ERROR BOUND OF THE FIXED-POINT SUMS (a deviation from the reference's fp32 float atomics,
- * which keep the relative precision of every cell): a contribution is rounded to a multiple of
+ * PRECISION OF THE FIXED-POINT SUMS (fp32 data; the reference's float atomics, src/raster.jl:62-64, keep
+ * the relative precision of every cell whatever its magnitude).  A contribution is rounded to a multiple of
  * 2^-sexp, with sexp chosen per work item so that n * maxw * 2^sexp <= 2^62 (n = records of the item,
- * maxw = |out_weight| * max |point_weight| OF THE WHOLE CALL).  A contribution therefore keeps at
- * least 38 bits below maxw (items hold < 2^24 records; typically 49): cells whose points all weigh
- * less than ~2^-38 * maxw receive 0.  NaN / Inf weights switch the item to IEEE f64 atomics. */
+ * maxw = |out_weight| * max |point_weight| of the SCOPE: the call on DPR_ALGO_TILED, the candidate chunks of
+ * a tile on the 3-D DPR_ALGO_CHUNKED forward, the 4096-point chunk on the 2-D one): a contribution keeps at
+ * least 38 bits below maxw (items hold < 2^24 records; typically 49).  Where the NON-ZERO |point_weight| of
+ * a scope span more than 2^10 -- or a weight is NaN / Inf -- the scope accumulates with IEEE f64 atomics
+ * instead (since 0.1.5; before, cells reached only by points lighter than ~2^-38 of the call's heaviest came
+ * out as 0).  So every contribution keeps >= 28 bits (typically 39) below the SMALLEST weight next to it,
+ * and a cell's absolute error is <= k * 2^-39 * (smallest weight in scope) for its k contributions: below
+ * fp32 rounding (2^-24 relative) for every cell except far corners of their only contributors (value below
+ * ~2^-12 of the local weight), which keep at least 16 good bits.  Default weights (NULL) never trip the guard.
+ * tests/test_parity_gpu.py::test_fp32_cells_reached_only_by_small_weights_keep_their_relative_precision.
+ *
+ * ENVIRONMENT.  The library reads one variable, DPR_MAX_TILES (16..32768, default 32768): the number of tiles
+ * DPR_ALGO_TILED handles per launch sequence before it cuts the grid into slabs along the last axis -- a test
+ * hook that lets a small grid walk the slab code; it moves slab boundaries, never results.  The A/B switches
+ * named in profiles/r0N_experiments.md (DPR_FIXED_POINT, DPR_SORT_BITS, DPR_CO_SORT, DPR_OWN_*, ...) exist
+ * only in builds made with `make EXPERIMENTS=1` (-DDPR_EXPERIMENTS); the shipped library ignores them. */
 
 /* flags (the *_ex entry points).  DPR_ALGO_TILED: any B -- with B > 1 every pose keeps its own
  * binning (the per-pose part of the workspace is laid out B times; pose groups are off);
@@ -334,8 +351,10 @@ int dpr_raster_pullback_ex_f64(void *stream, int algo, unsigned flags, int n_in,
  *     <all six outputs of dpr_raster_pullback_*>(ds_dout, ...)
  *     loss[b] = sum over pose b's grid of (out - target)^2      (loss may be NULL)
  * The sensitivity is formed in the kernels that consume it: the grid is read twice (out,
- * target) instead of read twice, written once and read again.  Flags / workspace as for
- * dpr_raster_pullback_ex_*; DPR_ALGO_CHUNKED is not available (DPR_ERR_UNSUPPORTED_ALGO). */
+ * target) instead of read twice, written once and read again.  Flags as for
+ * dpr_raster_pullback_ex_*; workspace: dpr_workspace_bytes_*(DPR_OP_RESIDUAL_PULLBACK, ...).  An explicit
+ * DPR_ALGO_CHUNKED on a 3-D grid is refused (DPR_ERR_UNSUPPORTED_ALGO: the direct gather kernels have no
+ * residual variant); DPR_ALGO_AUTO picks among the algorithms that have one. */
 int dpr_raster_residual_pullback_f32(void *stream, int n_in, int n_out, const int64_t *grid,
                                      int64_t P, int64_t B, const float *out, const float *target,
                                      double residual_scale, const float *points,

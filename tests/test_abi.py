@@ -318,3 +318,119 @@ def test_workspace_and_flag_errors_precede_any_launch(suf, ctype):
     dummy2 = (ctypes.c_char * 1024)()
     d2 = ctypes.c_void_p((ctypes.addressof(dummy2) + 255) & ~255)
     assert srt(None, 3, 10, d, d2, d, None, None, d, 8) == dpr_amd._lib.ERR_WORKSPACE
+
+
+# ------------------------------------------------------------------ code-object gates (no GPU needed)
+# Kernels that may use scratch, as (regex on the demangled name, bytes of scratch allowed, why).  Everything
+# else in libdpr.so must have .vgpr_spill_count == 0 and .private_segment_fixed_size == 0: a spill in
+# a record loop is a silent 10-30 % (round 4: `k_bin_local` 62 -> 150 us when it went from 60 to 128
+# VGPRs + scratch).  Budgets are what the round-6 build needs: a larger number fails the test too.
+SCRATCH_ALLOWED = [
+    (r"rocprim::", 128, "third-party radix sort (private arrays, no VGPR spills)"),
+    (r"dpr::k_co_splat_wide<float, 3, (true|false)>", 84,
+     "cold path of the 2-D chunk-owner forward (footprints that outgrow the tile): 16 contributions per thread "
+     "kept across row bands; recomputing them instead measured slower (experiments/r05_wide_splat_recompute...)"),
+    (r"dpr::k_co_splat_wide<float, 2, (true|false)>", 48, "as above, 2-D -> 2-D"),
+    (r"dpr::k_co_splat_wide<double, 3, true>", 28, "as above, fp64 with point weights"),
+    (r"dpr::k_co_gather<double, 3, true>", 36, "fp64 chunk-owner pullback with point weights at the 128-VGPR cap of a "
+                                               "1024-thread workgroup"),
+    (r"dpr::k_scatter_wc<float, 3, 3, (true|false), 4096, true, (true|false)>", 76,
+     "pose-GROUP variants (batches on 3-D grids of <= 256 tiles): the sub-chunk's points live across the pose loop"),
+    (r"dpr::k_bin_local<float, 3, 3, (true|false), 4096, false, false, 1024, true>", 68,
+     "local binning of a BATCH (points live across the pose loop); the single-pose variant is clean"),
+    (r"dpr::k_tile_gather<double, 3, 3, false, false, false>", 20, "fp64 pullback tile kernel at the 128-VGPR cap"),
+    (r"dpr::k_tile_gather_runs<double, 3, 3, true, (true|false), (true|false), true>", 12,
+     "fp64 run-walking pullback tile kernel with point weights at the 128-VGPR cap"),
+]
+
+
+def test_no_kernel_spills_or_uses_scratch():
+    """Zero-scratch gate: llvm-readelf --notes on the gfx950 code objects inside libdpr.so (no GPU)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources, short
+
+    ks = kernel_resources()
+    assert len(ks) > 300, "libdpr.so should hold several hundred kernel instantiations"
+    bad, used = [], set()
+    for k in ks:
+        if not (k["vgpr_spill"] or k["scratch"]):
+            continue
+        name = short(k["demangled"])
+        for i, (pat, budget, _why) in enumerate(SCRATCH_ALLOWED):
+            if re.search(pat, k["demangled"]):
+                used.add(i)
+                if k["scratch"] > budget:
+                    bad.append(f"{name}: {k['scratch']} B of scratch > allowed {budget}")
+                break
+        else:
+            bad.append(f"{name}: {k['vgpr_spill']} spilled VGPRs, {k['scratch']} B of scratch")
+    assert not bad, "\n".join(bad)
+    stale = [SCRATCH_ALLOWED[i][0] for i in range(len(SCRATCH_ALLOWED)) if i not in used]
+    assert not stale, f"allow-list entries no kernel needs any more: {stale}"
+    # the kernels of the headline configuration (C3, one pose, fp32) are not on the list at all
+    for k in ks:
+        if re.search(r"dpr::(k_count|k_tile_splat|k_tile_gather|k_unpermute|k_halo_gather|k_own_\w+)<float, 3", k["demangled"]) \
+                or re.search(r"dpr::k_scatter_wc<float, 3, 3, false, 4096, false", k["demangled"]):
+            assert k["vgpr_spill"] == 0 and k["scratch"] == 0, short(k["demangled"])
+
+
+# ------------------------------------------------------------------ DPR_ALGO_AUTO, pinned
+def _auto_regret(rows, n_in):
+    worst = {"raster": (1.0, None), "pullback": (1.0, None)}
+    for r in rows:
+        kw = dict(coherent_points=True) if r["order"] == "coherent" else {}
+        for op in ("raster", "pullback"):
+            auto = dpr_amd.resolve_algo(op, tuple(r["grid"]), r["P"], r["B"], n_in, **kw)
+            assert auto in r[op], f"AUTO picks {auto} where the table has no time: {r}"
+            regret = r[op][auto] / min(r[op].values())
+            if regret > worst[op][0]:
+                worst[op] = (regret, r)
+    return worst
+
+
+def test_auto_stays_within_its_measured_regret():
+    """`resolve_algo` is ~250 lines of thresholds fitted to measured tables; the table of round 5 (336 shapes
+    x 2 operations, three cloud distributions, both point orders; tools/auto_regret.py on one MI355X) is
+    committed as tests/golden/auto_regret_r05.json and AUTO is re-evaluated against it on the host: the
+    worst ratio t(AUTO) / t(best) must stay where profiles/r05_auto_regret.txt left it (1.59 forward, 1.43
+    pullback).  A threshold edit that sends a measured shape to a slower algorithm fails here."""
+    import json
+    tab = json.load(open(os.path.join(ROOT, "tests", "golden", "auto_regret_r05.json")))
+    assert len(tab["rows"]) == 336
+    worst = _auto_regret(tab["rows"], tab["n_in"])
+    assert worst["raster"][0] <= 1.60, worst["raster"]
+    assert worst["pullback"][0] <= 1.45, worst["pullback"]
+
+
+def test_auto_choice_for_the_baseline_configs_and_the_readme_shapes():
+    """The documented choices: every BASELINE.json config and the reference's published
+    shapes (README.md:189-193: 1e4 / 1e5 points x 64 images -> 128^2 / 1024^2, and 1e5 points -> 1024^3)."""
+    ra = dpr_amd.resolve_algo
+    # C1: 1k 2-D points -> 5x5: direct kernels
+    assert ra("raster", (5, 5), 1000, 1, 2) == "atomic" and ra("pullback", (5, 5), 1000, 1, 2) == "atomic"
+    # C2 / C3: single pose, dense cloud on a 3-D grid in any order: tiled (also as a KEEP / REUSE pair)
+    for P, g in ((1_000_000, (128,) * 3), (10_000_000, (256,) * 3)):
+        assert ra("raster", g, P, 1, 3) == "tiled" and ra("pullback", g, P, 1, 3) == "tiled"
+        assert ra("raster", g, P, 1, 3, sharing=True) == "tiled"
+    # C3 on a cloud flagged coherent: the pullback gathers directly (nothing to share with the forward)
+    assert ra("pullback", (256,) * 3, 10_000_000, 1, 3, coherent_points=True) == "chunked"
+    assert not dpr_amd.sharing_effective((256,) * 3, 10_000_000, 1, 3, coherent_points=True)
+    # C4: 10 M points -> 512^2, 64 poses per GPU (and the 512-pose job): chunk-owner tiles
+    for B in (64, 512):
+        assert ra("raster", (512, 512), 10_000_000, B, 3) == "chunked"
+        assert ra("pullback", (512, 512), 10_000_000, B, 3) == "chunked"
+    # C5: 50 M points -> 512^3, 8 poses per GPU: tiled forward; the pullback of a cloud in any order sorts
+    # inside the call and gathers directly (>= 8 poses of >= 1e7 points)
+    assert ra("raster", (512,) * 3, 50_000_000, 8, 3) == "tiled"
+    assert ra("pullback", (512,) * 3, 50_000_000, 8, 3) == "chunked"
+    # the README's timing table: 1e5 points x 64 poses
+    for P in (10_000, 100_000):
+        assert ra("raster", (128, 128), P, 64, 3) == "chunked"
+        assert ra("pullback", (128, 128), P, 64, 3) in ("atomic", "chunked")
+        assert ra("raster", (1024, 1024), P, 64, 3) in ("chunked", "atomic")
+    assert ra("raster", (1024,) * 3, 100_000, 1, 3) == "atomic"  # (a sparse cloud on a huge grid: direct atomics)
+    assert ra("pullback", (1024,) * 3, 100_000, 1, 3) == "atomic"
+    # the residual pullback never resolves to the 3-D direct kernels
+    assert ra("residual_pullback", (256,) * 3, 10_000_000, 1, 3, coherent_points=True) == "tiled"
+    assert ra("residual_pullback", (256,) * 3, 10_000_000, 16, 3) == "tiled"
