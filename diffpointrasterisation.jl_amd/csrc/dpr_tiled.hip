@@ -118,7 +118,9 @@ template <typename T> __host__ __device__ constexpr int gather_waves_per_simd() 
 #define DPR_BIN_BLOCKS 512
 #endif
 constexpr int kMaxBinBlocks = DPR_BIN_BLOCKS;  // rows of the counts table (2 per CU)
-constexpr int kSplitChunks = 32;     // k_halo_gather work items per split tile (256 voxels a step)
+constexpr int kSplitChunks = 8;      // k_halo_gather work items per split tile (3-D: kSplitRows tile rows each;
+                                     // 2-D: 256 voxels a step of the flat loop)
+constexpr int kSplitRows = 16;       // rows (l1, l2) of a 64 x 16 x 8 tile per work item
 constexpr int kSplitGrid = 2048;     // ... and the blocks that walk them (idle blocks cost nothing
                                      // measurable: a grid limited to the live items changed no kernel time)
 
@@ -1690,6 +1692,24 @@ __device__ __forceinline__ void splat_record(const R& rc, bool active, const Pos
     bool interior = true;
 #pragma unroll
     for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+#if defined(DPR_ABL) && DPR_ABL == 1  // ablation: all the arithmetic, no LDS atomics (timing only, wrong results)
+    if (active) {
+        unsigned long long sink = 0;
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) sink ^= fix_bits((float)voxel_weight<T, NO>(dlo, s, w), fs) + lds_index<NO>(lb);
+        if (sink == 0x123456789abcull) acc[threadIdx.x] = 1.0;
+    }
+    return;
+#elif defined(DPR_ABL) && DPR_ABL == 2  // ablation: the LDS atomics only, at pseudo-random cells
+    if (active) {
+        uint32_t h = __float_as_uint((float)pt[0]) * 2654435761u;
+        h ^= h >> 15;
+        double* base = &acc[h % (uint32_t)(tile_voxels_halo<NO>() - nbr_lds_offset<NO>((1 << NO) - 1) - 1)];
+#pragma unroll
+        for (int s = 0; s < (1 << NO); ++s) atomicAdd((unsigned long long*)(base + nbr_lds_offset<NO>(s)), 12345ull);
+    }
+    return;
+#endif
     if (active && interior) {
         // common case: one base address, the 2^N neighbours are compile-time offsets
         // (they fold into the ds_add offset field)
@@ -1712,6 +1732,69 @@ __device__ __forceinline__ void splat_record(const R& rc, bool active, const Pos
             cell_add<FIX, T>(&acc[lds_index<NO>(l)], ok ? v : T(0), fs);
         }
     }
+}
+
+// Flush of a forward tile kernel's LDS tile, one row (TX + 1 cells along x) per wave pass: the row's y / z
+// coordinates, bounds and base offsets are wave-uniform, a lane only adds its x.  Owned rows leave as
+// out = background + acc (plain non-temporal stores of TX contiguous values); the rows of the upper y / z
+// halo and the x == TX column go to the compact per-tile halo buffer (always fully written, zeros
+// included).  kFB rows per wave are in flight together (round 6): one row at a time was a chain of ~19
+// dependent LDS round trips per wave, and the tile kernel WITHOUT its record loop took 38 of its 71 us at C3
+// (ablation builds, profiles/r06_experiments.md).
+template <typename T, int NO>
+__device__ __forceinline__ void flush_tile(const double* __restrict__ acc, const FixScale& fs, double bgv,
+                                           const GridDesc<NO>& gd, const int (&x0)[NO], bool ghost_tile,
+                                           T* __restrict__ o, T* __restrict__ hb) {
+    constexpr int NVH = tile_voxels_halo<NO>();
+    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
+    constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
+    constexpr int ROWS = NVH / (TX + 1);   // (TY + 1) [* (TZ + 1)]
+    constexpr int RPW = kWave / TX;        // rows per wave pass (1 for TX = 64, 2 for TX = 32)
+    static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
+    constexpr int NW = kSplatThreads / kWave;
+#ifndef DPR_FLUSH_BATCH
+#define DPR_FLUSH_BATCH 4
+#endif
+    constexpr int kFB = DPR_FLUSH_BATCH;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int x = lane % TX;
+    const bool x_ok = x0[0] + x < gd.n[0];
+    for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += NW * RPW * kFB) {
+        double raw[kFB];
+        int rows[kFB];
+#pragma unroll
+        for (int u = 0; u < kFB; ++u) {
+            int row = row0 + u * NW * RPW + lane / TX;
+            if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
+            rows[u] = row;
+            raw[u] = acc[(row < ROWS ? row : 0) * (TX + 1) + x];
+        }
+#pragma unroll
+        for (int u = 0; u < kFB; ++u) {
+            const int row = rows[u];
+            if (row >= ROWS) continue;
+            const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
+            const double a = fix_value(raw[u], fs);
+            const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
+            if (owned) {
+                const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
+                const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
+                if (in && x_ok && !ghost_tile)
+                    __builtin_nontemporal_store(
+                        (T)(bgv + a),
+                        &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
+            } else {
+                int h[NO];
+                h[0] = x;
+                h[1] = l1;
+                if (NO == 3) h[NO - 1] = l2;
+                hb[halo_index<NO>(h)] = (T)a;
+            }
+        }
+    }
+    // x == TX column: the X-face of the halo buffer is indexed by the row number
+    for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
+        hb[row] = (T)fix_value(acc[row * (TX + 1) + TX], fs);
 }
 
 // ------------------------------------------------------------------ forward K4
@@ -1797,58 +1880,36 @@ __global__ __launch_bounds__(kSplatThreads) void k_tile_splat(
                 splat_record<FIX, T, NI, NO, HAS_PW>(cur[u], r_cur + u * step < r1, ps, gd, x0, acc, fs);
         }
     };
+#if defined(DPR_ABL) && DPR_ABL == 3  // ablation: no record loop (clear + flush + dispatch only)
+    (void)record_loop;
+#else
     if (fs.mul != 0.0) record_loop(std::true_type{});  // (uniform)
     else record_loop(std::false_type{});
+#endif
     lds_barrier();  // LDS phases only: prefetched records stay in flight
     if ((item.part_nparts >> 16) > 1) {
         // part of a split tile: the whole LDS tile goes to this part's overflow slab;
         // k_halo_gather sums the parts
         T* slab = ovf + (size_t)(tile_slab[item.tile] + (item.part_nparts & 0xffffu)) * NVH;
-        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)fix_value(acc[i], fs);
+        constexpr int kSB = 4;  // cells per thread in flight
+        for (int i0 = threadIdx.x; i0 < NVH; i0 += kSplatThreads * kSB) {
+            double raw[kSB];
+#pragma unroll
+            for (int u = 0; u < kSB; ++u) {
+                const int i = i0 + u * kSplatThreads;
+                raw[u] = acc[i < NVH ? i : NVH - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < kSB; ++u) {
+                const int i = i0 + u * kSplatThreads;
+                if (i < NVH) slab[i] = (T)fix_value(raw[u], fs);
+            }
+        }
         return;
     }
-    // Flush, one LDS row (TX + 1 cells along x) at a time: the row's y/z coordinates, bounds
-    // and base offsets are computed once per row, a lane only adds its x.  Owned rows leave
-    // as out = background + acc (plain stores of TX contiguous values); the rows of the upper
-    // y / z halo and the x == TX column go to the compact per-tile halo buffer (always fully
-    // written, zeros included).
-    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
-    constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
-    constexpr int ROWS = NVH / (TX + 1);   // (TY + 1) [* (TZ + 1)]
-    constexpr int RPW = kWave / TX;        // rows per wave pass (1 for TX = 64, 2 for TX = 32)
-    static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
     const double bgv = bg ? (double)bg[b] : 0.0;
-    T* o = out + b * gd.G;
-    T* hb = halo + (size_t)item.tile * halo_count<NO>();
-    const bool ghost_tile = tg.ghost && tc[NO - 1] == 0;  // (only its upper halo is wanted)
-    const int lane = threadIdx.x & (kWave - 1);
-    const int x = lane % TX;
-    const bool x_ok = x0[0] + x < gd.n[0];
-    for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += (kSplatThreads / kWave) * RPW) {
-        int row = row0 + lane / TX;
-        if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
-        if (row >= ROWS) continue;
-        const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
-        const double a = fix_value(acc[row * (TX + 1) + x], fs);
-        const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
-        if (owned) {
-            const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
-            const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
-            if (in && x_ok && !ghost_tile)
-                __builtin_nontemporal_store(
-                    (T)(bgv + a),
-                    &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
-        } else {
-            int h[NO];
-            h[0] = x;
-            h[1] = l1;
-            if (NO == 3) h[NO - 1] = l2;
-            hb[halo_index<NO>(h)] = (T)a;
-        }
-    }
-    // x == TX column: the X-face of the halo buffer is indexed by the row number
-    for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
-        hb[row] = (T)fix_value(acc[row * (TX + 1) + TX], fs);
+    flush_tile<T, NO>(acc, fs, bgv, gd, x0, tg.ghost && tc[NO - 1] == 0 /* (only its upper halo is wanted) */,
+                      out + b * gd.G, halo + (size_t)item.tile * halo_count<NO>());
 }
 
 // ------------------------------------------------------------------ forward K4, local binning
@@ -1949,51 +2010,25 @@ __global__ __launch_bounds__(kSplatThreads, DPR_SPLAT_RUNS_OCC) void k_tile_spla
         // part of a split tile: the whole LDS tile goes to this part's overflow slab;
         // k_halo_gather sums the parts
         T* slab = ovf + (size_t)(tile_slab[item.tile] + (item.part_nparts & 0xffffu)) * NVH;
-        for (int i = threadIdx.x; i < NVH; i += kSplatThreads) slab[i] = (T)fix_value(acc[i], fs);
+        constexpr int kSB = 4;  // cells per thread in flight
+        for (int i0 = threadIdx.x; i0 < NVH; i0 += kSplatThreads * kSB) {
+            double raw[kSB];
+#pragma unroll
+            for (int u = 0; u < kSB; ++u) {
+                const int i = i0 + u * kSplatThreads;
+                raw[u] = acc[i < NVH ? i : NVH - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < kSB; ++u) {
+                const int i = i0 + u * kSplatThreads;
+                if (i < NVH) slab[i] = (T)fix_value(raw[u], fs);
+            }
+        }
         return;
     }
-    // Flush, one LDS row (TX + 1 cells along x) at a time: the row's y/z coordinates, bounds
-    // and base offsets are computed once per row, a lane only adds its x.  Owned rows leave
-    // as out = background + acc (plain stores of TX contiguous values); the rows of the upper
-    // y / z halo and the x == TX column go to the compact per-tile halo buffer (always fully
-    // written, zeros included).
-    constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1];
-    constexpr int TZ = (NO == 3) ? TileDims<NO>::T[NO - 1] : 0;
-    constexpr int ROWS = NVH / (TX + 1);   // (TY + 1) [* (TZ + 1)]
-    constexpr int RPW = kWave / TX;        // rows per wave pass (1 for TX = 64, 2 for TX = 32)
-    static_assert(kWave % TX == 0, "tile rows must divide the wavefront");
     const double bgv = bg ? (double)bg[b] : 0.0;
-    T* o = out + b * gd.G;
-    T* hb = halo + (size_t)item.tile * halo_count<NO>();
-    const bool ghost_tile = tg.ghost && tc[NO - 1] == 0;  // (only its upper halo is wanted)
-    const int lane = threadIdx.x & (kWave - 1);
-    const int x = lane % TX;
-    const bool x_ok = x0[0] + x < gd.n[0];
-    for (int row0 = (threadIdx.x / kWave) * RPW; row0 < ROWS; row0 += (kSplatThreads / kWave) * RPW) {
-        int row = row0 + lane / TX;
-        if (RPW == 1) row = __builtin_amdgcn_readfirstlane(row);
-        if (row >= ROWS) continue;
-        const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
-        const double a = fix_value(acc[row * (TX + 1) + x], fs);
-        const bool owned = l1 < TY && (NO == 2 || l2 < TZ);
-        if (owned) {
-            const int g1 = x0[1] + l1, g2 = (NO == 3) ? x0[NO - 1] + l2 : 0;
-            const bool in = g1 < gd.n[1] && (NO == 2 || g2 < gd.n[NO - 1]);
-            if (in && x_ok && !ghost_tile)
-                __builtin_nontemporal_store(
-                    (T)(bgv + a),
-                    &o[((NO == 3) ? (size_t)g2 * gd.n[1] + g1 : (size_t)g1) * gd.n[0] + x0[0] + x]);
-        } else {
-            int h[NO];
-            h[0] = x;
-            h[1] = l1;
-            if (NO == 3) h[NO - 1] = l2;
-            hb[halo_index<NO>(h)] = (T)a;
-        }
-    }
-    // x == TX column: the X-face of the halo buffer is indexed by the row number
-    for (int row = threadIdx.x; row < ROWS; row += kSplatThreads)
-        hb[row] = (T)fix_value(acc[row * (TX + 1) + TX], fs);
+    flush_tile<T, NO>(acc, fs, bgv, gd, x0, tg.ghost && tc[NO - 1] == 0 /* (only its upper halo is wanted) */,
+                      out + b * gd.G, halo + (size_t)item.tile * halo_count<NO>());
 }
 
 // ------------------------------------------------------------------ forward K5
@@ -2090,6 +2125,82 @@ __device__ __forceinline__ void halo_gather_tile(const GridDesc<NO>& gd, const T
         any_nbr_split = any_nbr_split || (v && nparts[m] > 1);
     }
     if constexpr (NO == 3 && TileDims<NO>::T[0] == kWave) {
+        if (split) {
+            // A SPLIT 3-D tile, ROW form (round 6): chunk `c` = kSplitRows rows (l1, l2) of the tile's
+            // TY * TZ owned rows, a wave takes kSplitRows / 4 of them at once, lane = l0.  Every owned
+            // voxel = background + the parts' slab values in part order (coalesced 256-byte rows, the
+            // loads of the wave's rows in flight together); rows on a low face add the lower
+            // neighbours' halos, lane 0 also the four combinations that reach through x.  Same terms
+            // in the same order as the flat loop at the end of this function, which took ~25 ns per
+            // voxel (div / mod per voxel, one dependent slab chain at a time) and made finer splits
+            // of heavy tiles a net loss -- with the heaviest item of C3 at 39 000 records (8 x the
+            // mean) setting the time of BOTH tile kernels.
+            constexpr int TX = TileDims<NO>::T[0], TY = TileDims<NO>::T[1], TZ = TileDims<NO>::T[2];
+            constexpr int YF = (TY + 1) * (TZ + 1), ZF = YF + TX * (TZ + 1);  // face bases (halo_index)
+            constexpr int NW = 256 / kWave, RIT = kSplitRows / NW;
+            static_assert(kSplitRows % NW == 0 && (TY * TZ) % kSplitRows == 0, "whole rows per wave");
+            static_assert(kSplitChunks * kSplitRows == TY * TZ, "chunks cover the tile");
+            const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+            const uint32_t my_parts = tile_parts[ptile], my_slab = tile_slab[ptile];
+            const double bgv = bg ? (double)bg[b] : 0.0;
+            const bool x_ok = x0[0] + lane < gd.n[0];
+            const size_t HC = halo_count<NO>();
+            double own[RIT];
+            bool act[RIT];
+            int offs[RIT], cell[RIT], l1s[RIT], l2s[RIT];
+#pragma unroll
+            for (int k = 0; k < RIT; ++k) {
+                const int row = __builtin_amdgcn_readfirstlane(c * kSplitRows + wave * RIT + k);
+                l1s[k] = row % TY;
+                l2s[k] = row / TY;
+                const int g1 = x0[1] + l1s[k], g2 = x0[2] + l2s[k];
+                act[k] = x_ok && g1 < gd.n[1] && g2 < gd.n[2];
+                offs[k] = act[k] ? (g2 * gd.n[1] + g1) * gd.n[0] + x0[0] + lane : 0;
+                cell[k] = lane + (TX + 1) * (l1s[k] + (TY + 1) * l2s[k]);
+                own[k] = bgv;
+            }
+            const T* sp = ovf + (size_t)my_slab * NVH;
+            for (uint32_t q = 0; q < my_parts; ++q) {  // (uniform)
+                T a[RIT];
+#pragma unroll
+                for (int k = 0; k < RIT; ++k) a[k] = sp[(size_t)q * NVH + cell[k]];
+#pragma unroll
+                for (int k = 0; k < RIT; ++k) own[k] += (double)a[k];
+            }
+            // a neighbour's contribution to one cell: its halo value, or -- a split neighbour -- the sum
+            // over its parts' slabs (cell index in the (T + 1)^3 tile)
+            auto nbr = [&](int m, bool on, int hidx, int ncell) -> double {
+                if (nparts[m] > 1) {  // (uniform)
+                    const T* np_ = ovf + (size_t)nslab[m] * NVH + (on ? ncell : 0);
+                    double sum = 0.0;
+                    for (uint32_t q = 0; q < nparts[m]; ++q) sum += (double)np_[(size_t)q * NVH];
+                    return on ? sum : 0.0;
+                }
+                const T v = halo[on ? (size_t)nsrc[m] * HC + hidx : (size_t)0];
+                return on ? (double)v : 0.0;
+            };
+#pragma unroll
+            for (int k = 0; k < RIT; ++k) {
+                const int l1 = l1s[k], l2 = l2s[k];
+                const bool lowy = l1 == 0, lowz = l2 == 0, l0z = lane == 0;  // (lowy, lowz: uniform)
+                if (!(lowy || lowz || nvalid[1])) {  // an interior row of a tile without an x neighbour
+                    if (act[k]) o[offs[k]] = (T)own[k];
+                    continue;
+                }
+                double add = 0.0;  // m = 1 .. 7 in order, as the flat loop adds them
+                if (nvalid[1]) add += nbr(1, act[k] && l0z, l1 + (TY + 1) * l2, TX + (TX + 1) * (l1 + (TY + 1) * l2));
+                if (lowy && nvalid[2]) add += nbr(2, act[k], YF + lane + TX * l2, lane + (TX + 1) * (TY + (TY + 1) * l2));
+                if (lowy && nvalid[3]) add += nbr(3, act[k] && l0z, TY + (TY + 1) * l2, TX + (TX + 1) * (TY + (TY + 1) * l2));
+                if (lowz && nvalid[4]) add += nbr(4, act[k], ZF + lane + TX * l1, lane + (TX + 1) * (l1 + (TY + 1) * TZ));
+                if (lowz && nvalid[5]) add += nbr(5, act[k] && l0z, l1 + (TY + 1) * TZ, TX + (TX + 1) * (l1 + (TY + 1) * TZ));
+                if (lowy && lowz && nvalid[6])
+                    add += nbr(6, act[k], YF + TX * TZ + lane, lane + (TX + 1) * (TY + (TY + 1) * TZ));
+                if (lowy && lowz && nvalid[7])
+                    add += nbr(7, act[k] && l0z, TY + (TY + 1) * TZ, TX + (TX + 1) * (TY + (TY + 1) * TZ));
+                if (act[k]) o[offs[k]] = (T)(own[k] + add);
+            }
+            return;
+        }
         if (!split) {
             // An unsplit 3-D tile, ROW form.  The flat form below spends ~2000 VALU instructions
             // per thread on index arithmetic (face coordinates by div / mod, seven neighbour
