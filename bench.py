@@ -121,18 +121,18 @@ def algorithmic_bytes(cfg, B, P=None, with_point_weight=False):
     return a_fwd, a_bwd
 
 
-def load_traffic_profile(cfg, algo_f, order):
+def load_traffic_profile(cfg, algo_f, order, poses=None):
     """HBM bytes per forward call from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in
     separate rocprofv3 passes of this same command and corrected as MI355X_MICROARCH.md
     prescribes); measured offline, committed under profiles/ -- bench.py cannot profile itself."""
-    for name in ("r05_c3_hbm_traffic.json", "r04_c3_hbm_traffic.json", "r03_c3_hbm_traffic.json",
+    for name in ("r06_hbm_traffic.json", "r05_c3_hbm_traffic.json", "r04_c3_hbm_traffic.json", "r03_c3_hbm_traffic.json",
                  "r02_c3_hbm_traffic.json", "r01_c3_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         with open(path) as f:
             prof = json.load(f)
-        key = f"{cfg}/{algo_f}/{order}"
+        key = f"{cfg}/{algo_f}/{order}" + (f"/B{poses}" if poses and poses > 1 else "")
         ent = prof.get("forward", {}).get(key)
         if ent:
             return {"bytes": ent["hbm_bytes_corrected"], "source": f"profiles/{name}[{key}]"}
@@ -287,6 +287,17 @@ def run_rank(args):
         torch.cuda.empty_cache()
         sh = run_job(share_args, "C4", rank, world, device, dist, backend, lean=True)
         ceiling = ref["ms_per_step"] / sh["ms_per_step"]
+        # ... and the same two for a caller that sorts the cloud ONCE outside the step (dpr_sort_points_* +
+        # DPR_FLAG_COHERENT_POINTS: pose refinement over a fixed cloud -- what the reference's example does):
+        # the in-call sort is a per-call cost that does not shrink with the pose share
+        so_args = argparse.Namespace(**vars(ref_args))
+        so_args.order, so_args.coherent = "hilbert", True
+        torch.cuda.empty_cache()
+        so_ref = run_job(so_args, "C4", rank, world, device, dist, backend, lean=True)
+        so_share_args = argparse.Namespace(**vars(so_args))
+        so_share_args.poses = 64
+        torch.cuda.empty_cache()
+        so_sh = run_job(so_share_args, "C4", rank, world, device, dist, backend, lean=True)
         line["scaling_reference"] = {
             "what": "the job of the --gpus N > 1 runs (C4: 10M points -> 512^2, 512 poses, fwd+bwd, "
                     "AUTO) on ONE GPU, same process: value(N) / this value = same-job strong scaling",
@@ -299,6 +310,14 @@ def run_rank(args):
                                       "command": "python bench.py --config C4 --poses 64"},
             "predicted_speedup_at_8_gpus_before_exchange": round(ceiling, 2),
             "exposed_exchange_budget_ms_for_6x": round(ref["ms_per_step"] / 6.0 - sh["ms_per_step"], 3),
+            "cloud_sorted_once_outside_the_step": {
+                "what": "the same job and share on a cloud Hilbert-sorted once by the caller (dpr_sort_points, "
+                        "not timed) + DPR_FLAG_COHERENT_POINTS",
+                "ms_per_step": so_ref["ms_per_step"], "value": so_ref["value"],
+                "share_of_one_gpu_of_8_ms_per_step": so_sh["ms_per_step"],
+                "predicted_speedup_at_8_gpus_before_exchange": round(so_ref["ms_per_step"] / so_sh["ms_per_step"], 2),
+                "exposed_exchange_budget_ms_for_6x": round(so_ref["ms_per_step"] / 6.0 - so_sh["ms_per_step"], 3),
+            },
             "prediction_is": "a ceiling computed from one-GPU measurements (job time / share time); "
                              "the 160 MB all-reduce per step overlaps the next step's kernels, what "
                              "of it stays exposed has to fit the budget above for >= 6x; NOT measured "
@@ -541,7 +560,7 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
         "ms_is": f"median of {reps} event-timed calls",
         "frac_of_measured_copy_peak": round(gbs(a_fwd, ms_fwd) / HBM_COPY_GBS, 4),
     }
-    traffic = load_traffic_profile(cfg, algo_f, args.order)
+    traffic = load_traffic_profile(cfg, algo_f, args.order, B_local if batched else None)
     if traffic:
         roof["traffic"], roof["traffic_source"] = traffic["bytes"], traffic["source"]
     if do_bwd:
@@ -645,6 +664,11 @@ def run_job(args, cfg, rank, world, device, dist, backend, lean=False):
         # (a secondary figure: median of 3 loops, like the headline)
         el = float(np.median([timed(args.steps, False) for _ in range(3 if world == 1 else 1)]))
         line["config"]["drop_in_ms_per_step"] = round(el / args.steps * 1e3, 4)
+        line["config"]["rotation_layout"] = ("column-major N_out x N_in per pose (the reference's SMatrix memory, what the C "
+                                             "ABI takes), prepared ONCE outside the step with column_major_rotation(); "
+                                             "rounds 1-4 passed a row-major torch tensor and the host mirror transposed it "
+                                             "inside every call (two copy kernels, ~9 us per step at C3): their "
+                                             "ms_per_step includes that, round 5+ does not")
         line["config"]["drop_in_is"] = ("the same step through the plain dpr_raster_* / dpr_raster_pullback_* "
                                         "entry points (no KEEP / REUSE flags): the `no_share` entry")
         line["no_share"] = {"timing": "median of 3 loops" if world == 1 else "one loop",

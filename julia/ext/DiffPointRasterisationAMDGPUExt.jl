@@ -233,7 +233,7 @@ function raster_residual_pullback!(
     rot, tr = devbuf(rotation, T), devbuf(translation, T)
     ow, pw = devbuf(out_weight, T), devbuf(point_weight, T)
     grid = collect(Int64, size(out)[1:N_out])
-    ws = workspace(1, T, N_in, N_out, grid, P, B)
+    ws = workspace(2, T, N_in, N_out, grid, P, B)  # DPR_OP_RESIDUAL_PULLBACK (include/dpr.h)
     GC.@preserve out target points rot tr ow pw ws begin
         args = (AMDGPU.stream().stream, N_in, N_out, grid, P, B, devptr(out, T), devptr(target, T),
             Float64(scale), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(ow, T),

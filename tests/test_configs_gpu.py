@@ -124,6 +124,48 @@ def test_c5_share_8_poses(dev):
     assert_close(pb.point_weight, np.full(P, 0.5 * float(ow.sum())), 1e-12)
 
 
+def test_c5_full_job_64_poses_of_50m_points_on_one_gpu(dev):
+    """BASELINE.json configs[4] as ONE job on one GPU -- the N = 1 anchor of its scaling curve: 50 M points ->
+    512^3 fp64, all 64 poses in one call each way (`out` and `ds_dout`: 68.7 GB each; with the workspace
+    ~165 GB of the 288).  Too large for the oracle: size-independent properties per pose -- mass (every
+    point of the ball lands inside the grid under every pose: sum(out[b]) = out_weight[b] * P), the
+    background sensitivity (= sum of ds_dout[b]), the adjoint identity <ds_dout[b], out[b]> = out_weight[b]
+    * ds_dout_weight[b] (the forward is linear in out_weight) -- and a constant sensitivity, whose point
+    gradients vanish while ds_dpoint_weight = 0.5 * sum(out_weight)."""
+    P, n, B = 50_000_000, 512, 64
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 200e9:
+        pytest.skip(f"needs ~170 GB of device memory, {free / 1e9:.0f} GB free")
+    f64 = dict(device=dev, dtype=torch.float64)
+    pts = _ball_points(P, dev, torch.float64, seed=5)
+    rng = np.random.default_rng(6)
+    R = T(D.random_rotations(rng, B), dev)
+    t = T((0.05 * rng.normal(size=(B, 3))).clip(-0.1, 0.1), dev)
+    ow = torch.linspace(0.5, 1.5, B, **f64)
+    out = dpr_amd.raster((n, n, n), pts, R, t, None, ow)
+    mass = out.sum(dim=(0, 1, 2))
+    assert float((mass - ow * P).abs().max()) <= 1e-9 * P
+    g = torch.empty(B, n, n, n, **f64)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    for b in range(B):
+        g[b].normal_(generator=gen)
+    g = g.permute(3, 2, 1, 0)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, None, ow)
+    for b in range(0, B, 7):  # (every seventh pose: each check reads 2 x 1 GB)
+        gb = g[..., b]
+        assert abs(float(pb.background[b]) - float(gb.sum())) <= 1e-8 * float(gb.abs().sum())
+        lhs = float((gb * out[..., b]).sum())
+        rhs = float(ow[b]) * float(pb.out_weight[b])
+        assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.0), b
+    assert bool(torch.isfinite(pb.points).all()) and bool(torch.isfinite(pb.rotation).all())
+    del out
+    torch.cuda.empty_cache()
+    g.fill_(0.5)
+    pb = dpr_amd.raster_pullback_(g, pts, R, t, None, ow)
+    assert float(pb.points.abs().max()) <= 1e-9 * n * B
+    assert float((pb.point_weight - 0.5 * float(ow.sum())).abs().max()) <= 1e-10 * B
+
+
 @pytest.mark.parametrize("n_points,n_in,n_out,batch,grid_n", [
     (500, 3, 3, 1, 8),          # AUTO -> atomic: nothing to keep, the flags are ignored
     (300_000, 3, 3, 1, 64),     # AUTO -> tiled for both calls, shared binning

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): bench lines + rocprofv3 kernel stats + HBM traffic PMC passes of round 5.
-# Outputs under gpurun_out/final5/ ; tools/summarise_profiles_r05.py turns them into profiles/r05_*.
+# Runs on the GPU box (gpurun): bench lines + rocprofv3 kernel stats + HBM traffic PMC passes of round 6.
+# Outputs under gpurun_out/final6/ ; tools/summarise_profiles_r06.py turns them into profiles/r06_*.
 # Every profiled program is `python ...` itself after `--` (no wrapper that would re-exec).
 set -o pipefail
 ROOT=$PWD
-O=$ROOT/gpurun_out/final5
+O=$ROOT/gpurun_out/final6
 PART=${1:-all}   # "a" = bench lines + kernel stats, "b" = counter passes + the rest (two gpurun calls)
 mkdir -p $O
 step() { echo "== $1 $(date +%T)"; }
@@ -18,6 +18,10 @@ step bench_c4
 timeout -k 10 300 python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --cpu-budget 5 2>/dev/null | tail -1 > $O/bench_c4_64poses.json || exit 1
 step bench_c5
 timeout -k 10 300 python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5_8poses.json || exit 1
+step bench_c5_coherent
+timeout -k 10 300 python bench.py --config C5 --poses 8 --order hilbert --coherent --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c5_8poses_coherent.json || exit 1
+step bench_c5_full
+timeout -k 10 600 python bench.py --config C5 --poses 64 --steps 2 --warmup 1 --cpu-budget 15 2>/dev/null | tail -1 > $O/bench_c5_full.json || exit 1
 step bench_c3_coherent_auto
 timeout -k 10 300 python bench.py --order hilbert --coherent --steps 30 --warmup 5 --no-cpu-baseline --no-scaling-reference 2>/dev/null | tail -1 > $O/bench_c3_coherent_auto.json || exit 1
 step bench_c3_coherent_chunked
@@ -51,9 +55,26 @@ for mode in random coh_chunked; do
   step sqi_$mode
   timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD --output-format csv -d $O/sqi_$mode -- python3 $ROOT/bench.py --steps 3 --warmup 1 $ARGS $M > $O/sqi_$mode.log 2>&1 || exit 1
 done
+step fetch_c5
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_c5 -- python $ROOT/bench.py --config C5 --poses 8 --steps 2 --warmup 1 $ARGS > $O/fetch_c5.log 2>&1 || exit 1
+step write_c5
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_c5 -- python $ROOT/bench.py --config C5 --poses 8 --steps 2 --warmup 1 $ARGS > $O/write_c5.log 2>&1 || exit 1
 cd $ROOT
-step owner_stats
-DPR_LIB_OVERRIDE=$ROOT/diffpointrasterisation.jl_amd/libdpr_stats.so timeout -k 10 200 python tools/own_probe.py > $O/owner_stats.json 2>/dev/null || true
+step ablations
+P=$ROOT/diffpointrasterisation.jl_amd
+(python tools/c3_stage_probe.py --tag shipped
+ for n in 1 2 3; do [ -f $P/libdpr_abl$n.so ] && DPR_LIB_OVERRIDE=$P/libdpr_abl$n.so python tools/c3_stage_probe.py --tag tile_splat_ablation_$n; done
+ python tools/c3_stage_probe.py --coherent --tag shipped_coherent_tiled
+ python tools/c3_stage_probe.py --coherent --algo chunked --tag shipped_coherent_chunked
+ [ -f $P/libdpr_own_noatom.so ] && DPR_LIB_OVERRIDE=$P/libdpr_own_noatom.so python tools/c3_stage_probe.py --coherent --algo chunked --tag own_splat_without_lds_atomics
+ [ -f $P/libdpr_own_map0.so ] && DPR_LIB_OVERRIDE=$P/libdpr_own_map0.so python tools/c3_stage_probe.py --coherent --algo chunked --tag own_splat_quads_of_neighbouring_lanes
+ for n in 1 2 3; do [ -f $P/libdpr_planstop$n.so ] && DPR_LIB_OVERRIDE=$P/libdpr_planstop$n.so python tools/c3_stage_probe.py --coherent --algo chunked --tag plan_stopped_after_phase_$n; done
+) 2>/dev/null > $O/ablations.jsonl
+step microbench
+[ -x tools/microbench_valu ] && ./tools/microbench_valu > $O/microbench_valu.txt 2>&1
+[ -x tools/microbench_write ] && ./tools/microbench_write > $O/microbench_write.txt 2>&1
+step readme_timings
+timeout -k 10 300 python tools/readme_timings.py 2>&1 | grep -v amdgpu.ids > $O/readme_timings.txt
 step other_configs
 timeout -k 10 600 python tools/bench_configs.py 2>&1 | grep -v amdgpu.ids > $O/other_configs.txt
 ls $O

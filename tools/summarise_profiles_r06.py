@@ -1,12 +1,12 @@
-"""Turns gpurun_out/final5/* (tools/collect_profiles_r05.sh) into the committed profiles/r05_* files."""
+"""Turns gpurun_out/final6/* (tools/collect_profiles_r06.sh) into the committed profiles/r06_* files."""
 import collections, csv, glob, json, os, shutil, subprocess
-O = "gpurun_out/final5"
-for a, b in [("bench_default.json", "r05_bench_default.json"), ("bench_under_rocprof.json", "r05_bench_under_rocprof.json"),
-             ("bench_c2.json", "r05_bench_c2.json"), ("bench_c4_64poses.json", "r05_bench_c4_64poses.json"),
-             ("bench_c5_8poses.json", "r05_bench_c5_8poses.json"),
-             ("bench_c3_coherent_auto.json", "r05_bench_c3_coherent_auto.json"),
-             ("bench_c3_coherent_chunked.json", "r05_bench_c3_coherent_chunked.json"),
-             ("owner_stats.json", "r05_owner_forward_stats.json"), ("other_configs.txt", "r05_other_configs.txt")]:
+O = "gpurun_out/final6"
+for a, b in [("bench_default.json", "r06_bench_default.json"), ("bench_under_rocprof.json", "r06_bench_under_rocprof.json"),
+             ("bench_c2.json", "r06_bench_c2.json"), ("bench_c4_64poses.json", "r06_bench_c4_64poses.json"),
+             ("bench_c5_8poses.json", "r06_bench_c5_8poses.json"),
+             ("bench_c3_coherent_auto.json", "r06_bench_c3_coherent_auto.json"),
+             ("bench_c3_coherent_chunked.json", "r06_bench_c3_coherent_chunked.json"),
+             ("bench_c5_8poses_coherent.json", "r06_bench_c5_8poses_coherent.json"), ("bench_c5_full.json", "r06_bench_c5_full.json"), ("ablations.jsonl", "r06_ablations.jsonl"), ("microbench_valu.txt", "r06_microbench_valu.txt"), ("microbench_write.txt", "r06_microbench_write_bandwidth.txt"), ("readme_timings.txt", "r06_reference_readme_timings.txt"), ("other_configs.txt", "r06_other_configs.txt")]:
     if os.path.exists(f"{O}/{a}") and os.path.getsize(f"{O}/{a}") > 0:
         shutil.copy(f"{O}/{a}", f"profiles/{b}")
 
@@ -21,11 +21,11 @@ def kernel_stats(sub, title, dst):
     print("\n".join(lines))
 
 CMD = "rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-secondary --no-scaling-reference"
-kernel_stats("stats", CMD + "\n(C3: 10M points 0.4*N(0,I) random order -> 256^3 fp32, tiled algorithm, KEEP / REUSE pair, MI355X)", "r05_c3_kernel_stats")
-kernel_stats("stats_coh_auto", CMD + " --order hilbert --coherent\n(C3, Hilbert-sorted cloud + DPR_FLAG_COHERENT_POINTS, DPR_ALGO_AUTO: tiled forward with local binning, direct 3-D pullback)", "r05_c3_coherent_auto_kernel_stats")
-kernel_stats("stats_coh_chunked", CMD + " --order hilbert --coherent --algo chunked\n(C3, Hilbert-sorted cloud, DPR_ALGO_CHUNKED: owner-computes forward over the box hierarchy, direct pullback)", "r05_c3_coherent_chunked_kernel_stats")
-kernel_stats("stats_c4", "rocprofv3 --kernel-trace --stats -- python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-scaling-reference\n(C4 at the share of one GPU of 8: 10M points -> 512^2 fp32, 64 poses, chunk-owner algorithm)", "r05_c4_kernel_stats")
-kernel_stats("stats_c5", "rocprofv3 --kernel-trace --stats -- python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-scaling-reference\n(C5 at the share of one GPU of 8: 50M points -> 512^3 fp64, 8 poses, tiled algorithm)", "r05_c5_kernel_stats")
+kernel_stats("stats", CMD + "\n(C3: 10M points 0.4*N(0,I) random order -> 256^3 fp32, tiled algorithm, KEEP / REUSE pair, MI355X)", "r06_c3_kernel_stats")
+kernel_stats("stats_coh_auto", CMD + " --order hilbert --coherent\n(C3, Hilbert-sorted cloud + DPR_FLAG_COHERENT_POINTS, DPR_ALGO_AUTO: tiled forward with local binning, direct 3-D pullback)", "r06_c3_coherent_auto_kernel_stats")
+kernel_stats("stats_coh_chunked", CMD + " --order hilbert --coherent --algo chunked\n(C3, Hilbert-sorted cloud, DPR_ALGO_CHUNKED: owner-computes forward over the box hierarchy, direct pullback)", "r06_c3_coherent_chunked_kernel_stats")
+kernel_stats("stats_c4", "rocprofv3 --kernel-trace --stats -- python bench.py --config C4 --poses 64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-scaling-reference\n(C4 at the share of one GPU of 8: 10M points -> 512^2 fp32, 64 poses, chunk-owner algorithm)", "r06_c4_kernel_stats")
+kernel_stats("stats_c5", "rocprofv3 --kernel-trace --stats -- python bench.py --config C5 --poses 8 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-scaling-reference\n(C5 at the share of one GPU of 8: 50M points -> 512^3 fp64, 8 poses, tiled algorithm)", "r06_c5_kernel_stats")
 
 def pmc(pattern, name):
     rows = list(csv.DictReader(open(max(glob.glob(pattern), key=os.path.getmtime))))
@@ -82,7 +82,47 @@ for mode, key_f, key_b in (("random", "C3/tiled/random", "C3/tiled/random"),
                          "write_bytes": round(tot[grp][2]), "hbm_bytes_corrected": round(tot[grp][1] + tot[grp][2]),
                          "hbm_bytes_upper_bound": round(2 * tot[grp][0] + tot[grp][2]),
                          "collected_with": mode}
-json.dump(out, open("profiles/r05_c3_hbm_traffic.json", "w"), indent=1)
+# C5 share (50 M points -> 512^3 fp64, 8 poses): HBM bytes per CALL (all launches of one forward / one pullback
+# over the 8 poses).  Calls in the profiled run = launches of k_bin_local (one per forward call: all 8 poses in
+# one launch; the pullback of the KEEP / REUSE pair does not bin).
+if glob.glob(f"{O}/fetch_c5/*/*_counter_collection.csv"):
+    def whole_run(pattern, name):
+        rows = list(csv.DictReader(open(max(glob.glob(pattern), key=os.path.getmtime))))
+        tot = collections.defaultdict(float); n = collections.defaultdict(int)
+        for r in rows:
+            if r["Counter_Name"] == name:
+                k = r["Kernel_Name"].split("<")[0].split("(")[0].replace("void ", "")
+                tot[k] += float(r["Counter_Value"]) * 1024; n[k] += 1
+        return tot, n
+    fa, fn = whole_run(f"{O}/fetch_c5/*/*_counter_collection.csv", "FETCH_SIZE")
+    wa, wn = whole_run(f"{O}/write_c5/*/*_counter_collection.csv", "WRITE_SIZE")
+    ncall = max(fn.get("dpr::k_bin_local", 0), 1)
+    P5, G5, B5 = 50_000_000, 512 ** 3, 8
+    # what a kernel must read per CALL (bytes): decides the doubling of its FETCH_SIZE as above
+    floors = {"dpr::k_cell_count": 24 * P5, "dpr::k_cell_scatter": 24 * P5, "dpr::k_bin_local": 24 * P5,
+              "dpr::k_tile_splat_runs": 32 * P5 * B5, "dpr::k_tile_gather_runs": (32 * P5 + 8 * G5) * B5,
+              "dpr::k_unpermute_batch": 36 * P5 * B5, "dpr::k_unpermute": 36 * P5 * B5}
+    bwd5 = ("dpr::k_tile_gather", "dpr::k_tile_gather_runs", "dpr::k_unpermute", "dpr::k_unpermute_batch", "dpr::k_pose_reduce",
+            "dpr::k_unsort", "dpr::k_own_pullback", "dpr::k_own_pullback_batch", "dpr::k_own_reduce", "dpr::k_own_reduce_batch")
+    tot = {"forward": [0.0, 0.0, 0.0], "pullback": [0.0, 0.0, 0.0]}
+    for k in sorted(set(fa) | set(wa)):
+        if not (k.startswith("dpr::") or k.startswith("__amd_rocclr_fill")):
+            continue
+        fr, wr = fa.get(k, 0.0) / ncall, wa.get(k, 0.0) / ncall
+        floor = floors.get(k, 0)
+        doubled = floor > 0 and fr < 0.75 * floor
+        fc = 2 * fr if doubled else fr
+        out["kernels"][f"{k}/c5_share_per_call"] = {"FETCH_SIZE_bytes_raw": round(fr), "must_read_bytes": floor, "fetch_doubled": doubled,
+                                                    "fetch_bytes_corrected": round(fc), "WRITE_SIZE_bytes": round(wr),
+                                                    "launches_per_call": round(fn.get(k, wn.get(k, 0)) / ncall, 2)}
+        grp = "pullback" if k in bwd5 else "forward"
+        tot[grp][0] += fr; tot[grp][1] += fc; tot[grp][2] += wr
+    for grp in ("forward", "pullback"):
+        out[grp]["C5/tiled/random/B8"] = {"fetch_bytes_raw": round(tot[grp][0]), "fetch_bytes_corrected": round(tot[grp][1]),
+                                          "write_bytes": round(tot[grp][2]), "hbm_bytes_corrected": round(tot[grp][1] + tot[grp][2]),
+                                          "hbm_bytes_upper_bound": round(2 * tot[grp][0] + tot[grp][2]),
+                                          "collected_with": f"bench.py --config C5 --poses 8 ({ncall} calls in the profiled run)"}
+json.dump(out, open("profiles/r06_hbm_traffic.json", "w"), indent=1)
 for grp in ("forward", "pullback"):
     for k, v in out[grp].items():
         print(grp, k, {a: (round(b / 1e6, 1) if isinstance(b, (int, float)) else b) for a, b in v.items()})
@@ -110,9 +150,9 @@ HEAD = ("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACT
         "One pass of 8 SQ slots per command; averages per launch.  Derived columns: simd_time = kernel duration (kernel trace of the same command) x 1024 SIMDs x 2.0 GHz / 4\n"
         "(the clock is an assumption, +-10 %); waves/SIMD = WAVE_CYCLES / simd_time; VALU busy = ACTIVE_INST_VALU / simd_time; LDS busy likewise.\n\n")
 if glob.glob(f"{O}/sq_random/*/*_counter_collection.csv"):
-    open("profiles/r05_c3_sq_counters.txt", "w").write(HEAD)
-    sq("sq_random", "sqi_random", "profiles/r05_c3_kernel_stats.txt", "C3 step, random order", "r05_c3_sq_counters.txt", "a")
-    sq("sq_coh_chunked", "sqi_coh_chunked", "profiles/r05_c3_coherent_chunked_kernel_stats.txt",
-       "C3 step, --order hilbert --coherent --algo chunked (k_hilbert_keys / k_gather_points: the bench's untimed pre-sort)", "r05_c3_sq_counters.txt", "a")
-d = json.load(open("profiles/r05_bench_default.json"))
+    open("profiles/r06_c3_sq_counters.txt", "w").write(HEAD)
+    sq("sq_random", "sqi_random", "profiles/r06_c3_kernel_stats.txt", "C3 step, random order", "r06_c3_sq_counters.txt", "a")
+    sq("sq_coh_chunked", "sqi_coh_chunked", "profiles/r06_c3_coherent_chunked_kernel_stats.txt",
+       "C3 step, --order hilbert --coherent --algo chunked (k_hilbert_keys / k_gather_points: the bench's untimed pre-sort)", "r06_c3_sq_counters.txt", "a")
+d = json.load(open("profiles/r06_bench_default.json"))
 print("bench:", d["value"], d["ms_per_step"], d.get("ms_per_step_cold"), d["roofline"]["frac"], d["roofline"]["traffic"], d["coherent_input"]["value"], d["cpu_baseline"]["value"], d["no_share"])
