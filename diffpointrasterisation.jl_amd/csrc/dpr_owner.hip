@@ -22,20 +22,20 @@
 //   boxes    k_own_boxes    one streaming pass over the points (the only forward kernel that reads
 //                           all of them): level 0 and 1 for every pose of the group;
 //            k_own_boxes2   level 2 from level 1
-//   plan     k_own_plan     block per (tile, pose): walks the hierarchy top down to LEVEL 0 and writes the
-//                           EXACT list of sub-chunks that reach the tile, in cloud order, into a range of
-//                           the entry pool it reserves; splits heavy tiles into parts (contiguous ranges of
-//                           ~cap / 16 entries) and files the work items in buckets by size (heaviest first)
-//   forward  k_own_splat    block per work item, streaming its entries: a quad of lanes takes a sub-chunk
-//                           (4 points per lane, one 48-byte load), the wave's 64 lanes sit in 64 different
-//                           sub-chunks; list entry of round r + 2 and points of round r + 1 are in flight
-//                           while round r is accumulated.  Only contributions to cells the tile OWNS count
-//                           (a point near a tile face is visited by both tiles; the pad cells take the rest
-//                           and are dropped): no halo exchange, no global atomics; out = background + tile
-//                           with plain stores.  fp32 data: exact 64-bit fixed-point sums (dpr_device.h
-//                           FixScale), fp64 / non-finite weights: f64 atomics.  (Round 5's kernel found its
-//                           points itself -- waves drawing candidate chunks from a counter, 64 box tests,
-//                           queues, batches: 130 us at coherent C3 against 104 for the streamed list.)
+//   plan     k_own_plan     block per (tile, pose): walks the hierarchy top down, writes the tile's
+//                           candidate chunks, estimates its load from the box overlaps, splits
+//                           heavy tiles into parts (every n-th candidate) and files the work items
+//                           in buckets by size (heaviest first)
+//   forward  k_own_splat    block per work item.  A WAVE takes a candidate chunk, tests its 64
+//                           level-0 boxes (one per lane), queues the hits; whenever 64 sub-chunks
+//                           are queued every lane walks ONE of them (16 points, 4 per 48-byte
+//                           load) -- lanes are >= 16 points apart in the cloud, so LDS atomics of
+//                           one instruction rarely share an address.  Only contributions to cells
+//                           the tile OWNS count (a point near a tile face is visited by both
+//                           tiles; the pad cells take the rest and are dropped): no halo exchange,
+//                           no global atomics; out = background + tile with plain stores.  fp32
+//                           data: exact 64-bit fixed-point sums (dpr_device.h FixScale), fp64 /
+//                           non-finite weights: f64 atomics.
 //            k_own_combine  split tiles only: the parts left their raw 64-bit tiles in slabs,
 //                           summed here (integer sums: exact, whatever the split)
 //   pullback k_own_pullback a thread per point in cloud order, gathers straight from ds_dout (the
@@ -44,8 +44,8 @@
 //            k_own_reduce   per-block partial sums (f64) -> ds_drotation, ds_dtranslation, ...
 //
 // Correct for ANY point order: a box that covers half the grid is listed by every tile it
-// overlaps (slow, never wrong); a tile with more than 512 candidate chunks, or whose list does not fit
-// the entry pool any more, takes EVERY sub-chunk of the cloud and culls by level-0 box in the tile kernel.  Reference semantics: /root/reference/src/raster.jl:36-66 (forward kernel),
+// overlaps (slow, never wrong); candidate lists that outgrow their buffer make the tile take every
+// chunk as a candidate.  Reference semantics: /root/reference/src/raster.jl:36-66 (forward kernel),
 // src/raster_pullback.jl:39-72 (per-point pullback), :85-148 (batch).
 #include <hip/hip_runtime.h>
 
@@ -76,14 +76,11 @@ constexpr int kPCells = kPX * kPY * kPZ;                    // 18496
 constexpr int kBuckets = 16;
 constexpr int kMaxParts = 32;
 constexpr int kOwnBw = 16;           // poses planned at once (one copy of the per-pose arrays each)
-constexpr int kPoolCursors = 8;      // sub-pools of the entry pool (a tile allocates from the one its number hashes to)
-constexpr int kM0 = 512;             // candidate chunks (of 1024 points) a tile may have: their list, level-0 hit masks
-                                     // and entry offsets live in the plan block's LDS; a tile with more takes every
-                                     // sub-chunk of the cloud and culls by level-0 box in the tile kernel
-constexpr int kCtlWords = 32;        // per pose: [1] slab cursor (pose 0's), [2] split tiles, [3] list overflow
-                                     // seen, [4..11] entry-pool cursors, [16..31] bucket counts
+constexpr int kQueue = 128;          // queued sub-chunks per wave (64 + up to 63 left over)
+constexpr int kCtlWords = 32;        // per pose: [0] list cursor, [1] slab cursor (pose 0's), [2] split
+                                     // tiles, [3] list overflow seen, [16..31] bucket counts
 constexpr int kMaxOwnTiles = 1 << 20;
-constexpr int kPlanHits = 256;       // level-2 boxes a plan block can descend into (more: scan-all tile)
+constexpr int kPlanHits = 1024;      // level-2 boxes a plan block can descend into (more: scan-all tile)
 
 // cells [lo, hi] (per axis, existing cells only) a group of points contributes to under one pose;
 // lo > hi: none (no point of the group has a cell in the grid)
@@ -414,10 +411,7 @@ struct OwnPlanArgs {
     const IBox *b1, *b2;  // [pose copy][nL1], [pose copy][nL2]
     const float* mw1;     // [nL1] max, then at [nL1 + 1 + c] min non-zero |point_weight| per chunk; or nullptr (no point weights)
     int64_t nL1, nL2;
-    uint32_t list_cap;   // level-1 candidates a tile may have before it gives up and takes every sub-chunk
-    uint32_t sub_cap;    // entries per sub-pool of the entry pool (kPoolCursors of them per pose copy)
-    const IBox* b0;      // [pose copy][nSC] level-0 boxes
-    int64_t nSC;
+    uint32_t list_cap;   // entries per tile
     int max_items;       // per bucket
     int max_slabs;       // per pose group
     int max_split;       // per pose
@@ -427,20 +421,15 @@ struct OwnPlanArgs {
 
 // block per (tile, pose copy): level-2 boxes that reach the tile are collected first (wave w scans
 // the w-th quarter: a deterministic order), then the waves test the 64 chunks under each of them
-// (independent loads, two in flight per wave) and keep the hit masks in LDS.  Round 6: the block then
-// descends to LEVEL 0 itself -- two sweeps over the 64 sub-chunk boxes of every candidate chunk (count,
-// reserve a range of the entry pool, write) -- and leaves the EXACT list of sub-chunks that reach the
-// tile, in cloud order.  The tile kernel streams that list: no box tests, no queues, no counters in its
-// way (round 5: ~107 of its 123 us at coherent C3 were that walk, a chain of dependent steps per item).
+// (independent loads, two in flight per wave) and keep the hit masks in LDS; the candidate list is
+// written from the masks at the offset the block reserved.
 template <typename T>
 __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int64_t P, const T* __restrict__ ow,
                                                   int has_pw, int64_t bfirst, OwnPlanArgs pa) {
     __shared__ uint32_t s_hit[kPlanHits];
     __shared__ unsigned long long s_mask[kPlanHits];
     __shared__ uint32_t s_off[kPlanHits];
-    __shared__ uint32_t s_cnt2[4], s_begin, s_total1, s_total0;
-    __shared__ uint32_t s_l1[kM0], s_o0[kM0];       // candidate chunks (level 1) in cloud order; offsets of their entries
-    __shared__ unsigned long long s_m0[kM0];        // level-0 hit mask of every candidate chunk
+    __shared__ uint32_t s_cnt2[4], s_begin;
     __shared__ float s_est[4], s_mw[4], s_mn[4];
     const int tile = blockIdx.x, bl = blockIdx.y;
     const int64_t b = bfirst + bl;
@@ -536,114 +525,29 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
         s_mn[wave] = mn;
     }
     __syncthreads();
-#if defined(DPR_PLAN_STOP) && DPR_PLAN_STOP == 1
-    return;
-#endif
-    // 3. level-1 candidates in order: s_off[h] = candidates before hit h
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (uint32_t h = 0; h < H; ++h) {
             s_off[h] = total;
             total += (uint32_t)__popcll(s_mask[h]);
         }
-        // more candidates than a tile may have (an incoherent cloud, or a tenth of a large cloud inside one
-        // tile), or level-2 hits that did not fit: the tile takes EVERY sub-chunk of the cloud (their level-0
-        // boxes still cull exactly, in the tile kernel)
-        s_total1 = (scan_all || total > pa.list_cap) ? 0xffffffffu : total;
-    }
-    __syncthreads();
-    const uint32_t total1 = s_total1;
-    const bool give_up = total1 == 0xffffffffu;
-    const IBox* b0 = pa.b0 + (size_t)bl * pa.nSC;
-    if (!give_up) {
-        // the candidate chunks as a list in LDS, in cloud order
-        for (uint32_t h = wave; h < H; h += 4) {
-            const unsigned long long m = s_mask[h];
-            if ((m >> lane) & 1ull)
-                s_l1[s_off[h] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = hit_id(h) * kL2 + (uint32_t)lane;
-        }
-    }
-    __syncthreads();
-    // 4. level 0: hit mask of every candidate chunk (one box per lane; a wave takes candidates w, w + 4, ...,
-    // four of them in flight)
-    if (!give_up) {
-        constexpr int kU = 8;  // candidates a wave has in flight
-        for (uint32_t j0 = wave; j0 < total1; j0 += 4 * kU) {  // (uniform)
-            // (branch-free: clamped indices, all boxes requested before the first is tested -- with the
-            // loads inside `if (j < total1)` each waited for the one before it: 34 us of the plan at C3)
-            IBox bx[kU];
-            bool live[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const uint32_t j = j0 + 4 * u;
-                const int64_t sc = (int64_t)s_l1[j < total1 ? j : total1 - 1] * kFan + lane;
-                live[u] = j < total1 && sc < pa.nSC;
-                bx[u] = b0[sc < pa.nSC ? sc : pa.nSC - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const uint32_t j = j0 + 4 * u;
-                const unsigned long long m0 = __ballot(live[u] && box_hits(bx[u], x0));
-                if (lane == 0 && j < total1) s_m0[j] = m0;
-            }
-        }
-    }
-    __syncthreads();
-#if defined(DPR_PLAN_STOP) && DPR_PLAN_STOP == 2
-    return;
-#endif
-    // 5. offsets of the candidates' entries (one wave: 64 candidates a step), then one thread: entry range,
-    // parts, slabs, fixed-point exponent, work items
-    if (wave == 0 && !give_up) {
-        uint32_t carry = 0;
-        for (uint32_t j0 = 0; j0 < total1; j0 += kWave) {
-            const uint32_t j = j0 + lane;
-            const uint32_t c = j < total1 ? (uint32_t)__popcll(s_m0[j]) : 0u;
-            uint32_t incl = c;
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t v = __shfl_up(incl, o, kWave);
-                if (lane >= o) incl += v;
-            }
-            if (j < total1) s_o0[j] = carry + incl - c;
-            carry += __shfl(incl, kWave - 1, kWave);
-        }
-        if (lane == 0) s_total0 = carry;
-    }
-    __syncthreads();
-#if defined(DPR_PLAN_STOP) && DPR_PLAN_STOP == 3
-    return;
-#endif
-    if (threadIdx.x == 0) {
-        uint32_t total = give_up ? 0u : s_total0;  // entries = sub-chunks that reach the tile
-        // a range of the entry pool: kPoolCursors sub-pools, the tile's number picks one (1216 returning
-        // atomics on ONE cursor queued up for 20 us in round 5)
-        uint32_t begin = 0xffffffffu;
-        if (!give_up && total > 0) {
-            const uint32_t sp = ((uint32_t)tile * 2654435761u) >> 29;  // 0 .. 7
-            static_assert(kPoolCursors == 8, "three hash bits");
-            const uint32_t at = atomicAdd(&ctl[4 + sp], total);
-            if (at + total <= pa.sub_cap) begin = sp * pa.sub_cap + at;
-        } else if (!give_up) {
-            begin = 0u;  // (an empty list)
-        }
-        if (begin == 0xffffffffu) {
-            total = pa.nSC < 0xffffffffll ? (uint32_t)pa.nSC : 0xfffffffeu;  // every sub-chunk
-            ctl[3] = 1u;
-        }
-        s_begin = begin;
-        s_total0 = total;
-    }
-    __syncthreads();
-    // (the waves write the entries -- step 6 -- while thread 0 files the work items)
-    if (threadIdx.x == 0) {
-        const uint32_t begin = s_begin, total = s_total0;
+        const float e = s_est[0] + s_est[1] + s_est[2] + s_est[3];
+        // (largest weight of the candidates, or +Inf = f64 atomics when their non-zero weights span > 2^10)
         const float m = fix_guard_range(fmaxf(fmaxf(s_mw[0], s_mw[1]), fmaxf(s_mw[2], s_mw[3])),
                                         fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3])));
-        // (largest weight of the candidates, or +Inf = f64 atomics when their non-zero weights span > 2^10)
-        // parts: contiguous ranges of the entries, ~cap visits (16 per entry) each
-        const uint64_t ev64 = (uint64_t)total * kSC;
-        const uint32_t ev = ev64 < 4000000000ull ? (uint32_t)ev64 : 4000000000u;
+        // every tile has its own fixed slot of the list buffer (a cursor shared by all the blocks
+        // of a launch made them queue up on one address: 1216 returning atomics = 20 us)
+        uint32_t begin = (uint32_t)tile * pa.list_cap;
+        if (scan_all || total > pa.list_cap) {
+            begin = 0xffffffffu;  // more candidates than the slot holds: the tile takes every chunk
+            total = (uint32_t)pa.nL1;
+            ctl[3] = 1u;
+        }
+        // parts: every n-th candidate each
+        uint32_t ev = e < 4.0e9f ? (uint32_t)e : 4000000000u;
+        // (a tile whose candidates outgrow its slot still has the estimate of the masks; only a tile that could
+        // not scan its level-2 hits knows nothing)
+        if (scan_all) ev = P < 4000000000ll ? (uint32_t)P : 4000000000u;
         uint32_t np = 1;
         if (ev > pa.cap) {
             np = (ev + pa.cap - 1) / pa.cap;
@@ -666,14 +570,13 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
                 ((uint32_t*)(pa.ws + pa.off_split + (size_t)bl * pa.split_stride))[sidx] = (uint32_t)tile;
             }
         }
-        // fixed-point exponent of the tile: |contribution| <= |out_weight| * max|pw| of the candidates, and a
-        // cell collects at most one contribution per point of the CLOUD -- the bound must not depend on the
-        // tile's list, which depends on the order of the points: `out` is promised to be the same bits for any
-        // order (include/dpr.h), and the exponent decides how contributions far below the scale are rounded
+        // fixed-point exponent of the tile: |contribution| <= |out_weight| * max|pw| of the
+        // candidates, at most 1024 contributions per candidate to one cell
         const float owv = ow ? fabsf((float)ow[b]) : 1.f;
         float maxw = __builtin_inff();
         if (sizeof(T) == 4) maxw = owv * (has_pw ? (begin == 0xffffffffu ? __builtin_inff() : m) : 1.f);
-        const int sexp = fix_exponent(maxw, P < 0x7fffffffll ? (uint32_t)(P > 0 ? P : 1) : 0x7fffffffu, pa.fixed);
+        const uint64_t nmax = (uint64_t)(total ? total : 1) * kL1;
+        const int sexp = fix_exponent(maxw, nmax < 0x7fffffffu ? (uint32_t)nmax : 0x7fffffffu, pa.fixed);
         TileRec rec;
         rec.begin = begin;
         rec.count = total;
@@ -698,15 +601,17 @@ __global__ __launch_bounds__(256) void k_own_plan(OGeom tg, GridDesc<3> gd, int6
             it.pad0 = it.pad1 = 0u;
             items[slot + k] = it;
         }
+        s_begin = begin;
     }
+    __syncthreads();
     const uint32_t begin = s_begin;
-    if (begin == 0xffffffffu || give_up) return;
-    // 6. the entries, in cloud order
-    uint32_t* ent = (uint32_t*)(pa.ws + pa.off_list + (size_t)bl * pa.list_stride) + begin;
-    for (uint32_t j = wave; j < total1; j += 4) {
-        const unsigned long long m0 = s_m0[j];
-        if ((m0 >> lane) & 1ull)
-            ent[s_o0[j] + (uint32_t)__popcll(m0 & ((1ull << lane) - 1ull))] = s_l1[j] * kFan + (uint32_t)lane;
+    if (begin == 0xffffffffu) return;
+    // 3. the candidate list from the masks
+    uint32_t* list = (uint32_t*)(pa.ws + pa.off_list + (size_t)bl * pa.list_stride) + begin;
+    for (uint32_t h = wave; h < H; h += 4) {
+        const unsigned long long m = s_mask[h];
+        if ((m >> lane) & 1ull)
+            list[s_off[h] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = hit_id(h) * kL2 + (uint32_t)lane;
     }
 }
 
@@ -718,6 +623,7 @@ struct OwnTileArgs {
     int max_items;
     int64_t nL1, nSC;
     const IBox* b0;    // [pose copy][nSC]
+    size_t dbg_words;  // (stats build: 32-bit words of the slab area, per-item records at its end)
 };
 
 // work item of this block: buckets from the heaviest down
@@ -740,55 +646,152 @@ __device__ __forceinline__ bool own_item(const OwnTileArgs& ta, int bl, uint32_t
     return true;
 }
 
-// The points a lane takes from a sub-chunk: kLanesPerSC neighbouring lanes share one (16 points), four
-// points each -- one 48-byte load per lane, the four lanes read 192 contiguous bytes.
-constexpr int kLanesPerSC = 4;
+// LDS the discovery loop needs (the tile kernels put it in front of their tile)
+constexpr int kLanesPerSC = 4;                   // lanes that share a sub-chunk (4 points each)
+constexpr int kBatchSC = kWave / kLanesPerSC;    // 16 sub-chunks per batch of a wave
 constexpr int kPtsPerLane = kSC / kLanesPerSC;   // 4
-constexpr int kQuads = kOT / kLanesPerSC;        // 256 sub-chunks per round of a block
-template <typename T, bool HAS_PW> struct OwnPts {
-    T v[kPtsPerLane * 3], w[HAS_PW ? kPtsPerLane : 1];
-    int npts;  // live points (0: the lane has no sub-chunk this round)
+struct OwnWalkLds {
+    uint32_t queue[kOW][kQueue];  // per wave: sub-chunks waiting for a full batch
+    uint32_t pool[kOT];           // what the waves had left over (< 16 each), shared out again
+    uint32_t next, pool_n;
+    uint32_t pad[62];
 };
-// request the lane's quarter of sub-chunk `sc` (a lane without work is handed a valid sub-chunk too: it
-// loads like the others and treats every point as dead)
-// (WEIGHTS = false: the coordinates only -- fp64 clouds with point weights fetch the weights of a round when
-// it is worked on, own_load_weights: two rounds of coordinates AND weights in flight do not fit 128 VGPRs)
-template <typename T, bool HAS_PW, bool WEIGHTS = true>
-__device__ __forceinline__ void own_load(uint32_t sc, int quarter, bool have, int64_t P, const T* __restrict__ points,
-                                         const T* __restrict__ pw, bool vec, OwnPts<T, HAS_PW>& d) {
+
+// The discovery loop of a tile kernel.  Waves draw candidate chunks of the item from a counter in
+// LDS, test the 64 level-0 boxes of a chunk (one per lane; the boxes of the NEXT candidate are
+// requested before the current batch is worked on), queue the hits and call `visit(sc, quarter,
+// have)` with 16 queued sub-chunks at a time: four neighbouring lanes share a sub-chunk, four
+// points each (one 48-byte load; the four lanes read 192 contiguous bytes).  A batch is four points
+// deep -- with one lane per sub-chunk it was sixteen, 16-32 us during which the waves that had run
+// out of candidates waited, and the leftovers (up to 63 sub-chunks per wave, re-batched from a
+// pool) cost another sixteen on half the waves: half of an item's time (r05 experiments).  What a
+// wave has left when the candidates run out (< 16 sub-chunks) goes to a pool of the block, which
+// the waves share out again.  One block barrier inside, reached exactly once by every wave.
+template <typename Visit>
+__device__ __forceinline__ void own_walk(const OwnTileArgs& ta, const OwnItem& item, int bl, const int (&x0)[3],
+                                         OwnWalkLds* wl, Visit visit) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t* queue = wl->queue[wave];
+    const uint32_t part = item.part_nparts & 0xffffu, nparts = item.part_nparts >> 16;
+    // a tile whose candidate list did not fit its buffer (an incoherent cloud) takes EVERY chunk
+    // as a candidate: slow, never wrong
+    const bool overflow = item.begin == 0xffffffffu;
+    const uint32_t* list = (const uint32_t*)(ta.ws + ta.off_list + (size_t)bl * ta.list_stride) + (overflow ? 0u : item.begin);
+    const IBox* b0 = ta.b0 + (size_t)bl * ta.nSC;
+    const uint32_t units = item.count;
+    uint32_t qn = 0;
+    int64_t sc_mine = 0;
+    IBox bx;
+    // next candidate chunk of this wave: its level-0 boxes are requested here, tested later
+    auto acquire = [&]() -> bool {
+        uint32_t k = 0;
+        if (lane == 0) k = atomicAdd(&wl->next, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        const uint64_t u = (uint64_t)part + (uint64_t)k * nparts;
+        if (u >= units) return false;
+        const uint32_t c = overflow ? (uint32_t)u : list[u];
+        sc_mine = (int64_t)c * kFan + lane;
+        if (sc_mine < ta.nSC) bx = b0[sc_mine];
+        return true;
+    };
+    bool have_c = acquire();
+    int stage = 0;  // 0: candidates, 2: pooled batches
+    uint32_t pool_pos = 0, pool_total = 0;
+#ifdef DPR_OWN_STATS
+    uint32_t st_batches = 0, st_take = 0, st_tests = 0;
+#endif
+    for (;;) {
+        if (qn >= (uint32_t)kBatchSC || (stage == 2 && qn > 0)) {
+            const uint32_t take = qn >= (uint32_t)kBatchSC ? kBatchSC : qn;
+            const uint32_t base = qn - take;
+            const uint32_t e = (uint32_t)lane / kLanesPerSC;
+            const bool have = e < take;
+            const uint32_t sc = queue[base + (have ? e : 0u)];  // (idle lanes: a valid sub-chunk, not worked on)
+#ifdef DPR_OWN_STATS
+            ++st_batches;
+            st_take += take * kLanesPerSC;
+#endif
+            visit(sc, lane % kLanesPerSC, have);
+            qn = base;
+            continue;
+        }
+        if (stage == 0) {
+            if (have_c) {
+                const bool hit = sc_mine < ta.nSC && box_hits(bx, x0);
+                const unsigned long long mask = __ballot(hit);
+                if (hit) queue[qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)sc_mine;
+                qn += (uint32_t)__popcll(mask);
+#ifdef DPR_OWN_STATS
+                ++st_tests;
+#endif
+                have_c = acquire();
+                continue;
+            }
+            // the candidates are gone: what is left (< 16) goes to the block's pool
+            uint32_t pos = 0;
+            if (lane == 0 && qn) pos = atomicAdd(&wl->pool_n, qn);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if ((uint32_t)lane < qn) wl->pool[pos + lane] = queue[lane];
+            qn = 0;
+#ifdef DPR_OWN_STATS
+            if (threadIdx.x == 0) wl->pad[5] = (uint32_t)wall_clock64();
+#endif
+            __syncthreads();
+#ifdef DPR_OWN_STATS
+            if (threadIdx.x == 0) wl->pad[6] = (uint32_t)wall_clock64();
+#endif
+            pool_total = wl->pool_n;
+            pool_pos = (uint32_t)wave * kBatchSC;
+            stage = 2;
+        }
+        if (pool_pos >= pool_total) break;
+        const uint32_t n = pool_total - pool_pos < (uint32_t)kBatchSC ? pool_total - pool_pos : (uint32_t)kBatchSC;
+        if ((uint32_t)lane < n) queue[lane] = wl->pool[pool_pos + lane];
+        qn = n;
+        pool_pos += kOW * kBatchSC;
+    }
+#ifdef DPR_OWN_STATS
+    if (lane == 0) {
+        atomicAdd(&wl->pad[2], st_batches);
+        atomicAdd(&wl->pad[3], st_take);
+        atomicAdd(&wl->pad[4], st_tests);
+    }
+#endif
+}
+
+// the four points of a lane's quarter of a sub-chunk: body(point index in the sub-chunk, live, pt[3], w)
+template <typename T, bool HAS_PW, typename Body>
+__device__ __forceinline__ void own_points(uint32_t sc, int quarter, bool have, int64_t P,
+                                           const T* __restrict__ points, const T* __restrict__ pw, bool vec,
+                                           Body body) {
     constexpr int N = kPtsPerLane;
+    // (a lane without a sub-chunk was handed a valid one by own_walk: it loads like the others and
+    // treats every point as dead)
     const int64_t p0 = (int64_t)sc * kSC + quarter * N;
     const bool full = p0 + N <= P;  // false only in the last sub-chunk of the cloud
-    d.npts = have ? (full ? N : (p0 < P ? (int)(P - p0) : 0)) : 0;
+    const int npts = have ? (full ? N : (p0 < P ? (int)(P - p0) : 0)) : 0;
+    T v[N * 3], w[N];
     if (full) {
-        load_run<T, N * 3>(points + p0 * 3, vec, d.v);
-        if constexpr (HAS_PW && WEIGHTS) load_run<T, N>(pw + p0, vec, d.w);
+        load_run<T, N * 3>(points + p0 * 3, vec, v);
+        if constexpr (HAS_PW) load_run<T, N>(pw + p0, vec, w);
     } else {
 #pragma unroll
         for (int q = 0; q < N; ++q) {
             const int64_t p = p0 + q;
             const int64_t pc = p < P ? p : P - 1;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) d.v[q * 3 + j] = points[pc * 3 + j];
-            if constexpr (HAS_PW && WEIGHTS) d.w[q] = pw[pc];
+            for (int j = 0; j < 3; ++j) v[q * 3 + j] = points[pc * 3 + j];
+            if constexpr (HAS_PW) w[q] = pw[pc];
         }
     }
-}
-template <typename T>
-__device__ __forceinline__ void own_load_weights(uint32_t sc, int quarter, int64_t P, const T* __restrict__ pw,
-                                                 T (&w)[kPtsPerLane]) {
-    const int64_t p0 = (int64_t)sc * kSC + quarter * kPtsPerLane;
 #pragma unroll
-    for (int q = 0; q < kPtsPerLane; ++q) w[q] = pw[p0 + q < P ? p0 + q : P - 1];
+    for (int q = 0; q < N; ++q) {
+        const T pt[3] = {v[q * 3], v[q * 3 + 1], v[q * 3 + 2]};
+        body(quarter * N + q, q < npts, pt, HAS_PW ? w[q] : T(1));
+    }
 }
 
 // ---------------------------------------------------------------- forward
-// Block per work item = a contiguous range of a tile's ENTRIES (the exact list of sub-chunks that reach
-// the tile, written by k_own_plan; a tile that gave up: every sub-chunk of the cloud, culled here by
-// its level-0 box).  Round r hands entry r * 256 + slot to a quad of lanes; the slots of a wave's 16
-// quads are 16 entries apart, so the LDS atomics of one instruction rarely share a cell (sorted
-// neighbours would).  The list entry of round r + 2 and the points of round r + 1 are requested before
-// round r is accumulated: nothing but the first round waits for memory.
 template <typename T, bool HAS_PW>
 __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int64_t P,
                                                    const T* __restrict__ points, const T* __restrict__ pw,
@@ -798,19 +801,26 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
                                                    OwnTileArgs ta, unsigned long long* __restrict__ slabs,
                                                    T* __restrict__ out) {
     extern __shared__ unsigned char smem[];
-    double* acc = (double*)smem;  // kPCells cells
+    OwnWalkLds* wl = (OwnWalkLds*)smem;
+    double* acc = (double*)(smem + sizeof(OwnWalkLds));  // kPCells cells
     const int bl = blockIdx.y;
     const int64_t b = bfirst + bl;
     OwnItem rec;
     if (!own_item(ta, bl, blockIdx.x, rec)) return;
     const uint32_t tile = rec.tile, part = rec.part_nparts & 0xffffu, nparts = rec.part_nparts >> 16;
+#ifdef DPR_OWN_STATS
+    const uint64_t st_t0 = wall_clock64();
+#define DPR_STAMP(k) do { if (threadIdx.x == 0) wl->pad[8 + (k)] = (uint32_t)(wall_clock64() - st_t0); } while (0)
+#else
+#define DPR_STAMP(k) do { } while (0)
+#endif
     int tc[3], x0[3];
     tile_coords((int)tile, tg, tc, x0);
     const double bgv = bg ? (double)bg[b] : 0.0;
     T* o = out + b * gd.G;
     const bool vec_out = (gd.n[0] & 3) == 0 && (((uintptr_t)o) & 15) == 0;
     if (rec.count == 0 && rec.begin != 0xffffffffu) {
-        // no entry: the tile is background
+        // no candidate: the tile is background
         for (int i = threadIdx.x; i < kCells; i += kOT) {
             const int x = i % kTX, y = (i / kTX) % kTY, z = i / (kTX * kTY);
             const int g0 = x0[0] + x, g1 = x0[1] + y, g2 = x0[2] + z;
@@ -819,97 +829,105 @@ __global__ __launch_bounds__(kOT) void k_own_splat(OGeom tg, GridDesc<3> gd, int
         }
         return;
     }
-    // this part's entries [e0, e0 + n)
-    const bool every = rec.begin == 0xffffffffu;  // (a tile that gave up: entry e IS sub-chunk e)
-    const uint32_t len = (rec.count + nparts - 1) / nparts;
-    const uint32_t e0 = part * len < rec.count ? part * len : rec.count;
-    const uint32_t n = rec.count - e0 < len ? rec.count - e0 : len;
-    const uint32_t* __restrict__ list =
-        (const uint32_t*)(ta.ws + ta.off_list + (size_t)bl * ta.list_stride) + (every ? 0u : rec.begin);
-    const IBox* __restrict__ b0 = ta.b0 + (size_t)bl * ta.nSC;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-#ifndef DPR_OWN_MAP
-#define DPR_OWN_MAP 1
-#endif
-#if DPR_OWN_MAP == 0
-    const int quarter = lane % kLanesPerSC;
-    const uint32_t slot = (uint32_t)(lane / kLanesPerSC) * kOW + (uint32_t)wave;  // 0 .. 255
-#else
-    // the 64 lanes of a wave take the SAME quarter of 64 different sub-chunks, four entries (64 points of the
-    // sorted cloud) apart: the points one ds_add_u64 instruction adds for are rarely neighbours
-    const int quarter = wave >> 2;
-    const uint32_t slot = (uint32_t)lane * 4u + (uint32_t)(wave & 3);  // 0 .. 255
-#endif
-    const uint32_t rounds = (n + kQuads - 1) / kQuads;
-    auto entry = [&](uint32_t r, uint32_t& sc, bool& have) {
-        const uint32_t i = r * kQuads + slot;
-        have = i < n;
-        const uint32_t e = e0 + (have ? i : 0u);
-        if (every) {
-            sc = e < (uint32_t)ta.nSC ? e : 0u;
-            // (the exact cull the plan would have done)
-            if (have) have = e < (uint32_t)ta.nSC && box_hits(b0[sc], x0);
-        } else {
-            sc = n ? list[e] : 0u;
-        }
-    };
-    constexpr bool LATE_W = HAS_PW && sizeof(T) == 8;  // (see own_load)
-    uint32_t sc0 = 0, sc1 = 0, sc2 = 0;
-    bool hv1 = false, hv2 = false;
-    OwnPts<T, HAS_PW> cur, nxt;
-    {
-        bool hv0;
-        entry(0, sc0, hv0);
-        entry(1, sc1, hv1);
-        own_load<T, HAS_PW, !LATE_W>(sc0, quarter, hv0, P, points, pw, vec_ok != 0, cur);
-    }
     for (int i = threadIdx.x; i < kPCells; i += kOT) acc[i] = 0.0;
+    if (threadIdx.x == 0) {
+        wl->next = 0u;
+        wl->pool_n = 0u;
+        for (int k = 0; k < 8; ++k) wl->pad[k] = 0u;
+    }
     const Pose<T, 3, 3> ps = load_pose<T, 3, 3>(rot, trans, ow, b);
     const FixScale fs = fix_scale_from_exponent(rec.sexp);
     const OwnXform<T> xf = own_xform<T>(ps, gd);
+    DPR_STAMP(0);
     __syncthreads();
-#ifdef DPR_OWN_NOATOM
-    unsigned long long abl_sink = 0;
+    DPR_STAMP(1);
+#ifdef DPR_OWN_STATS
+    uint32_t st_vis = 0, st_touch = 0;
+#endif
+#ifdef DPR_OWN_EXP
+    double exp_sink = 0.0;
 #endif
     auto run = [&](auto fix_tag) {
         constexpr bool FIX = decltype(fix_tag)::value;
-        for (uint32_t r = 0; r < rounds; ++r) {  // (uniform)
-            entry(r + 2, sc2, hv2);
-            own_load<T, HAS_PW, !LATE_W>(sc1, quarter, hv1, P, points, pw, vec_ok != 0, nxt);
-            if constexpr (LATE_W) own_load_weights<T>(sc0, quarter, P, pw, cur.w);
-#pragma unroll
-            for (int q = 0; q < kPtsPerLane; ++q) {
-                const T pt[3] = {cur.v[q * 3], cur.v[q * 3 + 1], cur.v[q * 3 + 2]};
+        auto visit = [&](uint32_t sc, int quarter, bool have) {
+            own_points<T, HAS_PW>(sc, quarter, have, P, points, pw, vec_ok != 0, [&](int, bool live, const T (&pt)[3], T pwi) {
                 uint32_t l[3];
                 T dlo[3];
-                const bool ok = own_ref_local<T>(pt, ps, xf, x0, l, dlo) && q < cur.npts;
+                const bool ok = own_ref_local<T>(pt, ps, xf, x0, l, dlo) && live;
                 // padded tile coordinates of the lower neighbour: 0 .. T
-                if (ok && l[0] <= (uint32_t)kTX && l[1] <= (uint32_t)kTY && l[2] <= (uint32_t)kTZ) {
-                    const T w = HAS_PW ? ps.ow * cur.w[HAS_PW ? q : 0] : ps.ow;  // src/raster.jl:52
-                    double* cell = acc + (l[0] + kPX * l[1] + kPX * kPY * l[2]);
+                const uint32_t l0 = l[0], l1 = l[1], l2 = l[2];
+                const bool touches = ok && l0 <= (uint32_t)kTX && l1 <= (uint32_t)kTY && l2 <= (uint32_t)kTZ;
+#if defined(DPR_OWN_STATS) && DPR_OWN_STATS >= 2  /* (per-point counters slow the kernel down 2x) */
+                st_vis += live ? 1u : 0u;
+                st_touch += touches ? 1u : 0u;
+#endif
+#if defined(DPR_OWN_EXP) && DPR_OWN_EXP == 2  /* transform + test only */
+                exp_sink += touches ? (double)dlo[0] : 0.0;
+                if (false) {
+#else
+                if (touches) {
+#endif
+                    const T w = HAS_PW ? ps.ow * pwi : ps.ow;  // src/raster.jl:52
+                    double* cell = acc + (l0 + kPX * l1 + kPX * kPY * l2);
                     // all eight neighbours have a cell (pad cells, and owned cells beyond the grid
                     // edge, are never flushed: the individual drop of src/raster.jl:62)
 #pragma unroll
-                    for (int s_ = 0; s_ < 8; ++s_) {
-#ifdef DPR_OWN_NOATOM  /* ablation: the arithmetic without the LDS atomics (timing only) */
-                        abl_sink ^= fix_bits((float)voxel_weight<T, 3>(dlo, s_, w), fs) + (unsigned long long)(size_t)cell;
+                    for (int s = 0; s < 8; ++s) {
+#if defined(DPR_OWN_EXP) && DPR_OWN_EXP == 1  /* no LDS atomics: where does the time go? */
+                        exp_sink += (double)voxel_weight<T, 3>(dlo, s, w) * fs.mul + (double)(size_t)cell;
 #else
-                        cell_add<FIX, T>(cell + ((s_ & 1) + kPX * ((s_ >> 1) & 1) + kPX * kPY * (s_ >> 2)),
-                                         voxel_weight<T, 3>(dlo, s_, w), fs);
+                        cell_add<FIX, T>(cell + ((s & 1) + kPX * ((s >> 1) & 1) + kPX * kPY * (s >> 2)),
+                                         voxel_weight<T, 3>(dlo, s, w), fs);
 #endif
                     }
                 }
-            }
-            cur = nxt;
-            sc0 = sc1;
-            sc1 = sc2;
-            hv1 = hv2;
-        }
+            });
+        };
+        own_walk(ta, rec, bl, x0, wl, visit);
     };
     if (fs.mul != 0.0) run(std::true_type{});  // (uniform)
     else run(std::false_type{});
-#ifdef DPR_OWN_NOATOM
-    if (abl_sink == 0x123456789ull) acc[threadIdx.x] = 1.0;
+#ifdef DPR_OWN_STATS
+    {
+        const uint32_t a = (uint32_t)wave_sum<int>((int)st_vis), c = (uint32_t)wave_sum<int>((int)st_touch);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&wl->pad[0], a);
+            atomicAdd(&wl->pad[1], c);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t* ctl = (uint32_t*)(ta.ws + ta.off_ctl);
+            atomicAdd(&ctl[4], wl->pad[0]);
+            atomicAdd(&ctl[5], wl->pad[1]);
+            atomicAdd(&ctl[6], wl->pad[2]);
+            atomicAdd(&ctl[7], wl->pad[3]);
+            atomicAdd(&ctl[9], wl->pad[4]);
+            atomicAdd(&ctl[8], 1u);
+            const uint32_t dt = (uint32_t)(wall_clock64() - st_t0);
+            atomicAdd(&ctl[10], dt);
+            atomicMax(&ctl[11], dt);
+            // per-item record at the end of the slab area: {ticks, visits, tile, part | nparts << 16, start tick}
+            uint32_t* dbg = (uint32_t*)(slabs) + (size_t)ta.dbg_words - 8 * ((size_t)blockIdx.x + 1);
+            dbg[0] = dt;
+            dbg[1] = wl->pad[0];
+            dbg[2] = tile;
+            dbg[3] = part | (nparts << 16);
+            dbg[4] = (uint32_t)st_t0;
+            dbg[5] = rec.count;
+            // phases (ticks of 10 ns): setup | zero+barrier | wave 0 to the pool barrier | its wait there | pooled batches + final barrier
+            const uint32_t t_end_walk = (uint32_t)(wall_clock64() - st_t0);
+            atomicAdd(&ctl[12], wl->pad[8]);
+            atomicAdd(&ctl[13], wl->pad[9] - wl->pad[8]);
+            atomicAdd(&ctl[14], (wl->pad[5] - (uint32_t)st_t0) - wl->pad[9]);
+            atomicAdd(&ctl[15], wl->pad[6] - wl->pad[5]);
+            atomicAdd(&ctl[1 + 2], 0u);
+            dbg[6] = t_end_walk - (wl->pad[6] - (uint32_t)st_t0);
+            dbg[7] = wl->pad[8];
+        }
+    }
+#endif
+#ifdef DPR_OWN_EXP
+    if (exp_sink == 1.2345) acc[threadIdx.x] = exp_sink;
 #endif
     __syncthreads();
     // flush the owned cells: thread -> 4 cells along x
@@ -1447,7 +1465,7 @@ static size_t oalign(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct OwnPlan {
     int64_t nSC, nL1, nL2, Bw;
-    uint32_t list_cap, sub_cap, cap;
+    uint32_t list_cap, cap;
     int max_items, max_slabs, max_split;
     size_t off_ctl, off_b0, off_b1, off_b2, off_mw1, off_mw2, off_rec, off_list, off_items, off_split, off_slabs, total;
     size_t rec_stride, list_stride, items_stride, split_stride;
@@ -1486,7 +1504,7 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     // candidate chunks per tile: 64 times the average of a cloud that fills the grid, 256 .. 8192;
     // a tile with more takes every chunk as a candidate (its level-0 tests still cull exactly)
     int64_t lc = (64 * pl.nL1 / tg.NT + 63) / 64 * 64;
-    lc = lc < 256 ? 256 : (lc > kM0 ? kM0 : lc);
+    lc = lc < 256 ? 256 : (lc > 8192 ? 8192 : lc);
     pl.list_cap = (uint32_t)lc;
     size_t o = 0;
     pl.off_ctl = o;
@@ -1504,11 +1522,7 @@ static OwnPlan make_oplan(int op, const OGeom& tg, int64_t P, int64_t B) {
     pl.rec_stride = oalign((size_t)tg.NT * sizeof(TileRec));
     pl.off_rec = o;
     o += pl.rec_stride * pl.Bw;
-    // the entry pool: kPoolCursors sub-pools of nSC / 2 + 64 sub-chunk ids per pose copy (the lists hold
-    // ~1.6 entries per sub-chunk of a coherent cloud; a tile whose list does not fit its sub-pool any more
-    // takes every sub-chunk and culls by level-0 box itself)
-    pl.sub_cap = (uint32_t)(pl.nSC / 2 + 64 < 0x10000000 ? pl.nSC / 2 + 64 : 0x10000000);
-    pl.list_stride = oalign((size_t)pl.sub_cap * kPoolCursors * 4);
+    pl.list_stride = oalign((size_t)pl.list_cap * 4 * tg.NT);
     pl.off_list = o;
     o += pl.list_stride * pl.Bw;
     pl.items_stride = oalign((size_t)kBuckets * pl.max_items * sizeof(OwnItem));
@@ -1568,9 +1582,6 @@ static OwnPlanArgs plan_args(const OwnPlan& pl, char* ws) {
     pa.items_stride = pl.items_stride;
     pa.split_stride = pl.split_stride;
     pa.list_cap = pl.list_cap;
-    pa.sub_cap = pl.sub_cap;
-    pa.b0 = (const IBox*)(ws + pl.off_b0);
-    pa.nSC = pl.nSC;
     pa.max_items = pl.max_items;
     pa.max_slabs = pl.max_slabs;
     pa.max_split = pl.max_split;
@@ -1597,6 +1608,7 @@ static OwnTileArgs tile_args(const OwnPlan& pl, const char* ws) {
     ta.nL1 = pl.nL1;
     ta.nSC = pl.nSC;
     ta.b0 = (const IBox*)(ws + pl.off_b0);
+    ta.dbg_words = (size_t)pl.max_slabs * kCells * 2;
     return ta;
 }
 
@@ -1660,7 +1672,7 @@ int raster_owner(hipStream_t st, unsigned flags, const int64_t* grid, int64_t G,
     char* ws = (char*)ws_;
     const GridDesc<3> gd = ogrid_desc(grid, G);
     const OwnPlan pl = make_oplan(DPR_OP_RASTER, tg, P, B);
-    const size_t lds = (size_t)kPCells * 8;
+    const size_t lds = sizeof(OwnWalkLds) + (size_t)kPCells * 8;
     if (pw) {
         if (int rc = own_lds(k_own_splat<T, true>, lds)) return rc;
     } else {

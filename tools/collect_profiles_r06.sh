@@ -66,9 +66,6 @@ P=$ROOT/diffpointrasterisation.jl_amd
  for n in 1 2 3; do [ -f $P/libdpr_abl$n.so ] && DPR_LIB_OVERRIDE=$P/libdpr_abl$n.so python tools/c3_stage_probe.py --tag tile_splat_ablation_$n; done
  python tools/c3_stage_probe.py --coherent --tag shipped_coherent_tiled
  python tools/c3_stage_probe.py --coherent --algo chunked --tag shipped_coherent_chunked
- [ -f $P/libdpr_own_noatom.so ] && DPR_LIB_OVERRIDE=$P/libdpr_own_noatom.so python tools/c3_stage_probe.py --coherent --algo chunked --tag own_splat_without_lds_atomics
- [ -f $P/libdpr_own_map0.so ] && DPR_LIB_OVERRIDE=$P/libdpr_own_map0.so python tools/c3_stage_probe.py --coherent --algo chunked --tag own_splat_quads_of_neighbouring_lanes
- for n in 1 2 3; do [ -f $P/libdpr_planstop$n.so ] && DPR_LIB_OVERRIDE=$P/libdpr_planstop$n.so python tools/c3_stage_probe.py --coherent --algo chunked --tag plan_stopped_after_phase_$n; done
 ) 2>/dev/null > $O/ablations.jsonl
 step microbench
 [ -x tools/microbench_valu ] && ./tools/microbench_valu > $O/microbench_valu.txt 2>&1
