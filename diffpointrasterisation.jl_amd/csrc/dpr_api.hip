@@ -192,12 +192,14 @@ static bool direct3d_preferred(int op, int n_out, const int64_t* grid, int64_t P
     return P >= 3000000 || (P >= 1000000 && tiled_tiles(n_out, grid) <= 1024);
 }
 
-// (N_in, N_out) with 1 <= N_out <= N_in <= 3: the reference is generic in both
-// (/root/reference/src/raster.jl:5-13, src/util.jl:26-27).  The three shapes its tests use --
-// (2,2), (3,3), (3,2) -- have every algorithm; the others ((1,1), (2,1), (3,1)) run on the direct
-// kernels (DPR_ALGO_ATOMIC), which are templates over both dimensions.
+// (N_in, N_out) with 1 <= N_in, N_out <= 4, in any combination: the reference is generic in both
+// (/root/reference/src/raster.jl:5-13, src/util.jl:26-27 -- 2^N_out neighbours, an N_out x N_in matrix per pose).
+// The three shapes its tests use -- (2,2), (3,3), (3,2) -- have every algorithm; all the others (embeddings with
+// N_out > N_in and 4-D points / grids included) run on the direct kernels (DPR_ALGO_ATOMIC), which are templates
+// over both dimensions.
+constexpr int kMaxDim = 4;
 static bool dims_supported(int n_in, int n_out) {
-    return n_out >= 1 && n_out <= n_in && n_in <= 3;
+    return n_out >= 1 && n_out <= kMaxDim && n_in >= 1 && n_in <= kMaxDim;
 }
 static bool dims_have_all_algos(int n_in, int n_out) {
     return (n_in == 2 && n_out == 2) || (n_in == 3 && n_out == 3) || (n_in == 3 && n_out == 2);
@@ -207,7 +209,7 @@ static int check_common(int n_in, int n_out, const int64_t* grid, int64_t P, int
                         int64_t* G_out) {
     if (!dims_supported(n_in, n_out))
         return fail(DPR_ERR_UNSUPPORTED_DIMS,
-                    "unsupported (n_in, n_out) = (%d, %d); supported: 1 <= n_out <= n_in <= 3", n_in,
+                    "unsupported (n_in, n_out) = (%d, %d); supported: 1 <= n_in, n_out <= 4", n_in,
                     n_out);
     if (!grid) return fail(DPR_ERR_INVALID_ARG, "grid is NULL");
     if (P < 0 || B < 0) return fail(DPR_ERR_INVALID_ARG, "negative P (%lld) or B (%lld)",
@@ -405,9 +407,10 @@ static int raster_impl(void* stream, int algo, unsigned flags, int n_in, int n_o
 #define DPR_CASE_DIRECT(NI, NO)                                                                 \
     if (n_in == NI && n_out == NO && algo == DPR_ALGO_ATOMIC && !(flags & 3u))                  \
         return raster_atomic<T, NI, NO>(st, grid, G, P, B, out, points, rot, trans, bg, ow, pw);
-    DPR_CASE_DIRECT(1, 1)
-    DPR_CASE_DIRECT(2, 1)
-    DPR_CASE_DIRECT(3, 1)
+    DPR_CASE_DIRECT(1, 1) DPR_CASE_DIRECT(2, 1) DPR_CASE_DIRECT(3, 1) DPR_CASE_DIRECT(4, 1)
+    DPR_CASE_DIRECT(1, 2) DPR_CASE_DIRECT(4, 2)
+    DPR_CASE_DIRECT(1, 3) DPR_CASE_DIRECT(2, 3) DPR_CASE_DIRECT(4, 3)
+    DPR_CASE_DIRECT(1, 4) DPR_CASE_DIRECT(2, 4) DPR_CASE_DIRECT(3, 4) DPR_CASE_DIRECT(4, 4)
 #undef DPR_CASE_DIRECT
     if (!dims_have_all_algos(n_in, n_out))
         return fail(DPR_ERR_UNSUPPORTED_ALGO,
@@ -658,9 +661,10 @@ static int pullback_impl(void* stream, int algo, unsigned flags, int n_in, int n
     if (n_in == NI && n_out == NO && algo == DPR_ALGO_ATOMIC && !(flags & 3u))                    \
         return pullback_atomic<T, NI, NO>(st, grid, G, P, B, g, points, rot, trans, ow, pw, d_pts, \
                                           d_rot, d_trans, d_bg, d_ow, d_pw, rs);
-    DPR_CASE_DIRECT(1, 1)
-    DPR_CASE_DIRECT(2, 1)
-    DPR_CASE_DIRECT(3, 1)
+    DPR_CASE_DIRECT(1, 1) DPR_CASE_DIRECT(2, 1) DPR_CASE_DIRECT(3, 1) DPR_CASE_DIRECT(4, 1)
+    DPR_CASE_DIRECT(1, 2) DPR_CASE_DIRECT(4, 2)
+    DPR_CASE_DIRECT(1, 3) DPR_CASE_DIRECT(2, 3) DPR_CASE_DIRECT(4, 3)
+    DPR_CASE_DIRECT(1, 4) DPR_CASE_DIRECT(2, 4) DPR_CASE_DIRECT(3, 4) DPR_CASE_DIRECT(4, 4)
 #undef DPR_CASE_DIRECT
     if (!dims_have_all_algos(n_in, n_out))
         return fail(DPR_ERR_UNSUPPORTED_ALGO,

@@ -33,9 +33,10 @@
  * All data pointers are DEVICE pointers owned by the caller (including the
  * workspace).  Calls only enqueue work on `stream` (a hipStream_t; NULL = the
  * default stream); they never synchronise the device and keep no device memory
- * or global state between calls.  Supported (n_in, n_out): 1 <= n_out <= n_in <= 3.
+ * or global state between calls.  Supported (n_in, n_out): 1 <= n_in, n_out <= 4 in any
+ * combination -- the reference is generic in both (src/raster.jl:5-13).
  * (2,2), (3,3), (3,2) -- the shapes the reference tests (src/raster.jl:112,
- * test/data.jl:13-19) -- have every algorithm; (1,1), (2,1), (3,1) run on
+ * test/data.jl:13-19) -- have every algorithm; all other pairs (incl. n_out > n_in and 4-D) run on
  * DPR_ALGO_ATOMIC (what DPR_ALGO_AUTO resolves to for them; the other algorithms
  * and the KEEP / REUSE flags return DPR_ERR_UNSUPPORTED_ALGO).
  *
@@ -58,7 +59,7 @@ extern "C" {
 
 /* status codes */
 #define DPR_OK 0
-#define DPR_ERR_UNSUPPORTED_DIMS (-1) /* not 1 <= n_out <= n_in <= 3 */
+#define DPR_ERR_UNSUPPORTED_DIMS (-1) /* not 1 <= n_in, n_out <= 4 */
 #define DPR_ERR_INVALID_ARG (-2)      /* NULL required pointer, negative size, bad grid */
 #define DPR_ERR_WORKSPACE (-3)        /* workspace NULL/too small for the chosen algorithm */
 #define DPR_ERR_HIP (-4)              /* a HIP runtime call failed */

@@ -20,7 +20,7 @@
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SUF)
 
-#define DPR_MAX_DIM 3
+#define DPR_MAX_DIM 4
 
 /* src/raster.jl:85-101 reference_coordinate_and_deltas.
  * Returns 0 if the point has no in-range neighbour on some axis (then no
@@ -96,7 +96,7 @@ int FN(oracle_raster)(int n_in, int n_out, const int64_t *grid, int64_t P, int64
                       const REAL *translation, const REAL *background,
                       const REAL *out_weight, const REAL *point_weight)
 {
-    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > n_in) return -1;
+    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > DPR_MAX_DIM) return -1;
     int64_t G = 1;
     REAL scale[DPR_MAX_DIM];
     for (int d = 0; d < n_out; ++d) {
@@ -156,7 +156,7 @@ static void FN(pullback_one_pose)(int n_in, int n_out, const int64_t *grid, int6
         scale[d] = (REAL)grid[d] / (REAL)2; /* :29 */
     }
     const int ns = 1 << n_out;
-    REAL acc_t[DPR_MAX_DIM] = {0, 0, 0};            /* :34 */
+    REAL acc_t[DPR_MAX_DIM] = {0};                  /* :34 */
     REAL acc_R[DPR_MAX_DIM * DPR_MAX_DIM] = {0};    /* :35 */
     REAL acc_ow = 0;                                 /* :36 */
     for (int64_t p = 0; p < P; ++p) {               /* :39 */
@@ -165,7 +165,7 @@ static void FN(pullback_one_pose)(int n_in, int n_out, const int64_t *grid, int6
         int64_t ref0[DPR_MAX_DIM];
         REAL dlo[DPR_MAX_DIM];
         if (!FN(ref_and_deltas)(pt, R, t, scale, n_in, n_out, grid, ref0, dlo)) continue;
-        REAL dcoord[DPR_MAX_DIM] = {0, 0, 0};       /* :46 */
+        REAL dcoord[DPR_MAX_DIM] = {0};             /* :46 */
         REAL dpw_i = 0;                              /* :47 */
         for (int s = 0; s < ns; ++s) {              /* :49 */
             int64_t off = FN(nbr_offset)(ref0, s, n_out, grid);
@@ -211,7 +211,7 @@ int FN(oracle_raster_pullback)(int n_in, int n_out, const int64_t *grid, int64_t
                                REAL *ds_dtranslation, REAL *ds_dbackground,
                                REAL *ds_dout_weight, REAL *ds_dpoint_weight)
 {
-    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > n_in) return -1;
+    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > DPR_MAX_DIM) return -1;
     int64_t G = 1;
     for (int d = 0; d < n_out; ++d) G *= grid[d];
     memset(ds_dpoints, 0, sizeof(REAL) * (size_t)(P * n_in));      /* :112 */
@@ -243,7 +243,7 @@ int FN(oracle_raster_threaded)(int n_in, int n_out, const int64_t *grid, int64_t
                                const REAL *translation, const REAL *background,
                                const REAL *out_weight, const REAL *point_weight)
 {
-    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > n_in) return -1;
+    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > DPR_MAX_DIM) return -1;
     int64_t G = 1;
     REAL scale[DPR_MAX_DIM];
     for (int d = 0; d < n_out; ++d) {
@@ -290,7 +290,7 @@ int FN(oracle_raster_pullback_threaded)(int n_in, int n_out, const int64_t *grid
                                         REAL *ds_dout_weight, REAL *ds_dpoint_weight,
                                         int n_threads)
 {
-    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > n_in) return -1;
+    if (n_in < 1 || n_in > DPR_MAX_DIM || n_out < 1 || n_out > DPR_MAX_DIM) return -1;
     int64_t G = 1;
     for (int d = 0; d < n_out; ++d) G *= grid[d];
     if (n_threads < 1) n_threads = 1;

@@ -34,10 +34,21 @@ def random_rotations(rng, batch, n=3):
     return R
 
 
+def random_isometries(rng, batch, n_out, n_in):
+    """(batch, n_out, n_in) matrices with orthonormal rows (n_out <= n_in: projections of a rotation) or orthonormal
+    columns (n_out > n_in: embeddings) -- the dimension pairs beyond the reference's own data generator."""
+    m = max(n_out, n_in)
+    q = np.linalg.qr(rng.normal(size=(batch, m, m)))[0]
+    return q[:, :n_out, :n_in]
+
+
 def make(n_points=10, n_in=3, n_out=3, batch=3, grid_n=8, seed=0, dtype=np.float64):
     rng = np.random.default_rng(seed)
     points = 0.4 * rng.normal(size=(n_points, n_in))
-    rot = random_rotations(rng, batch, n_in)[:, :n_out, :]
+    if n_in > 3 or n_out > n_in:
+        rot = random_isometries(rng, batch, n_out, n_in)
+    else:
+        rot = random_rotations(rng, batch, n_in)[:, :n_out, :]
     trans = 0.1 * rng.normal(size=(batch, n_out))
     backgrounds = np.arange(1, batch + 1, dtype=np.float64)
     weights = 10 * rng.uniform(size=batch)

@@ -52,8 +52,8 @@ def test_argument_errors_are_reported_without_a_device(suf):
     grid = np.array([8, 8, 8], dtype=np.int64)
     gp = grid.ctypes.data_as(ctypes.c_void_p)
     fn = getattr(L, f"dpr_raster_{suf}")
-    # unsupported dims (2 -> 3)
-    rc = fn(None, 2, 3, gp, 10, 1, None, None, None, None, None, None, None, None, 0)
+    # unsupported dims (1 <= n_in, n_out <= 4 are supported, in any combination)
+    rc = fn(None, 2, 5, gp, 10, 1, None, None, None, None, None, None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
     assert "unsupported" in dpr_amd._lib.last_error()
     # NULL out
@@ -69,13 +69,16 @@ def test_argument_errors_are_reported_without_a_device(suf):
             None, None, None, 0)
     assert rc == dpr_amd._lib.ERR_INVALID_ARG
     pb = getattr(L, f"dpr_raster_pullback_{suf}")
-    rc = pb(None, 1, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_out > n_in
+    rc = pb(None, 0, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_in < 1
     assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
-    rc = pb(None, 4, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_in > 3
+    rc = pb(None, 5, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_in > 4
     assert rc == dpr_amd._lib.ERR_UNSUPPORTED_DIMS
+    rc = pb(None, 1, 2, gp, 10, 1, *([None] * 12), None, 0)  # n_out > n_in is fine: the next check fails
+    assert rc == dpr_amd._lib.ERR_INVALID_ARG
     ws = getattr(L, f"dpr_workspace_bytes_{suf}")
     assert ws(0, 0, 3, 3, gp, 1000, 2) != ctypes.c_size_t(-1).value
-    assert ws(0, 0, 4, 3, gp, 1000, 2) == ctypes.c_size_t(-1).value
+    assert ws(0, 0, 4, 3, gp, 1000, 2) == 0  # (4-D points: the direct kernels, no workspace)
+    assert ws(0, 0, 5, 3, gp, 1000, 2) == ctypes.c_size_t(-1).value
     assert ws(7, 0, 3, 3, gp, 1000, 2) == ctypes.c_size_t(-1).value
 
 

@@ -209,3 +209,65 @@ def test_one_dimensional_grids_follow_appendix_a(oracle, n_in):
                 expect[lo + 1, b] += w * delta[p]
     out = oracle.raster((n,), pts, R, t, bg, ow, pw)
     np.testing.assert_allclose(out, expect, rtol=1e-12, atol=1e-12)
+
+
+def _appendix_a_numpy(grid, pts, R, t, bg, ow, pw):
+    """SURVEY.md Appendix A restated for any (N_in, N_out) in plain numpy / python loops: the reference is
+    generic in both (src/raster.jl:5-13; neighbour order src/util.jl:7-8,26-27)."""
+    n_out = len(grid)
+    B = R.shape[0]
+    out = np.zeros(tuple(grid) + (B,))
+    n = np.asarray(grid, dtype=np.float64)
+    for b in range(B):
+        out[..., b] = bg[b]
+        coord = (pts @ R[b].T + t[b] + 1.0) * (n / 2)           # (P, n_out)
+        ref = np.ceil(coord - 0.5)                               # 1-based upper-neighbour index
+        delta = coord - (ref - 0.5)
+        for p in range(pts.shape[0]):
+            lo = ref[p].astype(np.int64) - 1                     # 0-based lower neighbour
+            if np.any(lo < -1) or np.any(lo > np.asarray(grid) - 1):
+                continue
+            for s in range(1 << n_out):
+                idx, w = [], ow[b] * pw[p]
+                ok = True
+                for d in range(n_out):
+                    sd = (s >> d) & 1
+                    i = lo[d] + sd
+                    ok = ok and 0 <= i < grid[d]
+                    idx.append(i)
+                    w *= delta[p, d] if sd else (1.0 - delta[p, d])
+                if ok:
+                    out[tuple(idx) + (b,)] += w
+    return out
+
+
+@pytest.mark.parametrize("n_in,n_out", [(1, 2), (2, 3), (1, 3), (4, 1), (4, 2), (4, 3), (4, 4), (2, 4), (3, 4), (1, 4)])
+def test_dimension_pairs_beyond_the_tested_three_follow_appendix_a(oracle, n_in, n_out):
+    """(N_in, N_out) pairs the reference's tests do not use -- embeddings with N_out > N_in and 4-D points / grids
+    included: the oracle's dimension-generic loops against the numpy restatement above, and its pullback against
+    central differences of its forward."""
+    rng = np.random.default_rng(40 + 10 * n_in + n_out)
+    grid = tuple(int(x) for x in rng.integers(3, 7, size=n_out))
+    P, B = 40, 2
+    pts = 0.5 * rng.normal(size=(P, n_in))
+    R = 0.7 * rng.normal(size=(B, n_out, n_in))
+    t = 0.1 * rng.normal(size=(B, n_out))
+    bg, ow, pw = rng.normal(size=B), rng.uniform(0.5, 2, size=B), rng.uniform(0.2, 1, size=P)
+    out = oracle.raster(grid, pts, R, t, bg, ow, pw)
+    np.testing.assert_allclose(out, _appendix_a_numpy(grid, pts, R, t, bg, ow, pw), rtol=1e-12, atol=1e-12)
+    g = np.asfortranarray(rng.normal(size=grid + (B,)))
+    pb = oracle.raster_pullback(g, pts, R, t, ow, pw)
+    f = lambda **kw: float(np.sum(g * oracle.raster(grid, kw.get("pts", pts), kw.get("R", R), kw.get("t", t), bg,
+                                                    kw.get("ow", ow), kw.get("pw", pw))))
+    h = 1e-6
+    for name, arr, got in (("pts", pts, pb.points), ("R", R, pb.rotation), ("t", t, pb.translation),
+                           ("ow", ow, pb.out_weight), ("pw", pw, pb.point_weight)):
+        it = np.nditer(arr, flags=["multi_index"])
+        for k, _ in enumerate(it):
+            if k % 3:  # (a third of the entries)
+                continue
+            idx = it.multi_index
+            ap = arr.copy(); ap[idx] += h
+            am = arr.copy(); am[idx] -= h
+            fdv = (f(**{name: ap}) - f(**{name: am})) / (2 * h)
+            assert abs(got[idx] - fdv) <= 1e-5 * max(1.0, abs(fdv)), (name, idx, got[idx], fdv)

@@ -188,7 +188,7 @@ def test_pullback_without_the_point_weight_gradient(oracle, dev, algo, npdt, tdt
 def test_other_dimension_pairs_on_the_direct_kernels(oracle, dev, algo, npdt, tdt, n_in, n_out,
                                                      n_points, grid_n):
     """The reference is generic in (N_in, N_out) (src/raster.jl:5-13, src/util.jl:26-27); beyond
-    the three shapes its tests use, 1 <= N_out <= N_in <= 3 runs on the direct kernels: AUTO
+    the three shapes its tests use, every other pair runs on the direct kernels: AUTO
     resolves to them, the other algorithms are refused."""
     d = D.make(n_points=n_points, n_in=n_in, n_out=n_out, batch=D.uneven_batch(4), grid_n=grid_n,
                seed=19, dtype=npdt)
@@ -196,6 +196,22 @@ def test_other_dimension_pairs_on_the_direct_kernels(oracle, dev, algo, npdt, td
     _compare(*_run_both(oracle, dev, d, npdt, algo), npdt)
     with pytest.raises(dpr_amd.DprError):
         dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), algo="tiled")
+
+
+@pytest.mark.parametrize("npdt,tdt", DTYPES)
+@pytest.mark.parametrize("n_in,n_out,grid_n", [(1, 2, 40), (1, 3, 20), (2, 3, 24), (4, 1, 300), (4, 2, 50), (4, 3, 21),
+                                               (4, 4, 11), (3, 4, 9), (2, 4, (7, 9, 5, 6)), (1, 4, 8)])
+def test_embeddings_and_four_dimensions_on_the_direct_kernels(oracle, dev, npdt, tdt, n_in, n_out, grid_n):
+    """1 <= N_in, N_out <= 4 in ANY combination (round 6): embeddings with N_out > N_in and 4-D points / grids, which
+    the reference's generic signatures (src/raster.jl:5-13) admit and its tests never exercise; forward and pullback
+    against the oracle (itself checked for these pairs against a numpy restatement and central differences,
+    tests/test_oracle_golden.py), optional arguments included, uneven batch."""
+    d = D.make(n_points=20_000, n_in=n_in, n_out=n_out, batch=D.uneven_batch(4), grid_n=grid_n, seed=23, dtype=npdt)
+    assert dpr_amd.resolve_algo("raster", d.grid, d.n_points, d.batch, n_in) == "atomic"
+    assert dpr_amd.resolve_algo("pullback", d.grid, d.n_points, d.batch, n_in, sharing=True) == "atomic"
+    _compare(*_run_both(oracle, dev, d, npdt, "auto"), npdt)
+    with pytest.raises(dpr_amd.DprError):
+        dpr_amd.raster(d.grid, T(d.points, dev), T(d.rotations, dev), T(d.translations, dev), algo="chunked")
 
 
 @pytest.mark.parametrize("algo", ALGOS)
