@@ -122,6 +122,13 @@ if glob.glob(f"{O}/fetch_c5/*/*_counter_collection.csv"):
                                           "write_bytes": round(tot[grp][2]), "hbm_bytes_corrected": round(tot[grp][1] + tot[grp][2]),
                                           "hbm_bytes_upper_bound": round(2 * tot[grp][0] + tot[grp][2]),
                                           "collected_with": f"bench.py --config C5 --poses 8 ({ncall} calls in the profiled run)"}
+    # the whole 64-pose job runs its forward in eight batches of 8 poses (one cell sort + binning per batch) and its
+    # pullback per 64-pose launch: the forward's traffic is 8 x the share's; recorded as such (not a PMC pass of its own)
+    e = dict(out["forward"]["C5/tiled/random/B8"])
+    for k in ("fetch_bytes_raw", "fetch_bytes_corrected", "write_bytes", "hbm_bytes_corrected", "hbm_bytes_upper_bound"):
+        e[k] = 8 * e[k]
+    e["collected_with"] = "8 x the C5/tiled/random/B8 entry (the forward walks the 64 poses in batches of 8); no PMC pass of its own"
+    out["forward"]["C5/tiled/random/B64"] = e
 json.dump(out, open("profiles/r06_hbm_traffic.json", "w"), indent=1)
 for grp in ("forward", "pullback"):
     for k, v in out[grp].items():
