@@ -366,6 +366,97 @@ function raster_pullback_reuse_batch!(ds_dout::ROCArray{T,N_out_p1}, points::ROC
             point_weight=o_pw)
 end
 
+# ---- optional: pose-independent Hilbert pre-sort of a cloud (not in the reference) -----------------
+# For callers that optimise poses over a FIXED cloud (the reference's use case, examples/logo.jl): sort
+# once, then pass `coherent=true` to `raster_coherent!` / `raster_pullback_coherent!` below
+# (DPR_FLAG_COHERENT_POINTS: a wrong claim costs time, never correctness).  Returns the sorted points, the
+# sorted point weights (or `nothing`) and `perm` with points_sorted[i] = points[perm[i] + 1]; gradients of
+# the sorted cloud go back with ds_dpoints[:, perm .+ 1] = ds_dpoints_sorted.
+const DPR_FLAG_COHERENT_POINTS = Cuint(4)
+
+function sort_points(points::ROCVector{<:StaticVector{N_in,T}},
+                     point_weight::Union{Nothing,ROCVector{T}}=nothing) where {N_in,T<:Union{Float32,Float64}}
+    P = length(points)
+    sorted = similar(points)
+    perm = ROCVector{UInt32}(undef, P)
+    pw_sorted = point_weight === nothing ? nothing : similar(point_weight)
+    nbytes = ccall((:dpr_sort_points_workspace_bytes, libdpr), Csize_t, (Int64,), P)
+    ws = ROCVector{UInt8}(undef, max(nbytes, 16))
+    stream = AMDGPU.stream()
+    sym = T === Float32 ? :dpr_sort_points_f32 : :dpr_sort_points_f64
+    GC.@preserve points sorted perm point_weight pw_sorted ws begin
+        check(ccall((sym, libdpr), Cint,
+            (Ptr{Cvoid}, Cint, Int64, Ptr{T}, Ptr{T}, Ptr{UInt32}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
+            stream.stream, N_in, P, devptr(points, T), devptr(sorted, T),
+            Ptr{UInt32}(UInt(pointer(perm))),
+            point_weight === nothing ? Ptr{T}(C_NULL) : devptr(point_weight, T),
+            pw_sorted === nothing ? Ptr{T}(C_NULL) : devptr(pw_sorted, T),
+            Ptr{Cvoid}(UInt(pointer(ws))), length(ws)))
+    end
+    keep_until_done(stream, ws)
+    return sorted, pw_sorted, perm
+end
+
+# raster! on a cloud the caller vouches for (sorted by `sort_points`): the plain entry point with the flag
+function raster_coherent!(out::ROCArray{T,N_out_p1}, points::ROCVector{<:StaticVector{N_in,T}},
+                          rotation::AbstractVector{<:StaticMatrix{N_out,N_in}},
+                          translation::AbstractVector{<:StaticVector{N_out}},
+                          background, out_weight, point_weight) where {T,N_in,N_out,N_out_p1}
+    B, P = length(rotation), length(points)
+    rot, tr = devbuf(rotation, T), devbuf(translation, T)
+    bg, ow, pw = devbuf(background, T), devbuf(out_weight, T), devbuf(point_weight, T)
+    grid = collect(Int64, size(out)[1:N_out])
+    wsym = T === Float32 ? :dpr_workspace_bytes_ex_f32 : :dpr_workspace_bytes_ex_f64
+    nbytes = ccall((wsym, libdpr), Csize_t, (Cint, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64),
+        0, 0, DPR_FLAG_COHERENT_POINTS, N_in, N_out, grid, P, B)
+    ws = ROCVector{UInt8}(undef, max(nbytes, 16))
+    stream = AMDGPU.stream()
+    sym = T === Float32 ? :dpr_raster_ex_f32 : :dpr_raster_ex_f64
+    GC.@preserve out points rot tr bg ow pw ws begin
+        check(ccall((sym, libdpr), Cint,
+            (Ptr{Cvoid}, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
+            stream.stream, DPR_ALGO_AUTO, DPR_FLAG_COHERENT_POINTS, N_in, N_out, grid, P, B,
+            devptr(out, T), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(bg, T),
+            devptr(ow, T), devptr(pw, T), Ptr{Cvoid}(UInt(pointer(ws))), length(ws)))
+    end
+    keep_until_done(stream, rot, tr, bg, ow, pw, ws)
+    return out
+end
+
+# raster_pullback! on such a cloud (flat outputs as in ext/DiffPointRasterisationCUDAExt.jl:231-321)
+function raster_pullback_coherent!(ds_dout::ROCArray{T,N_out_p1}, points::ROCVector{<:StaticVector{N_in,T}},
+                                   rotation::AbstractVector{<:StaticMatrix{N_out,N_in}},
+                                   translation::AbstractVector{<:StaticVector{N_out}},
+                                   out_weight, point_weight; want_pw::Bool=true) where {T,N_in,N_out,N_out_p1}
+    P, B = length(points), size(ds_dout, N_out_p1)
+    rot, tr = devbuf(rotation, T), devbuf(translation, T)
+    ow, pw = devbuf(out_weight, T), devbuf(point_weight, T)
+    o_pts = similar(ds_dout, T, (N_in, P))
+    o_rot, o_tr = similar(ds_dout, T, (N_out, N_in, B)), similar(ds_dout, T, (N_out, B))
+    o_bg, o_ow = similar(ds_dout, T, B), similar(ds_dout, T, B)
+    o_pw = want_pw ? similar(ds_dout, T, P) : nothing
+    flags = DPR_FLAG_COHERENT_POINTS | (want_pw ? Cuint(0) : DPR_FLAG_NO_POINT_WEIGHT_GRAD)
+    grid = collect(Int64, size(ds_dout)[1:N_out])
+    wsym = T === Float32 ? :dpr_workspace_bytes_ex_f32 : :dpr_workspace_bytes_ex_f64
+    nbytes = ccall((wsym, libdpr), Csize_t, (Cint, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64),
+        1, 0, flags, N_in, N_out, grid, P, B)
+    ws = ROCVector{UInt8}(undef, max(nbytes, 16))
+    stream = AMDGPU.stream()
+    sym = T === Float32 ? :dpr_raster_pullback_ex_f32 : :dpr_raster_pullback_ex_f64
+    GC.@preserve ds_dout points rot tr ow pw o_pts o_rot o_tr o_bg o_ow o_pw ws begin
+        check(ccall((sym, libdpr), Cint,
+            (Ptr{Cvoid}, Cint, Cuint, Cint, Cint, Ptr{Int64}, Int64, Int64, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{Cvoid}, Csize_t),
+            stream.stream, DPR_ALGO_AUTO, flags, N_in, N_out, grid, P, B,
+            devptr(ds_dout, T), devptr(points, T), devptr(rot, T), devptr(tr, T), devptr(ow, T),
+            devptr(pw, T), devptr(o_pts, T), devptr(o_rot, T), devptr(o_tr, T), devptr(o_bg, T),
+            devptr(o_ow, T), want_pw ? devptr(o_pw, T) : Ptr{T}(C_NULL), Ptr{Cvoid}(UInt(pointer(ws))),
+            length(ws)))
+    end
+    keep_until_done(stream, rot, tr, ow, pw, ws)
+    return (; points=o_pts, rotation=o_rot, translation=o_tr, background=o_bg, out_weight=o_ow,
+            point_weight=o_pw)
+end
+
 # The ChainRules `rrule` for ROCArray points (forward keeps the binning, the pullback closure
 # reuses it: `raster_keep!` / `raster_pullback_reuse!` above) needs BOTH AMDGPU and ChainRulesCore
 # and therefore lives in its own two-trigger extension,

@@ -87,3 +87,32 @@ end
         @test Array(again[4]) ≈ ref.rotation
     end
 end
+
+@testitem "AMDGPU sorted cloud with the coherence flag" begin
+    # sort_points + raster_coherent! / raster_pullback_coherent! (not in the reference: dpr.h
+    # dpr_sort_points_*, DPR_FLAG_COHERENT_POINTS) against the CPU path on the ORIGINAL order
+    using Adapt, AMDGPU, StaticArrays, FillArrays
+    include("data.jl")
+    include("util_amdgpu.jl")
+    if AMDGPU.functional()
+        ext = Base.get_extension(DiffPointRasterisation, :DiffPointRasterisationAMDGPUExt)
+        pts = adapt(ROCArray, D.more_points)
+        sorted, _, perm = ext.sort_points(pts)
+        p = Array(perm) .+ 1
+        @test Array(sorted) == D.more_points[p]
+        out = AMDGPU.zeros(Float64, D.grid_size_3d..., D.batch_size)
+        B = D.batch_size
+        ext.raster_coherent!(out, sorted, D.rotations_static, D.translations_3d_static,
+                             Zeros(Float64, B), Ones(Float64, B), Ones(Float64, length(p)))
+        @test Array(out) ≈ raster(D.grid_size_3d, D.more_points, D.rotations_static, D.translations_3d_static)
+        g = randn(D.grid_size_3d..., B)
+        ref = raster_pullback!(g, D.more_points, D.rotations_static, D.translations_3d_static)
+        got = ext.raster_pullback_coherent!(adapt(ROCArray, g), sorted, D.rotations_static,
+                                            D.translations_3d_static, Ones(Float64, B), Ones(Float64, length(p)))
+        back = similar(ref.points)
+        back[:, p] = Array(got.points)   # ds_dpoints[perm[i]] = ds_dpoints_sorted[i]
+        @test back ≈ ref.points
+        @test Array(got.rotation) ≈ ref.rotation
+        @test Array(got.translation) ≈ ref.translation
+    end
+end
