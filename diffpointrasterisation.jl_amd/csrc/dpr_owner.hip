@@ -64,9 +64,20 @@ constexpr int kSC = 16;              // points per sub-chunk (level-0 box, one l
 constexpr int kFan = 64;             // sub-chunks per chunk (level-1 box, one wave's box tests)
 constexpr int kL1 = kSC * kFan;      // 1024 points
 constexpr int kL2 = 64;              // chunks per level-2 box (65536 points)
-constexpr int kOT = 1024;            // threads of the tile kernels
+// (experiment builds override the tile kernels' block and tile: -DDPR_OWN_THREADS=512 -DDPR_OWN_TY=16 -DDPR_OWN_TZ=13
+// is the half tile that fits two workgroups per CU, profiles/r06_experiments.md)
+#ifndef DPR_OWN_THREADS
+#define DPR_OWN_THREADS 1024
+#endif
+#ifndef DPR_OWN_TY
+#define DPR_OWN_TY 32
+#endif
+#ifndef DPR_OWN_TZ
+#define DPR_OWN_TZ 14
+#endif
+constexpr int kOT = DPR_OWN_THREADS; // threads of the tile kernels
 constexpr int kOW = kOT / kWave;     // 16 waves
-constexpr int kTX = 32, kTY = 32, kTZ = 14;
+constexpr int kTX = 32, kTY = DPR_OWN_TY, kTZ = DPR_OWN_TZ;
 constexpr int kCells = kTX * kTY * kTZ;                     // 14336 owned cells
 // forward: the LDS tile is PADDED by one cell on every side (34 x 34 x 16 cells of 8 bytes = 148 KB):
 // all eight neighbours of every point the tile looks at have a cell, no ownership tests; the pad

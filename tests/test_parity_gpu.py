@@ -802,8 +802,14 @@ def test_dimension_errors(dev):
         dpr_amd.raster_(dpr_amd.empty_grid((4, 4), 2, torch.float64, dev), pts, R, t)
     with pytest.raises(dpr_amd.DimensionMismatch):
         dpr_amd.raster_pullback_(dpr_amd.empty_grid((4, 4, 4), 3, torch.float64, dev), pts, R, t)
-    with pytest.raises(dpr_amd.DprError):  # 2 -> 3 is rejected by the library itself
-        dpr_amd.raster((4, 4, 4), torch.zeros(5, 2, **f64), torch.zeros(1, 3, 2, **f64),
+    # an embedding 2 -> 3 is a legal pair since round 6 (1 <= N_in, N_out <= 4: the reference's generic
+    # signatures, src/raster.jl:5-13) ...
+    out = dpr_amd.raster((4, 4, 4), torch.zeros(5, 2, **f64), torch.zeros(1, 3, 2, **f64),
+                         torch.zeros(1, 3, **f64))
+    assert tuple(out.shape)[-3:] == (4, 4, 4) or tuple(out.shape)[:3] == (4, 4, 4)
+    # ... five dimensions are rejected by the library itself (DPR_ERR_UNSUPPORTED_DIMS)
+    with pytest.raises(dpr_amd.DprError):
+        dpr_amd.raster((4, 4, 4), torch.zeros(5, 5, **f64), torch.zeros(1, 3, 5, **f64),
                        torch.zeros(1, 3, **f64))
 
 
