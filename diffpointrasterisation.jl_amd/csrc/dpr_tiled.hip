@@ -2596,8 +2596,12 @@ __global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) vo
             }
         }
         };
+#if defined(DPR_ABL) && DPR_ABL == 6  // ablation: the ds_dout tile is not staged (timing only, wrong results)
+        (void)stage_rows;
+#else
         if ((item.part_nparts >> 16) > 1) stage_rows(std::false_type{});
         else stage_rows(std::true_type{});
+#endif
         // the x == TX column (halo cells only): one cell per row
         for (int row = threadIdx.x; row < ROWS; row += GT) {
             const int l1 = row % (TY + 1), l2 = (NO == 3) ? row / (TY + 1) : 0;
@@ -2620,6 +2624,9 @@ __global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) vo
     pin_record(nxt);
     if (HAS_PW && !UNPERM) pin_value(nxt_idx);
     drain_vmem();
+#if defined(DPR_ABL) && DPR_ABL == 5  // ablation: no record loop (dispatch, ds_dout staging, reductions only)
+    r = r1;
+#endif
     while (r < r1) {
         const Rec4<T> rc = nxt;
         const uint32_t p = HAS_PW ? nxt_idx : slot_to_idx(rc.v[3]);
@@ -2654,12 +2661,19 @@ __global__ __launch_bounds__(gather_threads<T>(), gather_waves_per_simd<T>()) vo
         bool interior = true;
 #pragma unroll
         for (int d = 0; d < NO; ++d) interior = interior && low_ok[d];
+#if defined(DPR_ABL) && DPR_ABL == 4  // ablation: the record loop WITHOUT its 2^N LDS reads (timing only, wrong results)
+        if (interior) {
+#pragma unroll
+            for (int s = 0; s < (1 << NO); ++s) gv[s] = (T)(lds_index<NO>(lb) + s);
+        } else {
+#else
         if (interior) {
             // common case: one base address, neighbours at compile-time offsets
             const T* base = &tile_g[lds_index<NO>(lb)];
 #pragma unroll
             for (int s = 0; s < (1 << NO); ++s) gv[s] = base[nbr_lds_offset<NO>(s)];
         } else {
+#endif
 #pragma unroll
             for (int s = 0; s < (1 << NO); ++s) {
                 int l[NO];
