@@ -1700,6 +1700,9 @@ __device__ __forceinline__ void splat_record(const R& rc, bool active, const Pos
         if (sink == 0x123456789abcull) acc[threadIdx.x] = 1.0;
     }
     return;
+#elif defined(DPR_ABL) && DPR_ABL == 7  // ablation: records loaded and looked at, NO arithmetic, NO LDS atomics
+    if (active && __float_as_uint((float)pt[0]) == 0x12345678u) acc[threadIdx.x] = 1.0;
+    return;
 #elif defined(DPR_ABL) && DPR_ABL == 2  // ablation: the LDS atomics only, at pseudo-random cells
     if (active) {
         uint32_t h = __float_as_uint((float)pt[0]) * 2654435761u;
