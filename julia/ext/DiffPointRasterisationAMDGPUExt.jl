@@ -368,7 +368,7 @@ end
 
 # ---- optional: pose-independent Hilbert pre-sort of a cloud (not in the reference) -----------------
 # For callers that optimise poses over a FIXED cloud (the reference's use case, examples/logo.jl): sort
-# once, then pass `coherent=true` to `raster_coherent!` / `raster_pullback_coherent!` below
+# once, then call `raster_coherent!` / `raster_pullback_coherent!` below on the sorted cloud
 # (DPR_FLAG_COHERENT_POINTS: a wrong claim costs time, never correctness).  Returns the sorted points, the
 # sorted point weights (or `nothing`) and `perm` with points_sorted[i] = points[perm[i] + 1]; gradients of
 # the sorted cloud go back with ds_dpoints[:, perm .+ 1] = ds_dpoints_sorted.
